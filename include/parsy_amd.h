@@ -1,0 +1,228 @@
+/*
+ * parsy_amd.h -- C ABI of the MI355X-native supernodal Cholesky + BCSC
+ * triangular-solve executor (libparsy_amd.so).
+ *
+ * Section 1 are DROP-IN replacements: same names, argument lists, ownership
+ * and return values as the reference's executors, so the reference's drivers
+ * (examples/choleskyTest01.cpp, choleskyTest03.cpp, triangularTest02.cpp) can
+ * link this library instead of including the OpenMP headers.  All pointers
+ * are caller-owned HOST pointers; the library uploads the pattern once per
+ * distinct pointer set (cached plan) and runs every numeric step in HIP
+ * kernels on the selected device.  There is no CPU fallback: when no HIP
+ * device is usable the functions fail loudly (stderr + false / 0).
+ *
+ * Section 2 is the plan (handle) API the drop-ins are built on: pattern
+ * resident in HBM, device pointers in / out, caller-supplied stream.
+ *
+ * Section 3/4 are host-side helpers (inspector, synthetic matrices) so the
+ * path can be exercised without the reference's inspector.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types.
+ */
+#ifndef PARSY_AMD_H
+#define PARSY_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* 1. Drop-in operators                                                      */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces cholesky_left_par_05, reference cholesky/parallel_PB_Cholesky_05.h:27-39.
+ *   n            matrix order
+ *   c, r, values CSC of the LOWER triangle of P A P' (reference's A2)
+ *   lC           value offset of every column of L (size n+1)          [L->p]
+ *   lR           sorted row ids of every supernode (size ssize)        [L->s]
+ *   Li_ptr       offset into lR for every column (size n+1)            [L->i_ptr]
+ *   lValues      OUT: BCSC values (size lC[n]); must be zeroed by the caller
+ *   blockSet     first column of every supernode (size supNo+1)        [L->super]
+ *   timing       OUT: [0] seconds of the level-parallel phase, [1] seconds of
+ *                the root phase (the GPU schedule has no separate root phase:
+ *                [1] = 0), [2] device seconds of the numeric kernels only
+ *   aTree        supernodal etree (-1 root)                            [L->sParent]
+ *   cT, rT       CSC pattern of the UPPER triangle of P A P' (reference's A1)
+ *   col2Sup      column -> supernode
+ *   nLevels, levelPtr, levelSet, nPar, parPtr, partition: H-level schedule of the
+ *                reference's inspector.  The factor is schedule independent; the
+ *                GPU executor validates the partition (every supernode exactly
+ *                once) and schedules by etree level itself.
+ *   chunk, threads, super_max, col_max, nodCost: accepted for signature
+ *                compatibility, unused (the reference ignores chunk/nodCost too).
+ * Returns false iff a diagonal block is not positive definite (lValues is then
+ * partial) or the device path could not run. */
+bool cholesky_left_par_05(int n, int* c, int* r, double* values, size_t* lC, int* lR,
+                          size_t* Li_ptr, double* lValues, int* blockSet, int supNo,
+                          double* timing, int* aTree, int* cT, int* rT, int* col2Sup,
+                          int nLevels, int* levelPtr, int* levelSet, int nPar, int* parPtr,
+                          int* partition, int chunk, int threads, int super_max, int col_max,
+                          double* nodCost);
+
+/* Replaces cholesky_left_par_waveFront, reference
+ * cholesky/Parallel_PB_Cholesky_wavefront.h:10-20.  levelPtr/levelSet are etree
+ * level sets (common/TreeUtils.h:119).  Like the reference it reports `true`
+ * unless the device path could not run; a non-positive pivot is reported on
+ * stderr only (the reference ignores LAPACK's info here, :137). */
+bool cholesky_left_par_waveFront(int n, int* c, int* r, double* values, size_t* lC, int* lR,
+                                 size_t* Li_ptr, double* lValues, int* blockSet, int supNo,
+                                 double* timing, int* aTree, int* cT, int* rT, int* col2Sup,
+                                 int nLevels, int* levelPtr, int* levelSet, int chunk,
+                                 int threads, int super_max, int col_max);
+
+/* Replace the BCSC forward solves L x = b (x in/out, one right-hand side),
+ * reference triangularSolve/Triangular_BCSC.h:14 / :115 / :171 / :238.
+ * Return 1 on success, 0 when Lp, Li or x is NULL (as the reference) or when
+ * the device path could not run.  NNZ, col2sup and chunk are unused, as in the
+ * reference.  All four run the same level-scheduled HIP solve; the level /
+ * partition arrays are validated, not interpreted. */
+int blockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                  int* col2sup, int* sup2col, int supNo, double* x);
+int leveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                         int* col2sup, int* sup2col, int supNo, double* x, int levels,
+                         int* levelPtr, int* levelSet, int chunk);
+int H2LeveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                           int* col2sup, int* sup2col, int supNo, double* x, int levels,
+                           int* levelPtr, int* levelSet, int parts, int* parPtr,
+                           int* partition, int chunk);
+int H2LeveledBlockedLsolve_Peeled(int n, size_t* Lp, int* Li, double* Lx, int NNZ,
+                                  size_t* Li_ptr, int* col2sup, int* sup2col, int supNo,
+                                  double* x, int levels, int* levelPtr, int* levelSet,
+                                  int parts, int* parPtr, int* partition, int chunk,
+                                  int threads);
+
+/* Drop the plans cached by the drop-in operators (frees device memory). */
+void parsy_dropin_reset(void);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Plan API (pattern resident on the device)                              */
+/* ------------------------------------------------------------------------ */
+
+typedef struct parsy_plan parsy_plan;
+
+/* Sizes and work counts of a plan (all exact, from the pattern). */
+typedef struct parsy_plan_info {
+    int32_t n, nsuper, nlevels, max_width, max_rows;
+    int32_t n_small, n_big;        /* supernodes on the LDS-resident / tiled path */
+    int32_t chol_launches;         /* kernel launches per factorization */
+    int32_t solve_launches;        /* kernel launches per forward solve */
+    int64_t nnzA, ssize, xsize, nnzL;
+    int64_t n_updates;             /* (target, descendant) pairs */
+    int64_t relpos_len;            /* relative-index entries */
+    int64_t device_bytes;          /* pattern + schedule bytes resident in HBM */
+    double flops_stored;           /* executed flops on the stored structure */
+    double update_flops;           /* flops in the SYRK/GEMM update kernels */
+    double reread_bytes;           /* left-looking re-read traffic 8*sum K*nSupRs */
+} parsy_plan_info;
+
+/* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).
+ * device < 0 builds the host schedule only (no HIP call; for CPU-side tests).
+ * first_sn/last_sn restrict the plan to supernodes [first_sn, last_sn) plus
+ * nothing else when both are >= 0 (multi-GPU subtree shards); pass -1,-1 for all.
+ * Returns NULL on error (see parsy_last_error). */
+parsy_plan* parsy_plan_create(int n, int supNo, const int* blockSet, const size_t* lC,
+                              const size_t* Li_ptr, const int* lR, const int* aTree,
+                              const int* col2Sup, const int* cT, const int* rT, const int* c,
+                              const int* r, int device);
+void parsy_plan_destroy(parsy_plan* plan);
+int parsy_plan_get_info(const parsy_plan* plan, parsy_plan_info* info);
+
+/* Restrict the work of the NEXT factor/solve calls to a set of supernodes
+ * (multi-GPU: the subtrees this rank owns, or the root part).  mask has one
+ * byte per supernode (non-zero = process).  NULL restores "all". Rebuilds the
+ * launch schedule; not meant for the timed region. */
+int parsy_plan_set_active(parsy_plan* plan, const uint8_t* mask);
+
+/* Numeric factorization, everything on the device.
+ *   d_values  device, nnz(A2) doubles (same order as the host `values`)
+ *   d_lValues device, xsize doubles; zeroed and overwritten
+ *   stream    hipStream_t (NULL = default stream); the call is asynchronous
+ * Returns 0 when the launches were enqueued, <0 on a HIP error. */
+int parsy_factor_device(parsy_plan* plan, const double* d_values, double* d_lValues,
+                        void* stream);
+/* After the stream has been synchronised: 0 = factor ok, k > 0 = first
+ * non-positive pivot seen at (1-based) column k, as LAPACK's dpotrf info. */
+int parsy_factor_status(parsy_plan* plan);
+
+/* Forward solve L X = B in place, X is n x nrhs column-major with leading
+ * dimension ldx (device pointers). Asynchronous on `stream`. */
+int parsy_solve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs,
+                       int ldx, void* stream);
+
+/* Host-buffer conveniences (H2D + kernels + D2H, synchronous). `seconds`, if
+ * non-NULL, receives the device time of the numeric kernels alone. */
+int parsy_factor_host(parsy_plan* plan, const double* values, double* lValues, double* seconds);
+int parsy_solve_host(parsy_plan* plan, const double* lValues, double* x, int nrhs, int ldx,
+                     double* seconds);
+
+/* Device time (ms, hipEvents on the launch stream) of the last factor / solve
+ * enqueued through the *_device calls, after synchronisation; <0 if none. */
+double parsy_last_factor_ms(parsy_plan* plan);
+double parsy_last_solve_ms(parsy_plan* plan);
+
+/* Thread-local message of the last failing call. */
+const char* parsy_last_error(void);
+
+/* Number of visible HIP devices (0 when none / runtime unusable). */
+int parsy_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Inspector (host)                                                       */
+/* ------------------------------------------------------------------------ */
+
+typedef struct parsy_symbolic parsy_symbolic;
+
+/* Borrowed pointers into a parsy_symbolic (valid until it is freed).
+ * Names follow the reference's BCSC (common/def.h:117-204). */
+typedef struct parsy_symbolic_view {
+    int32_t n, nsuper, nlevels, maxSupWid, maxCol;
+    int64_t ssize, xsize, nnzL, nnzA, n_updates;
+    double flops_colcount, flops_stored;
+    const int* Perm;       /* n, new -> old */
+    const int* Parent;     /* n, column etree */
+    const int* ColCount;   /* n */
+    const int* super;      /* nsuper+1 */
+    const int* col2Sup;    /* n */
+    const int* sParent;    /* nsuper */
+    const size_t* p;       /* n+1 */
+    const size_t* i_ptr;   /* n+1 */
+    const int* s;          /* ssize */
+    const int* A1p; const int* A1i;                       /* upper PAP' pattern */
+    const int* A2p; const int* A2i; const double* A2x;    /* lower PAP' */
+    const int* A2src;      /* nnzA: position of each A2 entry in the input Ax */
+    const int* levelPtr;   /* nlevels+1 */
+    const int* levelSet;   /* nsuper */
+    const int64_t* updPtr; /* nsuper+1 */
+    const int* updSn; const int* updLb; const int* updUb; /* n_updates each */
+} parsy_symbolic_view;
+
+/* Ap/Ai/Ax: lower triangle, CSC, sorted (what common/Util.h:77 reads).
+ * perm: n entries new->old or NULL.  nrelax/zrelax: 3 entries each or NULL for
+ * the reference driver's defaults {4,16,48} / {0.8,0.1,0.05}. */
+parsy_symbolic* parsy_analyze(int n, const int* Ap, const int* Ai, const double* Ax,
+                              const int* perm, const int* nrelax, const double* zrelax);
+void parsy_symbolic_free(parsy_symbolic* sym);
+int parsy_symbolic_get(const parsy_symbolic* sym, parsy_symbolic_view* view);
+/* Plan straight from an inspector result. */
+parsy_plan* parsy_plan_from_symbolic(const parsy_symbolic* sym, int device);
+
+/* ------------------------------------------------------------------------ */
+/* 4. Synthetic SPD matrices / orderings (host)                              */
+/* ------------------------------------------------------------------------ */
+
+/* Lower triangle of a grid stencil matrix (5/9-point 2-D with nz = 1, 7/27-point
+ * 3-D): off-diagonals -1, diagonal = degree + shift.  Call with Ai = Ax = NULL to
+ * get the entry count; Ap needs nx*ny*nz+1 ints. Returns nnz or <0. */
+int64_t parsy_grid_spd_lower(int nx, int ny, int nz, int stencil, double shift, int* Ap,
+                             int* Ai, double* Ax);
+/* Geometric nested dissection, perm[new] = old, nx*ny*nz entries. */
+int parsy_grid_nested_dissection(int nx, int ny, int nz, int leaf, int* perm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARSY_AMD_H */

@@ -1,0 +1,699 @@
+/*
+ * parsy_oracle.c -- CPU restatement of the reference hot path.  TEST
+ * INFRASTRUCTURE ONLY: nothing under parsy_bench_amd/ (the product) may call,
+ * link or import this file; only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py use it, as the checker / the timed CPU port.
+ *
+ * What it restates (reference = cheshmi/parsy_bench, paths relative to its root):
+ *   oracle_cholesky_left_par_05        cholesky/parallel_PB_Cholesky_05.h:27-425
+ *   oracle_cholesky_left_par_waveFront cholesky/Parallel_PB_Cholesky_wavefront.h:10-171
+ *   oracle_ereach_sn                   common/Reach.h:112-143
+ *   oracle_blockedLsolve               triangularSolve/Triangular_BCSC.h:14-49
+ *   oracle_leveledBlockedLsolve        triangularSolve/Triangular_BCSC.h:115-164
+ *   oracle_H2LeveledBlockedLsolve      triangularSolve/Triangular_BCSC.h:171-232
+ *   oracle_H2LeveledBlockedLsolve_Peeled  triangularSolve/Triangular_BCSC.h:238-348
+ *   oracle_dlsolve_blas_nonUnit / oracle_dmatvec_blas  triangularSolve/BLAS.h:8-103 / :119-191
+ *   oracle_getLevelSet                 common/TreeUtils.h:119-169
+ *   oracle_rhsInitBlocked / oracle_testTriangular / oracle_bcsc2csc  common/Util.h:277-338
+ *
+ * Third-party arithmetic: the reference calls Intel MKL (version unpinned, taken
+ * from $MKLROOT, reference CMakeLists.txt:3-5) for dsyrk / dgemm / dpotrf / dtrsm
+ * (parallel_PB_Cholesky_05.h:160,173,204,218) and dtrsm / dgemv in the peeled
+ * solve (Triangular_BCSC.h:319,328).  MKL's headers are not in this image, so the
+ * executors themselves cannot be compiled here without writing stand-in headers
+ * (not done).  The four BLAS/LAPACK operations are restated below from their
+ * published (netlib reference BLAS / LAPACK) definitions; an optional run-time
+ * binding to a system BLAS (oracle_bind_blas) exists for the timed CPU baseline.
+ *
+ * PARITY PIN STATUS: pieces of the reference that compile from their own sources
+ * (ereach_sn, getLevelSet, dlsolve_blas_nonUnit, dmatvec_blas, MyBLAS.h's
+ * Cholesky_col / lSolve_dense_col and the inspector functions) are built into
+ * oracle/_ref by oracle/Makefile and this file is checked against them
+ * (tests/test_oracle_vs_ref.py; committed vectors in tests/golden/).  The
+ * assembled executors are pinned through those pieces plus the uniqueness of the
+ * Cholesky factor (checked against LAPACK via numpy and against L L' = P A P').
+ * There is no end-to-end run of the reference executors behind it: at executor
+ * level parity is UNPINNED ("Oracle").
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------ */
+/* dense kernels: netlib semantics, column-major                             */
+/* ------------------------------------------------------------------------ */
+
+typedef void (*syrk_fn)(const char*, const char*, const int*, const int*, const double*,
+                        const double*, const int*, const double*, double*, const int*);
+typedef void (*gemm_fn)(const char*, const char*, const int*, const int*, const int*,
+                        const double*, const double*, const int*, const double*, const int*,
+                        const double*, double*, const int*);
+typedef void (*potrf_fn)(const char*, const int*, double*, const int*, int*);
+typedef void (*trsm_fn)(const char*, const char*, const char*, const char*, const int*,
+                        const int*, const double*, const double*, const int*, double*,
+                        const int*);
+
+static syrk_fn ext_syrk = NULL;
+static gemm_fn ext_gemm = NULL;
+static potrf_fn ext_potrf = NULL;
+static trsm_fn ext_trsm = NULL;
+
+/* Bind the four operations to a Fortran-convention BLAS/LAPACK already loaded by
+ * the caller (function addresses; 0 = keep the built-in loops). */
+ORACLE_API void oracle_bind_blas(void* syrk, void* gemm, void* potrf, void* trsm) {
+    ext_syrk = (syrk_fn)syrk;
+    ext_gemm = (gemm_fn)gemm;
+    ext_potrf = (potrf_fn)potrf;
+    ext_trsm = (trsm_fn)trsm;
+}
+
+/* C(0:n,0:n) lower := A A', A is n x k with leading dimension lda (dsyrk 'L','N', beta=0) */
+static void k_syrk_ln(int n, int k, const double* A, int lda, double* C, int ldc) {
+    if (ext_syrk) {
+        const double one = 1.0, zero = 0.0;
+        ext_syrk("L", "N", &n, &k, &one, A, &lda, &zero, C, &ldc);
+        return;
+    }
+    for (int j = 0; j < n; ++j) {
+        double* cj = C + (size_t)j * ldc;
+        for (int i = j; i < n; ++i) cj[i] = 0.0;
+        for (int l = 0; l < k; ++l) {
+            const double t = A[j + (size_t)l * lda];
+            const double* al = A + (size_t)l * lda;
+            for (int i = j; i < n; ++i) cj[i] += t * al[i];
+        }
+    }
+}
+
+/* C(0:m,0:n) := A B', A m x k (lda), B n x k (ldb)  (dgemm 'N','C', beta=0) */
+static void k_gemm_nt(int m, int n, int k, const double* A, int lda, const double* B, int ldb,
+                      double* C, int ldc) {
+    if (ext_gemm) {
+        const double one = 1.0, zero = 0.0;
+        ext_gemm("N", "C", &m, &n, &k, &one, A, &lda, B, &ldb, &zero, C, &ldc);
+        return;
+    }
+    for (int j = 0; j < n; ++j) {
+        double* cj = C + (size_t)j * ldc;
+        for (int i = 0; i < m; ++i) cj[i] = 0.0;
+        for (int l = 0; l < k; ++l) {
+            const double t = B[j + (size_t)l * ldb];
+            const double* al = A + (size_t)l * lda;
+            for (int i = 0; i < m; ++i) cj[i] += t * al[i];
+        }
+    }
+}
+
+/* dpotrf 'L': unblocked left-looking (LAPACK dpotf2 order). info = j+1 at the
+ * first non-positive (or NaN) pivot, matrix left as LAPACK leaves it. */
+static int k_potrf_l(int n, double* A, int lda) {
+    if (ext_potrf) {
+        int info = 0;
+        ext_potrf("L", &n, A, &lda, &info);
+        return info;
+    }
+    for (int j = 0; j < n; ++j) {
+        double ajj = A[j + (size_t)j * lda];
+        for (int l = 0; l < j; ++l) ajj -= A[j + (size_t)l * lda] * A[j + (size_t)l * lda];
+        if (!(ajj > 0.0)) {
+            A[j + (size_t)j * lda] = ajj;
+            return j + 1;
+        }
+        ajj = sqrt(ajj);
+        A[j + (size_t)j * lda] = ajj;
+        if (j + 1 < n) {
+            for (int l = 0; l < j; ++l) {
+                const double t = A[j + (size_t)l * lda];
+                const double* al = A + (size_t)l * lda;
+                double* aj = A + (size_t)j * lda;
+                for (int i = j + 1; i < n; ++i) aj[i] -= t * al[i];
+            }
+            const double r = 1.0 / ajj;
+            double* aj = A + (size_t)j * lda;
+            for (int i = j + 1; i < n; ++i) aj[i] *= r;
+        }
+    }
+    return 0;
+}
+
+/* dtrsm 'R','L','C','N', alpha = 1:  B := B inv(A'), A n x n lower, B m x n */
+static void k_trsm_rltn(int m, int n, const double* A, int lda, double* B, int ldb) {
+    if (m <= 0 || n <= 0) return;
+    if (ext_trsm) {
+        const double one = 1.0;
+        ext_trsm("R", "L", "C", "N", &m, &n, &one, A, &lda, B, &ldb);
+        return;
+    }
+    for (int k = 0; k < n; ++k) {
+        const double r = 1.0 / A[k + (size_t)k * lda];
+        double* bk = B + (size_t)k * ldb;
+        for (int i = 0; i < m; ++i) bk[i] *= r;
+        for (int j = k + 1; j < n; ++j) {
+            const double t = A[j + (size_t)k * lda];
+            if (t != 0.0) {
+                double* bj = B + (size_t)j * ldb;
+                for (int i = 0; i < m; ++i) bj[i] -= t * bk[i];
+            }
+        }
+    }
+}
+
+/* exported for unit tests of the dense kernels */
+ORACLE_API void oracle_dsyrk_ln(int n, int k, const double* A, int lda, double* C, int ldc) {
+    k_syrk_ln(n, k, A, lda, C, ldc);
+}
+ORACLE_API void oracle_dgemm_nt(int m, int n, int k, const double* A, int lda, const double* B,
+                                int ldb, double* C, int ldc) {
+    k_gemm_nt(m, n, k, A, lda, B, ldb, C, ldc);
+}
+ORACLE_API int oracle_dpotrf_l(int n, double* A, int lda) { return k_potrf_l(n, A, lda); }
+ORACLE_API void oracle_dtrsm_rltn(int m, int n, const double* A, int lda, double* B, int ldb) {
+    k_trsm_rltn(m, n, A, lda, B, ldb);
+}
+
+/* ------------------------------------------------------------------------ */
+/* ereach_sn  (common/Reach.h:112-143)                                       */
+/* ------------------------------------------------------------------------ */
+/* s[top..n) receives the supernodes whose panels update columns col1..col2-1, in
+ * the order the reference applies them; w is an n-int workspace of non-negative
+ * values, returned unchanged (the reference marks by sign flip: CS_FLIP). */
+#define OR_FLIP(i) (-(i)-2)
+ORACLE_API int oracle_ereach_sn(int n, const int* Ap, const int* Ai, int col1, int col2,
+                                const int* col2sup, const int* parent, int* s, int* w) {
+    if (!Ap || !Ai || !parent || !s || !w) return -1;
+    int top = n;
+    for (int k = col1; k < col2; ++k) {
+        if (k == col1) w[col2sup[k]] = OR_FLIP(w[col2sup[k]]);
+        for (int p = Ap[k]; p < Ap[k + 1]; ++p) {
+            if (Ai[p] > k) continue;
+            int i = col2sup[Ai[p]];
+            int len = 0;
+            for (; w[i] >= 0; i = parent[i]) {
+                s[len++] = i;
+                w[i] = OR_FLIP(w[i]);
+            }
+            while (len > 0) s[--top] = s[--len];
+        }
+    }
+    for (int p = top; p < n; ++p) w[s[p]] = OR_FLIP(w[s[p]]);
+    w[col2sup[col1]] = OR_FLIP(w[col2sup[col1]]);
+    return top;
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-supernode numeric kernel (parallel_PB_Cholesky_05.h:96-219)           */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int* map;
+    double* contribs;
+    int* xi;
+    size_t contribs_len;
+} oracle_ws;
+
+static int ws_alloc(oracle_ws* W, int n, int supNo, size_t contribs_len) {
+    W->map = (int*)calloc((size_t)n > 0 ? (size_t)n : 1, sizeof(int));
+    W->contribs = (double*)calloc(contribs_len > 0 ? contribs_len : 1, sizeof(double));
+    W->xi = (int*)calloc((size_t)(2 * supNo) > 0 ? (size_t)(2 * supNo) : 1, sizeof(int));
+    W->contribs_len = contribs_len;
+    return W->map && W->contribs && W->xi;
+}
+static void ws_free(oracle_ws* W) {
+    free(W->map);
+    free(W->contribs);
+    free(W->xi);
+}
+
+/* s is 1-based as in the reference's loop variable (blockSet[s-1] .. blockSet[s]).
+ * Returns LAPACK-style info of dpotrf (0 = ok). */
+static int factor_supernode(int s, const int* c, const int* r, const double* values,
+                            const size_t* lC, const int* lR, const size_t* Li_ptr,
+                            double* lValues, const int* blockSet, int supNo, const int* aTree,
+                            const int* cT, const int* rT, const int* col2Sup, oracle_ws* W) {
+    int* map = W->map;
+    double* contribs = W->contribs;
+    int* xi = W->xi;
+    const int curCol = s != 0 ? blockSet[s - 1] : 0;
+    const int nxtCol = blockSet[s];
+    const int supWdt = nxtCol - curCol;
+    const int nSupR = (int)(Li_ptr[nxtCol] - Li_ptr[curCol]);
+    int cnt = 0;
+    for (size_t i = Li_ptr[curCol]; i < Li_ptr[nxtCol]; ++i) map[lR[i]] = cnt++;
+    for (int i = curCol; i < nxtCol; ++i)
+        for (int j = c[i]; j < c[i + 1]; ++j) lValues[lC[i] + map[r[j]]] = values[j];
+    double* cur = &lValues[lC[curCol]];
+    const int top = oracle_ereach_sn(supNo, cT, rT, curCol, nxtCol, col2Sup, aTree, xi, xi + supNo);
+    for (int it = top; it < supNo; ++it) {
+        const int lSN = xi[it];
+        const int cSN = blockSet[lSN], cNSN = blockSet[lSN + 1];
+        const size_t b = Li_ptr[cSN], e = Li_ptr[cNSN];
+        const int nSNRCur = (int)(e - b);
+        const int supWdts = cNSN - cSN;
+        int lb = 0, ub = 0, sw = 1;
+        for (size_t j = b; j < e; ++j) {
+            if (lR[j] >= curCol && sw) {
+                lb = (int)(j - b);
+                sw = 0;
+            }
+            if (lR[j] < curCol + supWdt && !sw) ub = (int)(j - b);
+            if (lR[j] >= curCol + supWdt) break;
+        }
+        const int nSupRs = nSNRCur - lb;
+        const int ndrow1 = ub - lb + 1;
+        const int ndrow3 = nSupRs - ndrow1;
+        if ((size_t)ndrow1 * (size_t)nSupRs > W->contribs_len) {
+            fprintf(stderr, "oracle: contribs scratch too small\n");
+            abort();
+        }
+        const double* src = &lValues[lC[cSN] + lb];
+        const double* srcL = &lValues[lC[cSN] + ub + 1];
+        k_syrk_ln(ndrow1, supWdts, src, nSNRCur, contribs, nSupRs);
+        if (ndrow3 > 0)
+            k_gemm_nt(ndrow3, ndrow1, supWdts, srcL, nSNRCur, src, nSNRCur, contribs + ndrow1,
+                      nSupRs);
+        for (int i = 0; i < ndrow1; ++i) {
+            const int col = map[lR[b + lb + i]];
+            for (int j = i; j < nSupRs; ++j) {
+                const int cRow = lR[b + lb + j];
+                cur[(size_t)col * nSupR + map[cRow]] -= contribs[(size_t)i * nSupRs + j];
+            }
+        }
+    }
+    const int info = k_potrf_l(supWdt, cur, nSupR);
+    if (info != 0) return curCol + info;
+    k_trsm_rltn(nSupR - supWdt, supWdt, cur, nSupR, cur + supWdt, nSupR);
+    return 0;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* cholesky/parallel_PB_Cholesky_05.h:27-425.  l-levels 0..nLevels-2 run their
+ * w-partitions in parallel (one OpenMP thread each, supernodes of a partition in
+ * order); the last l-level runs on one thread ("root phase", :269-411).
+ * Deviation kept deliberately small: scratch is allocated once per thread instead
+ * of once per w-partition (:75-77) -- same values, less allocator time. */
+ORACLE_API int oracle_cholesky_left_par_05(
+    int n, int* c, int* r, double* values, size_t* lC, int* lR, size_t* Li_ptr, double* lValues,
+    int* blockSet, int supNo, double* timing, int* aTree, int* cT, int* rT, int* col2Sup,
+    int nLevels, int* levelPtr, int* levelSet, int nPar, int* parPtr, int* partition, int chunk,
+    int threads, int super_max, int col_max, double* nodCost) {
+    (void)levelSet; (void)nPar; (void)chunk; (void)threads; (void)nodCost;
+    const size_t clen = (size_t)super_max * (size_t)col_max;
+    volatile int fail = 0;
+    double t0 = now_s();
+    for (int i1 = 0; i1 < nLevels - 1; ++i1) {
+#pragma omp parallel
+        {
+            oracle_ws W;
+            int ok = ws_alloc(&W, n, supNo, clen);
+#pragma omp for schedule(dynamic)
+            for (int j1 = levelPtr[i1]; j1 < levelPtr[i1 + 1]; ++j1) {
+                if (!ok || fail) continue;
+                for (int k1 = parPtr[j1]; k1 < parPtr[j1 + 1]; ++k1) {
+                    const int s = partition[k1] + 1;
+                    int info = factor_supernode(s, c, r, values, lC, lR, Li_ptr, lValues, blockSet,
+                                                supNo, aTree, cT, rT, col2Sup, &W);
+                    if (info != 0) {
+                        fail = info;
+                        break;
+                    }
+                }
+            }
+            ws_free(&W);
+        }
+        if (fail) return 0;
+    }
+    double t1 = now_s();
+    if (timing) timing[0] = t1 - t0;
+    {
+        oracle_ws W;
+        if (!ws_alloc(&W, n, supNo, clen)) return 0;
+        for (int j1 = levelPtr[nLevels - 1]; j1 < levelPtr[nLevels] && !fail; ++j1)
+            for (int k1 = parPtr[j1]; k1 < parPtr[j1 + 1]; ++k1) {
+                const int s = partition[k1] + 1;
+                /* the reference's root phase does not test info (:381); a failed
+                 * pivot there leaves NaNs behind -- report it instead */
+                int info = factor_supernode(s, c, r, values, lC, lR, Li_ptr, lValues, blockSet,
+                                            supNo, aTree, cT, rT, col2Sup, &W);
+                if (info != 0) {
+                    fail = info;
+                    break;
+                }
+            }
+        ws_free(&W);
+    }
+    if (timing) timing[1] = now_s() - t1;
+    return fail ? 0 : 1;
+}
+
+/* cholesky/Parallel_PB_Cholesky_wavefront.h:10-171: every etree level is one
+ * parallel loop over its supernodes. The reference ignores dpotrf's info and
+ * always returns true; the oracle returns 0 on a failed pivot so tests can see it. */
+ORACLE_API int oracle_cholesky_left_par_waveFront(
+    int n, int* c, int* r, double* values, size_t* lC, int* lR, size_t* Li_ptr, double* lValues,
+    int* blockSet, int supNo, double* timing, int* aTree, int* cT, int* rT, int* col2Sup,
+    int nLevels, int* levelPtr, int* levelSet, int chunk, int threads, int super_max,
+    int col_max) {
+    (void)threads;
+    const size_t clen = (size_t)super_max * (size_t)col_max;
+    volatile int fail = 0;
+    if (chunk < 1) chunk = 1;
+    double t0 = now_s();
+    for (int lev = 0; lev < nLevels; ++lev) {
+#pragma omp parallel
+        {
+            oracle_ws W;
+            int ok = ws_alloc(&W, n, supNo, clen);
+#pragma omp for schedule(dynamic, chunk)
+            for (int it = levelPtr[lev]; it < levelPtr[lev + 1]; ++it) {
+                if (!ok || fail) continue;
+                const int s = levelSet[it] + 1;
+                int info = factor_supernode(s, c, r, values, lC, lR, Li_ptr, lValues, blockSet,
+                                            supNo, aTree, cT, rT, col2Sup, &W);
+                if (info != 0) fail = info;
+            }
+            ws_free(&W);
+        }
+    }
+    if (timing) timing[0] = now_s() - t0;
+    return fail ? 0 : 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* dense solve kernels of the BCSC solves (triangularSolve/BLAS.h)           */
+/* ------------------------------------------------------------------------ */
+/* Column groups of 8 / 4 / 2 / 1 exactly as BLAS.h:18-102 so that the rounding
+ * of every partial sum is the reference's. */
+ORACLE_API void oracle_dlsolve_blas_nonUnit(int ldm, int ncol, const double* M, double* rhs) {
+    int first = 0;
+    const double* M0 = M;
+    while (first < ncol - 7) {
+        const double* m[8];
+        double x[8];
+        m[0] = M0;
+        for (int t = 1; t < 8; ++t) m[t] = m[t - 1] + ldm + 1;
+        x[0] = rhs[first] / *m[0]++;
+        x[1] = (rhs[first + 1] - x[0] * *m[0]++) / *m[1]++;
+        x[2] = (rhs[first + 2] - x[0] * *m[0]++ - x[1] * *m[1]++) / *m[2]++;
+        x[3] = (rhs[first + 3] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++) / *m[3]++;
+        x[4] = (rhs[first + 4] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++) /
+               *m[4]++;
+        x[5] = (rhs[first + 5] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++ -
+                x[4] * *m[4]++) /
+               *m[5]++;
+        x[6] = (rhs[first + 6] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++ -
+                x[4] * *m[4]++ - x[5] * *m[5]++) /
+               *m[6]++;
+        x[7] = (rhs[first + 7] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++ -
+                x[4] * *m[4]++ - x[5] * *m[5]++ - x[6] * *m[6]++) /
+               *m[7]++;
+        for (int t = 0; t < 8; ++t) rhs[first++] = x[t];
+        for (int k = first; k < ncol; ++k)
+            rhs[k] = rhs[k] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++ -
+                     x[4] * *m[4]++ - x[5] * *m[5]++ - x[6] * *m[6]++ - x[7] * *m[7]++;
+        M0 += 8 * ldm + 8;
+    }
+    while (first < ncol - 3) {
+        const double* m[4];
+        double x[4];
+        m[0] = M0;
+        for (int t = 1; t < 4; ++t) m[t] = m[t - 1] + ldm + 1;
+        x[0] = rhs[first] / *m[0]++;
+        x[1] = (rhs[first + 1] - x[0] * *m[0]++) / *m[1]++;
+        x[2] = (rhs[first + 2] - x[0] * *m[0]++ - x[1] * *m[1]++) / *m[2]++;
+        x[3] = (rhs[first + 3] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++) / *m[3]++;
+        for (int t = 0; t < 4; ++t) rhs[first++] = x[t];
+        for (int k = first; k < ncol; ++k)
+            rhs[k] = rhs[k] - x[0] * *m[0]++ - x[1] * *m[1]++ - x[2] * *m[2]++ - x[3] * *m[3]++;
+        M0 += 4 * ldm + 4;
+    }
+    if (first < ncol - 1) {
+        const double* m0 = M0;
+        const double* m1 = m0 + ldm + 1;
+        const double x0 = rhs[first] / *m0++;
+        const double x1 = (rhs[first + 1] - x0 * *m0++) / *m1++;
+        rhs[first++] = x0;
+        rhs[first++] = x1;
+        for (int k = first; k < ncol; ++k) rhs[k] = rhs[k] - x0 * *m0++ - x1 * *m1++;
+        M0 += 2 * ldm + 2;
+    }
+    if (first == ncol - 1) rhs[first] = rhs[first] / *M0;
+}
+
+/* Mxvec += M vec, groups of 8 / 4 / 1 columns as BLAS.h:119-191 */
+ORACLE_API void oracle_dmatvec_blas(int ldm, int nrow, int ncol, const double* M,
+                                    const double* vec, double* Mxvec) {
+    int first = 0;
+    const double* M0 = M;
+    while (first < ncol - 7) {
+        const double* m[8];
+        double v[8];
+        for (int t = 0; t < 8; ++t) {
+            m[t] = M0 + (size_t)t * ldm;
+            v[t] = vec[first++];
+        }
+        for (int k = 0; k < nrow; ++k)
+            Mxvec[k] += v[0] * m[0][k] + v[1] * m[1][k] + v[2] * m[2][k] + v[3] * m[3][k] +
+                        v[4] * m[4][k] + v[5] * m[5][k] + v[6] * m[6][k] + v[7] * m[7][k];
+        M0 += 8 * (size_t)ldm;
+    }
+    while (first < ncol - 3) {
+        const double* m[4];
+        double v[4];
+        for (int t = 0; t < 4; ++t) {
+            m[t] = M0 + (size_t)t * ldm;
+            v[t] = vec[first++];
+        }
+        for (int k = 0; k < nrow; ++k)
+            Mxvec[k] += v[0] * m[0][k] + v[1] * m[1][k] + v[2] * m[2][k] + v[3] * m[3][k];
+        M0 += 4 * (size_t)ldm;
+    }
+    while (first < ncol) {
+        const double v0 = vec[first++];
+        for (int k = 0; k < nrow; ++k) Mxvec[k] += v0 * M0[k];
+        M0 += ldm;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* BCSC forward solves (triangularSolve/Triangular_BCSC.h)                   */
+/* ------------------------------------------------------------------------ */
+static void solve_supernode(int i0, const size_t* Lp, const int* Li, const double* Lx,
+                            const size_t* Li_ptr, const int* sup2col, double* x, double* tempVec,
+                            int atomic) {
+    const int curCol = sup2col[i0], nxtCol = sup2col[i0 + 1];
+    const int supWdt = nxtCol - curCol;
+    const int nSupR = (int)(Li_ptr[nxtCol] - Li_ptr[curCol]);
+    oracle_dlsolve_blas_nonUnit(nSupR, supWdt, &Lx[Lp[curCol]], &x[curCol]);
+    oracle_dmatvec_blas(nSupR, nSupR - supWdt, supWdt, &Lx[Lp[curCol] + supWdt], &x[curCol], tempVec);
+    int k = 0;
+    for (size_t l = Li_ptr[curCol] + supWdt; l < Li_ptr[nxtCol]; ++l, ++k) {
+        if (atomic) {
+#pragma omp atomic
+            x[Li[l]] -= tempVec[k];
+        } else {
+            x[Li[l]] -= tempVec[k];
+        }
+        tempVec[k] = 0;
+    }
+}
+
+/* :14-49 -- supernodes in order 0..supNo-1, the deterministic solve order */
+ORACLE_API int oracle_blockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ,
+                                    size_t* Li_ptr, int* col2sup, int* sup2col, int supNo,
+                                    double* x) {
+    (void)NNZ; (void)col2sup;
+    if (!Lp || !Li || !x) return 0;
+    double* tempVec = (double*)calloc((size_t)n > 0 ? (size_t)n : 1, sizeof(double));
+    for (int i = 0; i < supNo; ++i) solve_supernode(i, Lp, Li, Lx, Li_ptr, sup2col, x, tempVec, 0);
+    free(tempVec);
+    return 1;
+}
+
+/* :115-164 -- one parallel loop per etree level, atomic scatter */
+ORACLE_API int oracle_leveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ,
+                                           size_t* Li_ptr, int* col2sup, int* sup2col, int supNo,
+                                           double* x, int levels, int* levelPtr, int* levelSet,
+                                           int chunk) {
+    (void)NNZ; (void)col2sup; (void)supNo; (void)chunk;
+    if (!Lp || !Li || !x) return 0;
+    for (int l = 0; l < levels; ++l) {
+#pragma omp parallel
+        {
+            double* tempVec = (double*)calloc((size_t)n > 0 ? (size_t)n : 1, sizeof(double));
+#pragma omp for schedule(dynamic)
+            for (int li = levelPtr[l]; li < levelPtr[l + 1]; ++li)
+                solve_supernode(levelSet[li], Lp, Li, Lx, Li_ptr, sup2col, x, tempVec, 1);
+            free(tempVec);
+        }
+    }
+    return 1;
+}
+
+/* :171-232 -- l-levels -> w-partitions in parallel -> supernodes in order */
+ORACLE_API int oracle_H2LeveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ,
+                                             size_t* Li_ptr, int* col2sup, int* sup2col,
+                                             int supNo, double* x, int levels, int* levelPtr,
+                                             int* levelSet, int parts, int* parPtr,
+                                             int* partition, int chunk) {
+    (void)NNZ; (void)col2sup; (void)supNo; (void)chunk; (void)levelSet; (void)parts;
+    if (!Lp || !Li || !x) return 0;
+    for (int i1 = 0; i1 < levels; ++i1) {
+#pragma omp parallel
+        {
+            double* tempVec = (double*)calloc((size_t)n > 0 ? (size_t)n : 1, sizeof(double));
+#pragma omp for schedule(dynamic)
+            for (int j1 = levelPtr[i1]; j1 < levelPtr[i1 + 1]; ++j1)
+                for (int k1 = parPtr[j1]; k1 < parPtr[j1 + 1]; ++k1)
+                    solve_supernode(partition[k1], Lp, Li, Lx, Li_ptr, sup2col, x, tempVec, 1);
+            free(tempVec);
+        }
+    }
+    return 1;
+}
+
+/* :238-348 -- as H2, but the last l-level is peeled and run on one thread with
+ * dtrsm ('L','L','N','N', one column) and dgemv; restated with netlib order:
+ * forward substitution by columns, then y = L21 x accumulated column by column. */
+ORACLE_API int oracle_H2LeveledBlockedLsolve_Peeled(int n, size_t* Lp, int* Li, double* Lx,
+                                                    int NNZ, size_t* Li_ptr, int* col2sup,
+                                                    int* sup2col, int supNo, double* x,
+                                                    int levels, int* levelPtr, int* levelSet,
+                                                    int parts, int* parPtr, int* partition,
+                                                    int chunk, int threads) {
+    (void)threads;
+    if (!Lp || !Li || !x) return 0;
+    if (levels > 1)
+        oracle_H2LeveledBlockedLsolve(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x,
+                                      levels - 1, levelPtr, levelSet, parts, parPtr, partition,
+                                      chunk);
+    double* tempVec = (double*)calloc((size_t)n > 0 ? (size_t)n : 1, sizeof(double));
+    for (int j1 = levelPtr[levels - 1]; j1 < levelPtr[levels]; ++j1)
+        for (int k1 = parPtr[j1]; k1 < parPtr[j1 + 1]; ++k1) {
+            const int i0 = partition[k1];
+            const int curCol = sup2col[i0], nxtCol = sup2col[i0 + 1];
+            const int w = nxtCol - curCol;
+            const int r = (int)(Li_ptr[nxtCol] - Li_ptr[curCol]);
+            const double* T = &Lx[Lp[curCol]];
+            double* xs = &x[curCol];
+            for (int k = 0; k < w; ++k) { /* dtrsm L,L,N,N with one right-hand side */
+                if (xs[k] != 0.0) {
+                    xs[k] /= T[k + (size_t)k * r];
+                    for (int i = k + 1; i < w; ++i) xs[i] -= xs[k] * T[i + (size_t)k * r];
+                }
+            }
+            const double* B = T + w;
+            for (int k = 0; k < r - w; ++k) tempVec[k] = 0.0;
+            for (int j = 0; j < w; ++j) { /* dgemv 'N' */
+                const double t = xs[j];
+                for (int k = 0; k < r - w; ++k) tempVec[k] += t * B[k + (size_t)j * r];
+            }
+            int k = 0;
+            for (size_t l = Li_ptr[curCol] + w; l < Li_ptr[nxtCol]; ++l, ++k) {
+                x[Li[l]] -= tempVec[k];
+                tempVec[k] = 0;
+            }
+        }
+    free(tempVec);
+    return 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* harness helpers                                                           */
+/* ------------------------------------------------------------------------ */
+/* common/TreeUtils.h:119-169: strip childless nodes level by level */
+ORACLE_API int oracle_getLevelSet(size_t n, const int* inTree, int* levelPtr, int* levelSet) {
+    int begin = 0, end = (int)n - 1;
+    int* nChild = (int*)calloc(n > 0 ? n : 1, sizeof(int));
+    char* visited = (char*)calloc(n > 0 ? n : 1, 1);
+    for (size_t k = 0; k < n; ++k)
+        if (inTree[k] >= 0) nChild[inTree[k]]++;
+    int curLevel = 0, cnt = 0;
+    levelPtr[0] = 0;
+    while (begin <= end) {
+        for (int i = begin; i <= end; ++i)
+            if (nChild[i] == 0 && !visited[i]) {
+                visited[i] = 1;
+                levelSet[cnt++] = i;
+            }
+        curLevel++;
+        levelPtr[curLevel] = cnt;
+        while (begin <= end && nChild[begin] == 0) begin++;
+        while (begin <= end && nChild[end] == 0) end--;
+        for (int l = levelPtr[curLevel - 1]; l < levelPtr[curLevel]; ++l) {
+            int cc = levelSet[l];
+            if (inTree[cc] >= 0) nChild[inTree[cc]]--;
+        }
+    }
+    free(nChild);
+    free(visited);
+    return curLevel;
+}
+
+/* common/Util.h:277-288: b = L * ones on the stored BCSC structure */
+ORACLE_API void oracle_rhsInitBlocked(size_t n, size_t nBlocks, const size_t* Ap, const int* Ai,
+                                      const size_t* AiP, const double* Ax, double* b) {
+    (void)nBlocks;
+    for (size_t j = 0; j < n; ++j) b[j] = 0;
+    for (size_t c = 0; c < n; ++c) {
+        size_t j = 0;
+        for (size_t cc = Ap[c]; cc < Ap[c + 1]; ++cc, ++j) b[Ai[AiP[c] + j]] += Ax[cc];
+    }
+}
+
+/* common/Util.h:294-306 (one-sided, as the reference) */
+ORACLE_API int oracle_testTriangular(size_t n, const double* x) {
+    size_t ok = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (1 - x[i] < 0.001) ok++;
+    return ok == n;
+}
+
+/* common/Util.h:311-338: drop the zero padding above the diagonal */
+ORACLE_API int oracle_bcsc2csc(size_t n, size_t nBlocks, const size_t* Ap, const int* Ai,
+                               const size_t* AiP, const int* sup2col, const double* Ax,
+                               int64_t* Cp, int* Ci, double* Cx) {
+    (void)n;
+    size_t nnz = 0;
+    Cp[0] = 0;
+    for (size_t i = 0; i < nBlocks; ++i) {
+        const int curCol = sup2col[i], nxtCol = sup2col[i + 1];
+        for (int j = curCol; j < nxtCol; ++j) {
+            size_t kk = AiP[curCol] + (size_t)(j - curCol);
+            for (size_t k = Ap[j] + (size_t)(j - curCol); k < Ap[j + 1]; ++k, ++kk) {
+                Cx[nnz] = Ax[k];
+                Ci[nnz] = Ai[kk];
+                nnz++;
+            }
+            Cp[j + 1] = (int64_t)nnz;
+        }
+    }
+    return 1;
+}
+
+ORACLE_API int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORACLE_API void oracle_set_threads(int t) {
+#ifdef _OPENMP
+    omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}

@@ -1,0 +1,149 @@
+"""ctypes binding of libparsy_amd.so (declared in include/parsy_amd.h).
+
+The library is the product; there is no Python or CPU fallback behind it.  If it
+is missing it is built on first use (hipcc cross-compiles without a GPU); if that
+fails, importing callers get a loud RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "libparsy_amd.so"
+_lib = None
+
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+c_size_p = C.POINTER(C.c_size_t)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class SymbolicView(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("nsuper", C.c_int32), ("nlevels", C.c_int32),
+        ("maxSupWid", C.c_int32), ("maxCol", C.c_int32),
+        ("ssize", C.c_int64), ("xsize", C.c_int64), ("nnzL", C.c_int64),
+        ("nnzA", C.c_int64), ("n_updates", C.c_int64),
+        ("flops_colcount", C.c_double), ("flops_stored", C.c_double),
+        ("Perm", c_int_p), ("Parent", c_int_p), ("ColCount", c_int_p),
+        ("super", c_int_p), ("col2Sup", c_int_p), ("sParent", c_int_p),
+        ("p", c_size_p), ("i_ptr", c_size_p), ("s", c_int_p),
+        ("A1p", c_int_p), ("A1i", c_int_p),
+        ("A2p", c_int_p), ("A2i", c_int_p), ("A2x", c_dbl_p), ("A2src", c_int_p),
+        ("levelPtr", c_int_p), ("levelSet", c_int_p),
+        ("updPtr", c_i64_p), ("updSn", c_int_p), ("updLb", c_int_p), ("updUb", c_int_p),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("nsuper", C.c_int32), ("nlevels", C.c_int32),
+        ("max_width", C.c_int32), ("max_rows", C.c_int32),
+        ("n_small", C.c_int32), ("n_big", C.c_int32),
+        ("chol_launches", C.c_int32), ("solve_launches", C.c_int32),
+        ("nnzA", C.c_int64), ("ssize", C.c_int64), ("xsize", C.c_int64), ("nnzL", C.c_int64),
+        ("n_updates", C.c_int64), ("relpos_len", C.c_int64), ("device_bytes", C.c_int64),
+        ("flops_stored", C.c_double), ("update_flops", C.c_double), ("reread_bytes", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/parsy_amd.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "cholesky_left_par_05", "cholesky_left_par_waveFront", "blockedLsolve",
+    "leveledBlockedLsolve", "H2LeveledBlockedLsolve", "H2LeveledBlockedLsolve_Peeled",
+    "parsy_dropin_reset", "parsy_plan_create", "parsy_plan_destroy", "parsy_plan_get_info",
+    "parsy_plan_set_active", "parsy_factor_device", "parsy_factor_status", "parsy_solve_device",
+    "parsy_factor_host", "parsy_solve_host", "parsy_last_factor_ms", "parsy_last_solve_ms",
+    "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
+    "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
+    "parsy_grid_nested_dissection",
+]
+
+
+def _declare(lib):
+    vp = C.c_void_p
+    lib.parsy_last_error.restype = C.c_char_p
+    lib.parsy_device_count.restype = C.c_int
+    lib.parsy_analyze.restype = vp
+    lib.parsy_analyze.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.parsy_symbolic_free.argtypes = [vp]
+    lib.parsy_symbolic_get.argtypes = [vp, C.POINTER(SymbolicView)]
+    lib.parsy_grid_spd_lower.restype = C.c_int64
+    lib.parsy_grid_spd_lower.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+    lib.parsy_grid_nested_dissection.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.parsy_plan_create.restype = vp
+    lib.parsy_plan_create.argtypes = [C.c_int, C.c_int] + [vp] * 10 + [C.c_int]
+    lib.parsy_plan_from_symbolic.restype = vp
+    lib.parsy_plan_from_symbolic.argtypes = [vp, C.c_int]
+    lib.parsy_plan_destroy.argtypes = [vp]
+    lib.parsy_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    lib.parsy_plan_set_active.argtypes = [vp, vp]
+    lib.parsy_factor_device.argtypes = [vp, vp, vp, vp]
+    lib.parsy_factor_status.argtypes = [vp]
+    lib.parsy_solve_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.parsy_factor_host.argtypes = [vp, vp, vp, vp]
+    lib.parsy_solve_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.parsy_last_factor_ms.restype = C.c_double
+    lib.parsy_last_factor_ms.argtypes = [vp]
+    lib.parsy_last_solve_ms.restype = C.c_double
+    lib.parsy_last_solve_ms.argtypes = [vp]
+    lib.cholesky_left_par_05.restype = C.c_bool
+    lib.cholesky_left_par_05.argtypes = (
+        [C.c_int] + [vp] * 8 + [C.c_int] + [vp] * 5 + [C.c_int, vp, vp, C.c_int, vp, vp]
+        + [C.c_int] * 4 + [vp])
+    lib.cholesky_left_par_waveFront.restype = C.c_bool
+    lib.cholesky_left_par_waveFront.argtypes = (
+        [C.c_int] + [vp] * 8 + [C.c_int] + [vp] * 5 + [C.c_int, vp, vp] + [C.c_int] * 4)
+    base = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    lib.blockedLsolve.argtypes = base
+    lib.leveledBlockedLsolve.argtypes = base + [C.c_int, vp, vp, C.c_int]
+    lib.H2LeveledBlockedLsolve.argtypes = base + [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
+    lib.H2LeveledBlockedLsolve_Peeled.argtypes = base + [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int]
+    for name in ("blockedLsolve", "leveledBlockedLsolve", "H2LeveledBlockedLsolve",
+                 "H2LeveledBlockedLsolve_Peeled"):
+        getattr(lib, name).restype = C.c_int
+
+
+def lib():
+    """Load (building if needed) libparsy_amd.so. Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists() or os.environ.get("PARSY_REBUILD"):
+        from .build import build_native
+        build_native()
+    try:
+        loaded = C.CDLL(str(_LIB_PATH), mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"libparsy_amd.so could not be loaded ({e}); the HIP executor is the "
+                           "only implementation of this package -- there is no fallback") from e
+    _declare(loaded)
+    _lib = loaded
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().parsy_last_error()
+    return msg.decode() if msg else ""
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def view_array(p, n, dtype):
+    """Copy n elements from a ctypes pointer into a fresh numpy array."""
+    if n == 0 or not p:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(p, shape=(int(n),)).astype(dtype, copy=True)

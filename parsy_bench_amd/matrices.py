@@ -1,0 +1,96 @@
+"""Deterministic synthetic SPD matrices standing in for the SuiteSparse classes of
+BASELINE.json (the files themselves -- reference scripts/dlMat.sh:5-21 -- cannot be
+fetched offline) and geometric nested-dissection orderings (METIS, reference
+cholesky/LSparsity.h:597, is absent).  See SURVEY.md 8(d).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class LowerCSC:
+    """Lower triangle of a symmetric matrix, CSC, rows sorted (what the
+    reference's reader produces: common/Util.h:77-179)."""
+    n: int
+    Ap: np.ndarray  # int32 n+1
+    Ai: np.ndarray  # int32 nnz
+    Ax: np.ndarray  # float64 nnz
+
+    @property
+    def nnz(self) -> int:
+        return int(self.Ap[-1])
+
+    def to_dense(self) -> np.ndarray:
+        A = np.zeros((self.n, self.n))
+        for j in range(self.n):
+            sl = slice(self.Ap[j], self.Ap[j + 1])
+            A[self.Ai[sl], j] = self.Ax[sl]
+        return A + np.tril(A, -1).T
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        Lo = sp.csc_matrix((self.Ax, self.Ai, self.Ap), shape=(self.n, self.n))
+        return (Lo + sp.tril(Lo, -1).T).tocsc()
+
+
+def grid_spd(nx: int, ny: int, nz: int = 1, stencil: int = 5, shift: float = 0.1) -> LowerCSC:
+    lib = N.lib()
+    n = nx * ny * nz
+    Ap = np.zeros(n + 1, dtype=np.int32)
+    nnz = lib.parsy_grid_spd_lower(nx, ny, nz, stencil, shift, N.ptr(Ap), None, None)
+    if nnz < 0:
+        raise ValueError(N.last_error())
+    Ai = np.zeros(nnz, dtype=np.int32)
+    Ax = np.zeros(nnz, dtype=np.float64)
+    lib.parsy_grid_spd_lower(nx, ny, nz, stencil, shift, N.ptr(Ap), N.ptr(Ai), N.ptr(Ax))
+    return LowerCSC(n, Ap, Ai, Ax)
+
+
+def grid_nd(nx: int, ny: int, nz: int = 1, leaf: int | None = None) -> np.ndarray:
+    if leaf is None:
+        leaf = 8 if nz == 1 else 27
+    perm = np.zeros(nx * ny * nz, dtype=np.int32)
+    if N.lib().parsy_grid_nested_dissection(nx, ny, nz, leaf, N.ptr(perm)) != 0:
+        raise ValueError(N.last_error())
+    return perm
+
+
+def random_spd(n: int, density: float = 0.05, seed: int = 0) -> LowerCSC:
+    """Small random sparse SPD matrix (diagonally dominant), for ragged-pattern tests."""
+    rng = np.random.default_rng(seed)
+    M = np.tril((rng.random((n, n)) < density) * rng.uniform(-1.0, 1.0, (n, n)), -1)
+    A = M + M.T
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + rng.uniform(0.5, 1.5, n)
+    Ap = [0]
+    Ai = []
+    Ax = []
+    for j in range(n):
+        rows = np.nonzero(A[j:, j])[0] + j
+        Ai.extend(rows.tolist())
+        Ax.extend(A[rows, j].tolist())
+        Ap.append(len(Ai))
+    return LowerCSC(n, np.array(Ap, np.int32), np.array(Ai, np.int32), np.array(Ax, np.float64))
+
+
+# name -> (nx, ny, nz, stencil, shift): the stand-ins of BASELINE.json's configs
+WORKLOADS = {
+    "ex15": (83, 83, 1, 5, 0.1),             # configs[0]: n = 6 889   (ex15: 6 867)
+    "nd24k": (42, 42, 42, 27, 0.1),          # configs[1]: n = 74 088  (nd24k: 72 000)
+    "flan": (116, 116, 116, 27, 0.1),        # configs[2]: n = 1 560 896 (Flan_1565: 1 564 794)
+    "parabolic_fem": (725, 725, 1, 5, 0.1),  # configs[3]: n = 525 625 (parabolic_fem: 525 825)
+    # small ones for tests
+    "tiny2d": (12, 12, 1, 5, 0.1),
+    "small3d": (10, 10, 10, 27, 0.1),
+    "mid3d": (20, 20, 20, 27, 0.1),
+    "lap30": (30, 30, 30, 7, 0.01),          # the survey's probe problem
+}
+
+
+def workload(name: str):
+    nx, ny, nz, st, sh = WORKLOADS[name]
+    return grid_spd(nx, ny, nz, st, sh), grid_nd(nx, ny, nz)
