@@ -121,8 +121,6 @@ typedef struct parsy_plan_info {
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).
  * device < 0 builds the host schedule only (no HIP call; for CPU-side tests).
- * first_sn/last_sn restrict the plan to supernodes [first_sn, last_sn) plus
- * nothing else when both are >= 0 (multi-GPU subtree shards); pass -1,-1 for all.
  * Returns NULL on error (see parsy_last_error). */
 parsy_plan* parsy_plan_create(int n, int supNo, const int* blockSet, const size_t* lC,
                               const size_t* Li_ptr, const int* lR, const int* aTree,
@@ -163,6 +161,18 @@ int parsy_solve_host(parsy_plan* plan, const double* lValues, double* x, int nrh
  * enqueued through the *_device calls, after synchronisation; <0 if none. */
 double parsy_last_factor_ms(parsy_plan* plan);
 double parsy_last_solve_ms(parsy_plan* plan);
+
+/* Per-launch timing with hipEvents on the launch stream (adds two event records per
+ * kernel launch, so keep it out of throughput measurements).
+ *   parsy_plan_profile(plan, 1) on, (plan, 0) off, (plan, 2) on + reset accumulators.
+ *   parsy_plan_profile_collect(plan): after the stream is synchronised, add the
+ *     elapsed time of every launch of the last factor/solve to its kernel kind.
+ *   parsy_plan_profile_get: accumulated ms and launch counts per kind (8 entries:
+ *     0 SMALL, 1 TILES, 2 INNER, 3 PANEL, 4 FIXUP, 5 SOLVE_SMALL, 6 SOLVE_PANEL,
+ *     7 SOLVE_FIXUP) and the number of collected runs. */
+int parsy_plan_profile(parsy_plan* plan, int enable);
+int parsy_plan_profile_collect(parsy_plan* plan);
+int parsy_plan_profile_get(parsy_plan* plan, double* kind_ms, int* kind_launches, int* runs);
 
 /* Thread-local message of the last failing call. */
 const char* parsy_last_error(void);

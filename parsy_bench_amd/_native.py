@@ -63,7 +63,8 @@ EXPORTED_SYMBOLS = [
     "parsy_factor_host", "parsy_solve_host", "parsy_last_factor_ms", "parsy_last_solve_ms",
     "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
-    "parsy_grid_nested_dissection",
+    "parsy_grid_nested_dissection", "parsy_plan_profile", "parsy_plan_profile_collect",
+    "parsy_plan_profile_get",
 ]
 
 
@@ -94,6 +95,9 @@ def _declare(lib):
     lib.parsy_last_factor_ms.argtypes = [vp]
     lib.parsy_last_solve_ms.restype = C.c_double
     lib.parsy_last_solve_ms.argtypes = [vp]
+    lib.parsy_plan_profile.argtypes = [vp, C.c_int]
+    lib.parsy_plan_profile_collect.argtypes = [vp]
+    lib.parsy_plan_profile_get.argtypes = [vp, vp, vp, vp]
     lib.cholesky_left_par_05.restype = C.c_bool
     lib.cholesky_left_par_05.argtypes = (
         [C.c_int] + [vp] * 8 + [C.c_int] + [vp] * 5 + [C.c_int, vp, vp, C.c_int, vp, vp]

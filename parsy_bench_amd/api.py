@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Two layers, both thin ctypes shims over libparsy_amd.so (the C ABI in
+include/parsy_amd.h) -- no numerics happen in Python:
+
+* the drop-in operators, with the reference's names, argument order and return
+  values (cholesky/parallel_PB_Cholesky_05.h:27, Parallel_PB_Cholesky_wavefront.h:10,
+  triangularSolve/Triangular_BCSC.h:14/115/171/238), taking numpy arrays where the
+  reference takes raw pointers;
+* `Plan`, the pattern-resident handle API (device pointers in/out) used by
+  bench.py and by multi-GPU sharding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+KIND_NAMES = ["SMALL", "TILES", "INNER", "PANEL", "FIXUP", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP"]
+
+
+def device_count() -> int:
+    return int(N.lib().parsy_device_count())
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _sz(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------
+# drop-in operators (host arrays in, host arrays out)
+# ---------------------------------------------------------------------------
+def cholesky_left_par_05(n, c, r, values, lC, lR, Li_ptr, lValues, blockSet, supNo, timing, aTree,
+                         cT, rT, col2Sup, nLevels, levelPtr, levelSet, nPar, parPtr, partition,
+                         chunk, threads, super_max, col_max, nodCost=None) -> bool:
+    """lValues (zeroed by the caller) receives the factor; returns False on a
+    non-positive pivot or if the HIP path could not run."""
+    assert lValues.dtype == np.float64 and lValues.flags["C_CONTIGUOUS"]
+    a = [_i32(c), _i32(r), _f64(values), _sz(lC), _i32(lR), _sz(Li_ptr), _i32(blockSet), _i32(aTree),
+         _i32(cT), _i32(rT), _i32(col2Sup), _i32(levelPtr), _i32(parPtr), _i32(partition)]
+    ls = None if levelSet is None else _i32(levelSet)
+    return bool(N.lib().cholesky_left_par_05(
+        n, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]), N.ptr(a[4]), N.ptr(a[5]), N.ptr(lValues),
+        N.ptr(a[6]), supNo, N.ptr(timing), N.ptr(a[7]), N.ptr(a[8]), N.ptr(a[9]), N.ptr(a[10]), nLevels,
+        N.ptr(a[11]), N.ptr(ls), nPar, N.ptr(a[12]), N.ptr(a[13]), chunk, threads, super_max, col_max,
+        None))
+
+
+def cholesky_left_par_waveFront(n, c, r, values, lC, lR, Li_ptr, lValues, blockSet, supNo, timing,
+                                aTree, cT, rT, col2Sup, nLevels, levelPtr, levelSet, chunk, threads,
+                                super_max, col_max) -> bool:
+    assert lValues.dtype == np.float64 and lValues.flags["C_CONTIGUOUS"]
+    a = [_i32(c), _i32(r), _f64(values), _sz(lC), _i32(lR), _sz(Li_ptr), _i32(blockSet), _i32(aTree),
+         _i32(cT), _i32(rT), _i32(col2Sup), _i32(levelPtr), _i32(levelSet)]
+    return bool(N.lib().cholesky_left_par_waveFront(
+        n, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]), N.ptr(a[4]), N.ptr(a[5]), N.ptr(lValues),
+        N.ptr(a[6]), supNo, N.ptr(timing), N.ptr(a[7]), N.ptr(a[8]), N.ptr(a[9]), N.ptr(a[10]), nLevels,
+        N.ptr(a[11]), N.ptr(a[12]), chunk, threads, super_max, col_max))
+
+
+def _solve_base(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x):
+    assert x is None or (x.dtype == np.float64 and x.flags["C_CONTIGUOUS"])
+    keep = [None if Lp is None else _sz(Lp), None if Li is None else _i32(Li), _f64(Lx), _sz(Li_ptr),
+            _i32(col2sup), _i32(sup2col)]
+    return keep, (n, N.ptr(keep[0]), N.ptr(keep[1]), N.ptr(keep[2]), int(NNZ), N.ptr(keep[3]),
+                  N.ptr(keep[4]), N.ptr(keep[5]), supNo, N.ptr(x))
+
+
+def blockedLsolve(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x) -> int:
+    keep, base = _solve_base(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x)
+    return int(N.lib().blockedLsolve(*base))
+
+
+def leveledBlockedLsolve(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x, levels, levelPtr,
+                         levelSet, chunk) -> int:
+    keep, base = _solve_base(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x)
+    lp, ls = _i32(levelPtr), _i32(levelSet)
+    return int(N.lib().leveledBlockedLsolve(*base, levels, N.ptr(lp), N.ptr(ls), chunk))
+
+
+def H2LeveledBlockedLsolve(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x, levels, levelPtr,
+                           levelSet, parts, parPtr, partition, chunk) -> int:
+    keep, base = _solve_base(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x)
+    lp, pp, pt = _i32(levelPtr), _i32(parPtr), _i32(partition)
+    ls = None if levelSet is None else _i32(levelSet)
+    return int(N.lib().H2LeveledBlockedLsolve(*base, levels, N.ptr(lp), N.ptr(ls), parts, N.ptr(pp),
+                                              N.ptr(pt), chunk))
+
+
+def H2LeveledBlockedLsolve_Peeled(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x, levels,
+                                  levelPtr, levelSet, parts, parPtr, partition, chunk, threads) -> int:
+    keep, base = _solve_base(n, Lp, Li, Lx, NNZ, Li_ptr, col2sup, sup2col, supNo, x)
+    lp, pp, pt = _i32(levelPtr), _i32(parPtr), _i32(partition)
+    ls = None if levelSet is None else _i32(levelSet)
+    return int(N.lib().H2LeveledBlockedLsolve_Peeled(*base, levels, N.ptr(lp), N.ptr(ls), parts,
+                                                     N.ptr(pp), N.ptr(pt), chunk, threads))
+
+
+def dropin_reset() -> None:
+    N.lib().parsy_dropin_reset()
+
+
+# ---------------------------------------------------------------------------
+# plan API
+# ---------------------------------------------------------------------------
+class Plan:
+    """Pattern + launch schedule resident on one device (parsy_plan)."""
+
+    def __init__(self, sym, device: int = 0):
+        lib = N.lib()
+        self.sym = sym
+        self.device = device
+        if getattr(sym, "_handle", None):
+            h = lib.parsy_plan_from_symbolic(sym._handle, device)
+        else:
+            a = [_i32(sym.super), _sz(sym.p), _sz(sym.i_ptr), _i32(sym.s), _i32(sym.sParent),
+                 _i32(sym.col2Sup), _i32(sym.A1p), _i32(sym.A1i), _i32(sym.A2p), _i32(sym.A2i)]
+            h = lib.parsy_plan_create(sym.n, sym.nsuper, *[N.ptr(v) for v in a], device)
+        if not h:
+            raise RuntimeError("parsy_plan_create failed: " + N.last_error())
+        self._h = h
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            N.lib().parsy_plan_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self) -> dict:
+        pi = N.PlanInfo()
+        N.lib().parsy_plan_get_info(self._h, C.byref(pi))
+        return pi.as_dict()
+
+    def set_active(self, mask) -> None:
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if N.lib().parsy_plan_set_active(self._h, N.ptr(m)) != 0:
+            raise RuntimeError(N.last_error())
+
+    # host-buffer conveniences -------------------------------------------------
+    def factor(self, values):
+        """Returns (lValues, device_seconds). Raises on a HIP failure; check `status()`."""
+        vals = _f64(values)
+        lValues = np.zeros(int(self.sym.xsize), dtype=np.float64)
+        sec = C.c_double(0)
+        if N.lib().parsy_factor_host(self._h, N.ptr(vals), N.ptr(lValues), C.byref(sec)) != 0:
+            raise RuntimeError("parsy_factor_host failed: " + N.last_error())
+        return lValues, sec.value
+
+    def status(self) -> int:
+        return int(N.lib().parsy_factor_status(self._h))
+
+    def solve(self, lValues, b):
+        """Forward solve; b is (n,) or (n, nrhs) (any layout); returns x of the same shape."""
+        b = np.asarray(b, dtype=np.float64)
+        one = b.ndim == 1
+        X = np.asfortranarray(b.reshape(self.sym.n, -1)).copy(order="F")
+        nrhs = X.shape[1]
+        lv = _f64(lValues)
+        sec = C.c_double(0)
+        rc = N.lib().parsy_solve_host(self._h, N.ptr(lv), X.ctypes.data_as(C.c_void_p), nrhs,
+                                      self.sym.n, C.byref(sec))
+        if rc != 0:
+            raise RuntimeError("parsy_solve_host failed: " + N.last_error())
+        return (X[:, 0].copy() if one else np.ascontiguousarray(X)), sec.value
+
+    # device-pointer API ---------------------------------------------------------
+    def factor_device(self, d_values: int, d_lValues: int, stream: int = 0) -> None:
+        if N.lib().parsy_factor_device(self._h, d_values, d_lValues, stream) != 0:
+            raise RuntimeError("parsy_factor_device failed: " + N.last_error())
+
+    def solve_device(self, d_lValues: int, d_x: int, nrhs: int, ldx: int, stream: int = 0) -> None:
+        if N.lib().parsy_solve_device(self._h, d_lValues, d_x, nrhs, ldx, stream) != 0:
+            raise RuntimeError("parsy_solve_device failed: " + N.last_error())
+
+    def last_factor_ms(self) -> float:
+        return float(N.lib().parsy_last_factor_ms(self._h))
+
+    def last_solve_ms(self) -> float:
+        return float(N.lib().parsy_last_solve_ms(self._h))
+
+    def profile(self, mode: int) -> None:
+        N.lib().parsy_plan_profile(self._h, mode)
+
+    def profile_collect(self) -> None:
+        if N.lib().parsy_plan_profile_collect(self._h) != 0:
+            raise RuntimeError("profile_collect: no profiled run to collect")
+
+    def profile_get(self) -> dict:
+        ms = np.zeros(8, dtype=np.float64)
+        cnt = np.zeros(8, dtype=np.int32)
+        runs = C.c_int(0)
+        N.lib().parsy_plan_profile_get(self._h, N.ptr(ms), N.ptr(cnt), C.byref(runs))
+        return {"runs": runs.value, "ms": dict(zip(KIND_NAMES, ms.tolist())),
+                "launches": dict(zip(KIND_NAMES, cnt.tolist()))}

@@ -1,0 +1,480 @@
+// C ABI, device part: plan API and the drop-in operators (include/parsy_amd.h §1, §2).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/parsy_amd.h"
+#include "errors.hpp"
+#include "executor.hpp"
+#include "inspector.hpp"
+
+using parsy::set_last_error;
+
+namespace {
+
+#define CAPI_HIP(call, ret)                                                          \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));       \
+            return ret;                                                              \
+        }                                                                            \
+    } while (0)
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int pick_device() {
+    // PARSY_DEVICE selects the HIP device of the drop-in operators (default 0)
+    const char* e = std::getenv("PARSY_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
+// ---- plan cache of the drop-in operators -------------------------------------
+uint64_t fnv(uint64_t h, const void* p, size_t bytes) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= c[i];
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+
+struct CacheKey {
+    const void* a;
+    const void* b;
+    const void* c;
+    uint64_t hash;
+    int n, supNo, kind;
+    bool operator<(const CacheKey& o) const {
+        return std::tie(a, b, c, hash, n, supNo, kind) < std::tie(o.a, o.b, o.c, o.hash, o.n, o.supNo, o.kind);
+    }
+};
+
+std::mutex g_mu;
+std::map<CacheKey, parsy_plan*> g_plans;
+
+bool validate_partition(int supNo, int nLevels, const int* levelPtr, const int* parPtr,
+                        const int* partition, const char* who) {
+    if (!levelPtr || !parPtr || !partition || nLevels < 1) {
+        set_last_error(std::string(who) + ": null H-level schedule");
+        return false;
+    }
+    std::vector<char> seen(supNo, 0);
+    const int nparts = levelPtr[nLevels];
+    int cnt = 0;
+    for (int q = 0; q < nparts; ++q)
+        for (int k = parPtr[q]; k < parPtr[q + 1]; ++k) {
+            const int s = partition[k];
+            if (s < 0 || s >= supNo || seen[s]) {
+                set_last_error(std::string(who) + ": H-level partition is not a permutation of the supernodes");
+                return false;
+            }
+            seen[s] = 1;
+            ++cnt;
+        }
+    if (cnt != supNo) {
+        set_last_error(std::string(who) + ": H-level partition does not cover every supernode");
+        return false;
+    }
+    return true;
+}
+
+bool validate_levelset(int supNo, int nLevels, const int* levelPtr, const int* levelSet, const char* who) {
+    if (!levelPtr || !levelSet || nLevels < 1 || levelPtr[nLevels] != supNo) {
+        set_last_error(std::string(who) + ": level set does not cover every supernode");
+        return false;
+    }
+    std::vector<char> seen(supNo, 0);
+    for (int k = 0; k < supNo; ++k) {
+        const int s = levelSet[k];
+        if (s < 0 || s >= supNo || seen[s]) {
+            set_last_error(std::string(who) + ": level set is not a permutation of the supernodes");
+            return false;
+        }
+        seen[s] = 1;
+    }
+    return true;
+}
+
+void loud(const char* who) {
+    std::fprintf(stderr, "[parsy_amd] %s failed: %s\n", who, parsy_last_error());
+}
+
+parsy_plan* cached_chol_plan(int n, int supNo, const int* blockSet, const size_t* lC,
+                             const size_t* Li_ptr, const int* lR, const int* aTree,
+                             const int* col2Sup, const int* cT, const int* rT, const int* c,
+                             const int* r) {
+    uint64_t h = 1469598103934665603ULL;
+    h = fnv(h, blockSet, sizeof(int) * (supNo + 1));
+    h = fnv(h, lR, sizeof(int) * Li_ptr[n]);
+    h = fnv(h, c, sizeof(int) * (n + 1));
+    h = fnv(h, aTree, sizeof(int) * supNo);
+    CacheKey key{blockSet, lR, c, h, n, supNo, 0};
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    parsy_plan* pl = parsy_plan_create(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r,
+                                       pick_device());
+    if (pl) g_plans[key] = pl;
+    return pl;
+}
+
+parsy_plan* cached_solve_plan(int n, int supNo, const size_t* Lp, const int* Li, const size_t* Li_ptr,
+                              const int* sup2col) {
+    uint64_t h = 1469598103934665603ULL;
+    h = fnv(h, sup2col, sizeof(int) * (supNo + 1));
+    h = fnv(h, Li, sizeof(int) * Li_ptr[n]);
+    CacheKey key{sup2col, Li, Lp, h, n, supNo, 1};
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    // supernodal etree straight from L's pattern: the parent of a supernode is the
+    // supernode of its first below-diagonal row.
+    std::vector<int> col2sup(n), sparent(supNo, -1);
+    for (int s = 0; s < supNo; ++s)
+        for (int k = sup2col[s]; k < sup2col[s + 1]; ++k) col2sup[k] = s;
+    for (int s = 0; s < supNo; ++s) {
+        const int w = sup2col[s + 1] - sup2col[s];
+        const size_t b = Li_ptr[sup2col[s]], e = Li_ptr[sup2col[s + 1]];
+        if (e - b > (size_t)w) sparent[s] = col2sup[Li[b + w]];
+    }
+    parsy::PatternRef P;
+    P.n = n;
+    P.nsuper = supNo;
+    P.super = sup2col;
+    P.col2sup = col2sup.data();
+    P.sparent = sparent.data();
+    P.i_ptr = Li_ptr;
+    P.s = Li;
+    if (parsy_device_count() < 1) {
+        set_last_error("no usable HIP device: the BCSC solve has no CPU fallback in this library");
+        return nullptr;
+    }
+    parsy_plan* pl = parsy::plan_build(P, Lp, nullptr, nullptr, pick_device());
+    if (pl) g_plans[key] = pl;
+    return pl;
+}
+
+int dropin_solve(const char* who, int n, size_t* Lp, int* Li, double* Lx, size_t* Li_ptr,
+                 int* sup2col, int supNo, double* x) {
+    if (!Lp || !Li || !x) return 0;  // reference: Triangular_BCSC.h:24
+    parsy_plan* pl = cached_solve_plan(n, supNo, Lp, Li, Li_ptr, sup2col);
+    if (!pl || parsy_solve_host(pl, Lx, x, 1, n, nullptr) != 0) {
+        loud(who);
+        return 0;
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int parsy_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+parsy_plan* parsy_plan_create(int n, int supNo, const int* blockSet, const size_t* lC,
+                              const size_t* Li_ptr, const int* lR, const int* aTree,
+                              const int* col2Sup, const int* cT, const int* rT, const int* c,
+                              const int* r, int device) {
+    if (!blockSet || !lC || !Li_ptr || !lR || !aTree || !col2Sup || !cT || !rT || !c || !r || n < 0 ||
+        supNo < 0) {
+        set_last_error("parsy_plan_create: null or negative argument");
+        return nullptr;
+    }
+    if (device >= 0 && device >= parsy_device_count()) {
+        set_last_error("parsy_plan_create: no usable HIP device " + std::to_string(device) +
+                       " (this library has no CPU fallback; pass device < 0 for a host-only schedule)");
+        return nullptr;
+    }
+    parsy::PatternRef P;
+    P.n = n;
+    P.nsuper = supNo;
+    P.super = blockSet;
+    P.col2sup = col2Sup;
+    P.sparent = aTree;
+    P.i_ptr = Li_ptr;
+    P.s = lR;
+    P.A1p = cT;
+    P.A1i = rT;
+    return parsy::plan_build(P, lC, c, r, device);
+}
+
+parsy_plan* parsy_plan_from_symbolic(const parsy_symbolic* sym, int device) {
+    const parsy::Symbolic* S = parsy_symbolic_cxx(sym);
+    if (!S) {
+        set_last_error("parsy_plan_from_symbolic: null symbolic");
+        return nullptr;
+    }
+    return parsy_plan_create(S->n, S->nsuper, S->super.data(), S->p.data(), S->i_ptr.data(), S->s.data(),
+                             S->sparent.data(), S->col2sup.data(), S->A1.p.data(), S->A1.i.data(),
+                             S->A2.p.data(), S->A2.i.data(), device);
+}
+
+void parsy_plan_destroy(parsy_plan* plan) { parsy::plan_free(plan); }
+
+int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
+    if (!pl || !o) return -1;
+    const parsy::Schedule& S = pl->S;
+    std::memset(o, 0, sizeof(*o));
+    o->n = S.n;
+    o->nsuper = S.nsuper;
+    o->nlevels = S.nlevels;
+    o->max_width = S.max_width;
+    o->max_rows = S.max_rows;
+    o->n_small = S.n_small;
+    o->n_big = S.n_big;
+    o->chol_launches = (int32_t)S.chol.size() + 1;  // + the A scatter
+    o->solve_launches = (int32_t)S.solve.size();
+    o->nnzA = S.nnzA;
+    o->ssize = S.ssize;
+    o->xsize = S.xsize;
+    o->nnzL = S.nnzL;
+    o->n_updates = (int64_t)S.upd.size();
+    o->relpos_len = (int64_t)S.relpos.size();
+    o->device_bytes = pl->device_bytes;
+    o->flops_stored = S.flops_stored;
+    o->update_flops = S.update_flops;
+    o->reread_bytes = S.reread_bytes;
+    return 0;
+}
+
+int parsy_plan_set_active(parsy_plan* pl, const uint8_t* mask) {
+    if (!pl) return -1;
+    parsy::build_launches(pl->S, mask);
+    return parsy::plan_upload_launches(pl);
+}
+
+int parsy_factor_device(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream) {
+    if (!pl || !d_values || !d_lValues) {
+        set_last_error("parsy_factor_device: null argument");
+        return -1;
+    }
+    return parsy::plan_factor(pl, d_values, d_lValues, (hipStream_t)stream);
+}
+
+int parsy_factor_status(parsy_plan* pl) {
+    if (!pl || pl->device < 0) return -1;
+    int v = 0;
+    if (hipMemcpy(&v, pl->dp.info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v >= 0x7f7f7f7f ? 0 : v;
+}
+
+int parsy_solve_device(parsy_plan* pl, const double* d_lValues, double* d_x, int nrhs, int ldx,
+                       void* stream) {
+    if (!pl || !d_lValues || !d_x) {
+        set_last_error("parsy_solve_device: null argument");
+        return -1;
+    }
+    return parsy::plan_solve(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream);
+}
+
+double parsy_last_factor_ms(parsy_plan* pl) {
+    float ms = -1;
+    if (!pl || !pl->have_f) return -1;
+    if (hipEventSynchronize(pl->ev_f1) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms, pl->ev_f0, pl->ev_f1) != hipSuccess) return -1;
+    return ms;
+}
+
+double parsy_last_solve_ms(parsy_plan* pl) {
+    float ms = -1;
+    if (!pl || !pl->have_s) return -1;
+    if (hipEventSynchronize(pl->ev_s1) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms, pl->ev_s0, pl->ev_s1) != hipSuccess) return -1;
+    return ms;
+}
+
+int parsy_plan_profile(parsy_plan* pl, int enable) {
+    if (!pl) return -1;
+    pl->profile = enable != 0;
+    if (enable == 2) {  // reset the accumulators
+        for (int k = 0; k < 8; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
+        pl->profiled_runs = 0;
+    }
+    return 0;
+}
+
+int parsy_plan_profile_collect(parsy_plan* pl) { return pl ? parsy::plan_collect_profile(pl) : -1; }
+
+int parsy_plan_profile_get(parsy_plan* pl, double* kind_ms, int* kind_launches, int* runs) {
+    if (!pl) return -1;
+    for (int k = 0; k < 8; ++k) {
+        if (kind_ms) kind_ms[k] = pl->kind_ms[k];
+        if (kind_launches) kind_launches[k] = pl->kind_launches[k];
+    }
+    if (runs) *runs = pl->profiled_runs;
+    return 0;
+}
+
+int parsy_factor_host(parsy_plan* pl, const double* values, double* lValues, double* seconds) {
+    if (!pl || !values || !lValues) {
+        set_last_error("parsy_factor_host: null argument");
+        return -1;
+    }
+    if (pl->device < 0) {
+        set_last_error("parsy_factor_host: plan has no device");
+        return -1;
+    }
+    const parsy::Schedule& S = pl->S;
+    CAPI_HIP(hipSetDevice(pl->device), -1);
+    if (!pl->h_values_dev) CAPI_HIP(hipMalloc((void**)&pl->h_values_dev, std::max<int64_t>(S.nnzA, 1) * 8), -1);
+    if (!pl->h_L_dev) CAPI_HIP(hipMalloc((void**)&pl->h_L_dev, std::max<int64_t>(S.xsize, 1) * 8), -1);
+    CAPI_HIP(hipMemcpy(pl->h_values_dev, values, (size_t)S.nnzA * 8, hipMemcpyHostToDevice), -1);
+    if (parsy::plan_factor(pl, pl->h_values_dev, pl->h_L_dev, nullptr) != 0) return -1;
+    CAPI_HIP(hipDeviceSynchronize(), -1);
+    if (seconds) *seconds = parsy_last_factor_ms(pl) * 1e-3;
+    CAPI_HIP(hipMemcpy(lValues, pl->h_L_dev, (size_t)S.xsize * 8, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+int parsy_solve_host(parsy_plan* pl, const double* lValues, double* x, int nrhs, int ldx,
+                     double* seconds) {
+    if (!pl || !lValues || !x) {
+        set_last_error("parsy_solve_host: null argument");
+        return -1;
+    }
+    if (pl->device < 0) {
+        set_last_error("parsy_solve_host: plan has no device");
+        return -1;
+    }
+    const parsy::Schedule& S = pl->S;
+    CAPI_HIP(hipSetDevice(pl->device), -1);
+    if (!pl->h_L_dev) CAPI_HIP(hipMalloc((void**)&pl->h_L_dev, std::max<int64_t>(S.xsize, 1) * 8), -1);
+    const int64_t need = (int64_t)ldx * nrhs;
+    if (pl->h_x_len < need) {
+        if (pl->h_x_dev) hipFree(pl->h_x_dev);
+        pl->h_x_dev = nullptr;
+        CAPI_HIP(hipMalloc((void**)&pl->h_x_dev, (size_t)need * 8), -1);
+        pl->h_x_len = need;
+    }
+    CAPI_HIP(hipMemcpy(pl->h_L_dev, lValues, (size_t)S.xsize * 8, hipMemcpyHostToDevice), -1);
+    CAPI_HIP(hipMemcpy(pl->h_x_dev, x, (size_t)need * 8, hipMemcpyHostToDevice), -1);
+    if (parsy::plan_solve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
+    CAPI_HIP(hipDeviceSynchronize(), -1);
+    if (seconds) *seconds = parsy_last_solve_ms(pl) * 1e-3;
+    CAPI_HIP(hipMemcpy(x, pl->h_x_dev, (size_t)need * 8, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+void parsy_dropin_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_plans) parsy::plan_free(kv.second);
+    g_plans.clear();
+}
+
+// ---- drop-in operators ----------------------------------------------------------
+
+bool cholesky_left_par_05(int n, int* c, int* r, double* values, size_t* lC, int* lR, size_t* Li_ptr,
+                          double* lValues, int* blockSet, int supNo, double* timing, int* aTree,
+                          int* cT, int* rT, int* col2Sup, int nLevels, int* levelPtr, int* levelSet,
+                          int nPar, int* parPtr, int* partition, int chunk, int threads,
+                          int super_max, int col_max, double* nodCost) {
+    (void)levelSet; (void)nPar; (void)chunk; (void)threads; (void)super_max; (void)col_max; (void)nodCost;
+    const char* who = "cholesky_left_par_05";
+    const double t0 = now_s();
+    if (!validate_partition(supNo, nLevels, levelPtr, parPtr, partition, who)) {
+        loud(who);
+        return false;
+    }
+    parsy_plan* pl = cached_chol_plan(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r);
+    double dev_s = 0;
+    if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
+        loud(who);
+        return false;
+    }
+    if (timing) {
+        timing[0] = now_s() - t0;
+        timing[1] = 0.0;
+        timing[2] = dev_s;
+    }
+    return parsy_factor_status(pl) == 0;
+}
+
+bool cholesky_left_par_waveFront(int n, int* c, int* r, double* values, size_t* lC, int* lR,
+                                 size_t* Li_ptr, double* lValues, int* blockSet, int supNo,
+                                 double* timing, int* aTree, int* cT, int* rT, int* col2Sup,
+                                 int nLevels, int* levelPtr, int* levelSet, int chunk, int threads,
+                                 int super_max, int col_max) {
+    (void)chunk; (void)threads; (void)super_max; (void)col_max;
+    const char* who = "cholesky_left_par_waveFront";
+    const double t0 = now_s();
+    if (!validate_levelset(supNo, nLevels, levelPtr, levelSet, who)) {
+        loud(who);
+        return false;
+    }
+    parsy_plan* pl = cached_chol_plan(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r);
+    double dev_s = 0;
+    if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
+        loud(who);
+        return false;
+    }
+    if (timing) {
+        timing[0] = now_s() - t0;
+        timing[1] = 0.0;
+        timing[2] = dev_s;
+    }
+    const int st = parsy_factor_status(pl);
+    if (st != 0)
+        std::fprintf(stderr, "[parsy_amd] %s: non-positive pivot at column %d (the reference ignores LAPACK's info here)\n",
+                     who, st);
+    return true;
+}
+
+int blockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr, int* col2sup,
+                  int* sup2col, int supNo, double* x) {
+    (void)NNZ; (void)col2sup;
+    return dropin_solve("blockedLsolve", n, Lp, Li, Lx, Li_ptr, sup2col, supNo, x);
+}
+
+int leveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                         int* col2sup, int* sup2col, int supNo, double* x, int levels,
+                         int* levelPtr, int* levelSet, int chunk) {
+    (void)NNZ; (void)col2sup; (void)chunk;
+    if (!Lp || !Li || !x) return 0;
+    if (!validate_levelset(supNo, levels, levelPtr, levelSet, "leveledBlockedLsolve")) {
+        loud("leveledBlockedLsolve");
+        return 0;
+    }
+    return dropin_solve("leveledBlockedLsolve", n, Lp, Li, Lx, Li_ptr, sup2col, supNo, x);
+}
+
+int H2LeveledBlockedLsolve(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                           int* col2sup, int* sup2col, int supNo, double* x, int levels,
+                           int* levelPtr, int* levelSet, int parts, int* parPtr, int* partition,
+                           int chunk) {
+    (void)NNZ; (void)col2sup; (void)chunk; (void)levelSet; (void)parts;
+    if (!Lp || !Li || !x) return 0;
+    if (!validate_partition(supNo, levels, levelPtr, parPtr, partition, "H2LeveledBlockedLsolve")) {
+        loud("H2LeveledBlockedLsolve");
+        return 0;
+    }
+    return dropin_solve("H2LeveledBlockedLsolve", n, Lp, Li, Lx, Li_ptr, sup2col, supNo, x);
+}
+
+int H2LeveledBlockedLsolve_Peeled(int n, size_t* Lp, int* Li, double* Lx, int NNZ, size_t* Li_ptr,
+                                  int* col2sup, int* sup2col, int supNo, double* x, int levels,
+                                  int* levelPtr, int* levelSet, int parts, int* parPtr,
+                                  int* partition, int chunk, int threads) {
+    (void)NNZ; (void)col2sup; (void)chunk; (void)levelSet; (void)parts; (void)threads;
+    if (!Lp || !Li || !x) return 0;
+    if (!validate_partition(supNo, levels, levelPtr, parPtr, partition, "H2LeveledBlockedLsolve_Peeled")) {
+        loud("H2LeveledBlockedLsolve_Peeled");
+        return 0;
+    }
+    return dropin_solve("H2LeveledBlockedLsolve_Peeled", n, Lp, Li, Lx, Li_ptr, sup2col, supNo, x);
+}
+
+}  // extern "C"

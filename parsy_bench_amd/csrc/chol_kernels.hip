@@ -1,0 +1,408 @@
+// HIP kernels of the supernodal left-looking Cholesky for gfx950 (MI355X).
+//
+// Numeric contract (reference cholesky/parallel_PB_Cholesky_05.h:96-219): for a
+// target supernode, panel := A(:, cols); for every descendant d in update order:
+// panel(rel(i), rel(j)) -= sum_k Ld(i,k) Ld(j,k) for j < ndrow1, i >= j; then
+// POTRF on the diagonal block and TRSM on the rows below it.  FP64 throughout.
+//
+// Data layout in HBM: lValues is the reference's BCSC value array (one
+// column-major rows x width panel per supernode, leading dimension = rows);
+// descriptors are the flat arrays of schedule.hpp.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "kernels.hpp"
+
+namespace parsy {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+static constexpr int kThreads = 256;
+static constexpr int kLdSub = kSub + 1;   // padded leading dimension of a wave's sub-tile in LDS
+static constexpr int kLdDiag = kTile + 1; // padded leading dimension of a diagonal block in LDS
+static constexpr int kChunk = 256;        // update entries staged per pass of the tile kernel
+
+// ---------------------------------------------------------------------------
+// A -> L scatter (reference :104-112, hoisted: the destination of every entry
+// is precomputed).  HBM-bound, 16 B read + 8 B written per entry.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_scatter_a(const double* __restrict__ values,
+                                                        const int64_t* __restrict__ a_dst,
+                                                        double* __restrict__ L, int64_t nnz) {
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nnz;
+         q += (int64_t)gridDim.x * kThreads)
+        L[a_dst[q]] = values[q];
+}
+
+void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int64_t nnz,
+                      hipStream_t stream) {
+    if (nnz <= 0) return;
+    int64_t blocks = (nnz + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_scatter_a, dim3((unsigned)blocks), dim3(kThreads), 0, stream, values, a_dst,
+                       L, nnz);
+}
+
+// ---------------------------------------------------------------------------
+// SMALL: one workgroup per supernode, whole panel resident in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restrict__ sn,
+                                                         const UpdDesc* __restrict__ upd,
+                                                         const int32_t* __restrict__ relpos,
+                                                         const int32_t* __restrict__ list,
+                                                         double* __restrict__ L,
+                                                         int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double P[];
+    const int tid = threadIdx.x;
+    const SnDesc D = sn[list[blockIdx.x]];
+    const int r = D.r, w = D.w, total = r * w;
+    double* __restrict__ G = L + D.px;
+
+    for (int e = tid; e < total; e += kThreads) P[e] = G[e];
+    __syncthreads();
+
+    for (int u = 0; u < D.nupd; ++u) {
+        const UpdDesc U = upd[D.upd0 + u];
+        const double* __restrict__ src = L + U.src;
+        const int32_t* __restrict__ rel = relpos + U.rel;
+        const int m = U.m, n1 = U.n1, K = U.K, ld = U.ld;
+        const int pairs = m * n1;
+        for (int e = tid; e < pairs; e += kThreads) {
+            const int j = e / m, i = e - j * m;
+            if (i >= j) {
+                const double* a = src + i;
+                const double* b = src + j;
+                double acc = 0.0;
+                for (int k = 0; k < K; ++k) acc = fma(a[(int64_t)k * ld], b[(int64_t)k * ld], acc);
+                P[rel[j] * r + rel[i]] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    // right-looking POTRF on the w diagonal rows with the r-w rows below carried
+    // along (= POTRF followed by TRSM 'R','L','T','N', reference :204,:218)
+    for (int j = 0; j < w; ++j) {
+        const double d = P[j * r + j];
+        const double s = sqrt(d);
+        const double inv = 1.0 / s;
+        if (tid == 0 && !(d > 0.0)) atomicMin(info, D.c0 + j + 1);
+        __syncthreads();
+        for (int i = j + tid; i < r; i += kThreads) P[j * r + i] = (i == j) ? s : P[j * r + i] * inv;
+        __syncthreads();
+        const int nc = w - j - 1, nr = r - j - 1;
+        for (int e = tid; e < nc * nr; e += kThreads) {
+            const int cc = e / nr;
+            const int c = j + 1 + cc, i = j + 1 + (e - cc * nr);
+            if (i >= c) P[c * r + i] = fma(-P[j * r + i], P[j * r + c], P[c * r + i]);
+        }
+        __syncthreads();
+    }
+
+    for (int e = tid; e < total; e += kThreads) G[e] = P[e];
+}
+
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
+                       hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), (size_t)lds_bytes, stream, P.sn,
+                       P.upd, P.relpos, P.small_list + first, L, P.info);
+}
+
+// ---------------------------------------------------------------------------
+// TILES / INNER: one workgroup per 64x64 tile of a panel, one wave per 32x32
+// sub-tile.  The sub-tile lives in LDS (each wave owns its own, so the update
+// loop needs no barrier and the summation order is fixed: update order, then
+// k).  The dense product of an update is formed in descendant coordinates with
+// v_mfma_f64_16x16x4_f64 straight from the descendant's column-major panel
+// (rows of a 16-row fragment are contiguous: 128-B segments per k), then
+// scatter-subtracted through the relative indices.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int n, int k0, int k1,
+                                             int k2, int& r0, int& r1, int& r2) {
+    int l0 = 0, l1 = 0, l2 = 0;
+    if (n > 0) {
+        for (int step = 1 << (31 - __clz(n)); step > 0; step >>= 1) {
+            const int p0 = l0 + step, p1 = l1 + step, p2 = l2 + step;
+            const int v0 = (p0 <= n) ? a[p0 - 1] : INT_MAX;
+            const int v1 = (p1 <= n) ? a[p1 - 1] : INT_MAX;
+            const int v2 = (p2 <= n) ? a[p2 - 1] : INT_MAX;
+            if (v0 < k0) l0 = p0;
+            if (v1 < k1) l1 = p1;
+            if (v2 < k2) l2 = p2;
+        }
+    }
+    r0 = l0;
+    r1 = l1;
+    r2 = l2;
+}
+
+template <bool INNER>
+__global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restrict__ sn,
+                                                         const UpdDesc* __restrict__ upd,
+                                                         const int32_t* __restrict__ relpos,
+                                                         const ColBlkEntry* __restrict__ colblk,
+                                                         const TileDesc* __restrict__ tiles, int jb,
+                                                         double* __restrict__ L) {
+    __shared__ double T[4][kSub * kLdSub];
+    __shared__ int64_t e_src[kChunk];
+    __shared__ int64_t e_rel[kChunk];
+    __shared__ int32_t e_ld[kChunk], e_K[kChunk];
+    __shared__ int32_t e_i0[kChunk], e_i1[kChunk], e_i2[kChunk];
+    __shared__ int32_t e_j0[kChunk], e_j1[kChunk], e_j2[kChunk];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const TileDesc td = tiles[blockIdx.x];
+    const SnDesc D = sn[td.sn];
+    const int r = D.r, w = D.w;
+    double* __restrict__ G = L + D.px;
+
+    const int wa = wave >> 1, wb = wave & 1;
+    const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
+    const bool wave_on = subrow0 < r && subcol0 < w && subrow0 >= subcol0;
+    const int nrows = min(kSub, r - subrow0), ncols = min(kSub, w - subcol0);
+    double* __restrict__ Tw = T[wave];
+
+    if (wave_on) {
+        for (int e = lane; e < kSub * kSub; e += 64) {
+            const int cc = e >> 5, rr = e & 31;
+            const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
+            Tw[cc * kLdSub + rr] = in ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+        }
+    }
+
+    const int n_entries = INNER ? 1 : (td.cb1 - td.cb0);
+    for (int base = 0; base < n_entries; base += kChunk) {
+        const int cnt = min(kChunk, n_entries - base);
+        __syncthreads();  // previous chunk fully consumed
+        if (INNER) {
+            if (tid == 0) {
+                e_src[0] = D.px;
+                e_rel[0] = -1;
+                e_ld[0] = r;
+                e_K[0] = jb * kTile;
+                e_i0[0] = td.row0;
+                e_i1[0] = min(td.row0 + kSub, r);
+                e_i2[0] = min(td.row0 + kTile, r);
+                e_j0[0] = td.col0;
+                e_j1[0] = min(td.col0 + kSub, w);
+                e_j2[0] = min(td.col0 + kTile, w);
+            }
+        } else if (tid < cnt) {
+            const ColBlkEntry ce = colblk[td.cb0 + base + tid];
+            const UpdDesc U = upd[ce.upd];
+            int i0, i1, i2;
+            lower_bound3(relpos + U.rel, U.m, td.row0, td.row0 + kSub, td.row0 + kTile, i0, i1, i2);
+            e_src[tid] = U.src;
+            e_rel[tid] = U.rel;
+            e_ld[tid] = U.ld;
+            e_K[tid] = U.K;
+            e_i0[tid] = i0;
+            e_i1[tid] = i1;
+            e_i2[tid] = i2;
+            e_j0[tid] = ce.jlo;
+            e_j1[tid] = ce.jmid;
+            e_j2[tid] = ce.jhi;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+
+        for (int e = 0; e < cnt; ++e) {
+            const int ia = wa ? e_i1[e] : e_i0[e], ib = wa ? e_i2[e] : e_i1[e];
+            const int ja = wb ? e_j1[e] : e_j0[e], jbnd = wb ? e_j2[e] : e_j1[e];
+            const int mi = ib - ia, nj = jbnd - ja;
+            if (mi <= 0 || nj <= 0) continue;
+            const double* __restrict__ src = L + e_src[e];
+            const int32_t* __restrict__ rel = relpos + (INNER ? 0 : e_rel[e]);
+            const int ld = e_ld[e], K = e_K[e];
+            const bool two_r = mi > 16, two_c = nj > 16;
+            const int l15 = lane & 15, kq = lane >> 4;
+
+            // relative indices this lane will scatter through (issued before the K loop)
+            int rR[2][4], rC[2];
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int il = tr * 16 + kq + 4 * v;
+                    int pos = -1;
+                    if (il < mi) pos = INNER ? (ia + il) : rel[ia + il];
+                    rR[tr][v] = pos - subrow0;
+                }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int jl = tc * 16 + l15;
+                int pos = -1;
+                if (jl < nj) pos = INNER ? (ja + jl) : rel[ja + jl];
+                rC[tc] = pos < 0 ? -1 : pos - subcol0;
+            }
+
+            const double* pa0 = src + min(ia + l15, ib - 1);
+            const double* pa1 = src + min(ia + 16 + l15, ib - 1);
+            const double* pb0 = src + min(ja + l15, jbnd - 1);
+            const double* pb1 = src + min(ja + 16 + l15, jbnd - 1);
+            double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                const int k = k0 + kq;
+                const bool kv = k < K;
+                const int64_t off = (int64_t)(kv ? k : 0) * ld;
+                double a0 = pa0[off], b0 = pb0[off];
+                double a1 = two_r ? pa1[off] : 0.0, b1 = two_c ? pb1[off] : 0.0;
+                if (!kv) { a0 = 0.0; a1 = 0.0; b0 = 0.0; b1 = 0.0; }
+                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+                if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+                if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+                if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+            }
+            // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+            const bool diag_sub = subrow0 == subcol0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int R0 = rR[0][v], R1 = rR[1][v];
+                const int C0 = rC[0], C1 = rC[1];
+                if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) Tw[C0 * kLdSub + R0] -= c00[v];
+                if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) Tw[C1 * kLdSub + R0] -= c01[v];
+                if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) Tw[C0 * kLdSub + R1] -= c10[v];
+                if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) Tw[C1 * kLdSub + R1] -= c11[v];
+            }
+        }
+    }
+
+    if (wave_on) {
+        for (int e = lane; e < kSub * kSub; e += 64) {
+            const int cc = e >> 5, rr = e & 31;
+            if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc))
+                G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] = Tw[cc * kLdSub + rr];
+        }
+    }
+}
+
+void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, double* L,
+                       hipStream_t stream) {
+    if (count <= 0) return;
+    if (inner)
+        hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
+                           P.relpos, P.colblk, P.tiles + first, jb, L);
+    else
+        hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
+                           P.relpos, P.colblk, P.tiles + first, jb, L);
+}
+
+// ---------------------------------------------------------------------------
+// PANEL: POTRF of diagonal block jb (every workgroup factors its own LDS copy;
+// the designated one parks the result in scratch so nobody reads a half-written
+// block) and TRSM of one 256-row chunk below it, one thread per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_chol_panel(const SnDesc* __restrict__ sn,
+                                                         const PanelDesc* __restrict__ pds,
+                                                         double* __restrict__ L,
+                                                         double* __restrict__ dscratch,
+                                                         int* __restrict__ info) {
+    __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
+    const int tid = threadIdx.x;
+    const PanelDesc pd = pds[blockIdx.x];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, cb = pd.jb * kTile, wbk = min(kTile, D.w - cb);
+    double* __restrict__ G = L + D.px;
+
+    for (int e = tid; e < kTile * kTile; e += kThreads) {
+        const int c = e >> 6, i = e & 63;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+        Dg[c * kLdDiag + i] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < wbk; ++j) {
+        const double d = Dg[j * kLdDiag + j];
+        const double s = sqrt(d);
+        const double inv = 1.0 / s;
+        __syncthreads();
+        if (tid < kTile) {
+            if (tid == j) {
+                Dg[j * kLdDiag + j] = s;
+                invd[j] = inv;
+                if (!(d > 0.0) && pd.row0 < 0) atomicMin(info, D.c0 + cb + j + 1);
+            } else if (tid > j && tid < wbk) {
+                Dg[j * kLdDiag + tid] *= inv;
+            }
+        }
+        __syncthreads();
+        const int nc = wbk - j - 1;  // trailing columns j+1 .. wbk-1
+        for (int e = tid; e < nc * kTile; e += kThreads) {
+            const int c = j + 1 + (e >> 6), i = e & 63;
+            if (i >= c && i < wbk)
+                Dg[c * kLdDiag + i] = fma(-Dg[j * kLdDiag + i], Dg[j * kLdDiag + c], Dg[c * kLdDiag + i]);
+        }
+        __syncthreads();
+    }
+
+    if (pd.row0 < 0) {
+        double* __restrict__ slot = dscratch + (int64_t)(D.dslot + pd.jb) * (kTile * kTile);
+        for (int e = tid; e < kTile * kTile; e += kThreads) {
+            const int c = e >> 6, i = e & 63;
+            slot[e] = (c < wbk && i < wbk && i >= c) ? Dg[c * kLdDiag + i] : 0.0;
+        }
+        return;
+    }
+
+    const int row = pd.row0 + tid;
+    if (row >= r) return;
+    // x := x * inv(Ljj'):  x[c] = (x[c] - sum_{k<c} x[k] Ljj[c][k]) / Ljj[c][c], 16 columns at a
+    // time in registers; columns already solved are re-read from the panel (own writes).
+    double* __restrict__ xr = G + (int64_t)cb * r + row;
+    for (int c0 = 0; c0 < wbk; c0 += 16) {
+        double xb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xb[j] = (c0 + j < wbk) ? xr[(int64_t)(c0 + j) * r] : 0.0;
+        for (int k = 0; k < c0; ++k) {
+            const double xk = xr[(int64_t)k * r];
+            const double* __restrict__ lk = &Dg[k * kLdDiag + c0];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xb[j] = fma(-xk, lk[j], xb[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double acc = xb[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) acc = fma(-xb[i], Dg[(c0 + i) * kLdDiag + c0 + j], acc);
+            xb[j] = acc * invd[min(c0 + j, wbk - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (c0 + j < wbk) xr[(int64_t)(c0 + j) * r] = xb[j];
+    }
+}
+
+void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_chol_panel, dim3(count), dim3(kThreads), 0, stream, P.sn, P.panels + first, L,
+                       P.dscratch, P.info);
+}
+
+// FIXUP: copy parked diagonal blocks into their panels (lower triangle only).
+__global__ __launch_bounds__(kThreads) void k_chol_fixup(const SnDesc* __restrict__ sn,
+                                                         const int32_t* __restrict__ list,
+                                                         double* __restrict__ L,
+                                                         const double* __restrict__ dscratch) {
+    const SnDesc D = sn[list[blockIdx.x]];
+    const int r = D.r, nbc = (D.w + kTile - 1) / kTile;
+    double* __restrict__ G = L + D.px;
+    for (int jb = blockIdx.y; jb < nbc; jb += gridDim.y) {
+        const int cb = jb * kTile, wbk = min(kTile, D.w - cb);
+        const double* __restrict__ slot = dscratch + (int64_t)(D.dslot + jb) * (kTile * kTile);
+        for (int e = threadIdx.x; e < kTile * kTile; e += kThreads) {
+            const int c = e >> 6, i = e & 63;
+            if (c < wbk && i < wbk && i >= c) G[(int64_t)(cb + c) * r + cb + i] = slot[e];
+        }
+    }
+}
+
+void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_chol_fixup, dim3(count, 32), dim3(kThreads), 0, stream, P.sn,
+                       P.fix_list + first, L, P.dscratch);
+}
+
+}  // namespace parsy

@@ -1,0 +1,216 @@
+// Plan construction, upload and launch sequencing (host side of the HIP executor).
+#include "executor.hpp"
+
+#include <climits>
+#include <cstring>
+#include <stdexcept>
+
+#include "errors.hpp"
+
+namespace parsy {
+
+#define PARSY_HIP(call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return -1;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+template <typename T>
+static int upload(parsy_plan* pl, const std::vector<T>& v, const T*& dptr, bool launch_array) {
+    dptr = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void* d = nullptr;
+    PARSY_HIP(hipMalloc(&d, bytes));
+    (launch_array ? pl->launch_owned : pl->owned).push_back(d);
+    if (!v.empty()) PARSY_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    pl->device_bytes += (int64_t)bytes;
+    dptr = (const T*)d;
+    return 0;
+}
+
+int plan_upload_launches(parsy_plan* pl) {
+    if (pl->device < 0) return 0;
+    PARSY_HIP(hipSetDevice(pl->device));
+    for (void* d : pl->launch_owned) hipFree(d);
+    pl->launch_owned.clear();
+    const Schedule& S = pl->S;
+    if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
+    if (upload(pl, S.tiles, pl->dp.tiles, true)) return -1;
+    if (upload(pl, S.panels, pl->dp.panels, true)) return -1;
+    if (upload(pl, S.fix_list, pl->dp.fix_list, true)) return -1;
+    if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
+    if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
+    if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
+    return 0;
+}
+
+static int plan_upload(parsy_plan* pl) {
+    PARSY_HIP(hipSetDevice(pl->device));
+    const Schedule& S = pl->S;
+    if (upload(pl, S.sn, pl->dp.sn, false)) return -1;
+    if (upload(pl, S.upd, pl->dp.upd, false)) return -1;
+    if (upload(pl, S.relpos, pl->dp.relpos, false)) return -1;
+    if (upload(pl, S.a_dst, pl->dp.a_dst, false)) return -1;
+    if (upload(pl, S.rows, pl->dp.rows, false)) return -1;
+    if (upload(pl, S.colblk, pl->dp.colblk, false)) return -1;
+    {
+        void* d = nullptr;
+        const size_t bytes = std::max<int64_t>(S.n_dslots, 1) * kTile * kTile * sizeof(double);
+        PARSY_HIP(hipMalloc(&d, bytes));
+        pl->owned.push_back(d);
+        pl->dp.dscratch = (double*)d;
+        pl->device_bytes += (int64_t)bytes;
+        PARSY_HIP(hipMalloc(&d, sizeof(int)));
+        pl->owned.push_back(d);
+        pl->dp.info = (int*)d;
+        PARSY_HIP(hipMemset(d, 0x7f, sizeof(int)));
+    }
+    PARSY_HIP(hipEventCreate(&pl->ev_f0));
+    PARSY_HIP(hipEventCreate(&pl->ev_f1));
+    PARSY_HIP(hipEventCreate(&pl->ev_s0));
+    PARSY_HIP(hipEventCreate(&pl->ev_s1));
+    return plan_upload_launches(pl);
+}
+
+parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
+                       int device) {
+    parsy_plan* pl = new parsy_plan;
+    try {
+        build_schedule(P, lC, A2p, A2i, nullptr, pl->S);
+    } catch (const std::exception& e) {
+        set_last_error(std::string("plan: ") + e.what());
+        delete pl;
+        return nullptr;
+    }
+    pl->solve_only = pl->S.solve_only;
+    pl->device = device;
+    if (device >= 0 && plan_upload(pl) != 0) {
+        plan_free(pl);
+        return nullptr;
+    }
+    return pl;
+}
+
+void plan_free(parsy_plan* pl) {
+    if (!pl) return;
+    if (pl->device >= 0) {
+        hipSetDevice(pl->device);
+        hipDeviceSynchronize();
+        for (void* d : pl->owned) hipFree(d);
+        for (void* d : pl->launch_owned) hipFree(d);
+        if (pl->xscratch) hipFree(pl->xscratch);
+        if (pl->h_values_dev) hipFree(pl->h_values_dev);
+        if (pl->h_L_dev) hipFree(pl->h_L_dev);
+        if (pl->h_x_dev) hipFree(pl->h_x_dev);
+        for (hipEvent_t e : {pl->ev_f0, pl->ev_f1, pl->ev_s0, pl->ev_s1})
+            if (e) hipEventDestroy(e);
+        for (hipEvent_t e : pl->pev) hipEventDestroy(e);
+    }
+    delete pl;
+}
+
+static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& cursor) {
+    if (!pl->profile) return;
+    if (cursor >= pl->pev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        pl->pev.push_back(e);
+    }
+    if (cursor >= pl->pev_kind.size()) pl->pev_kind.push_back(kind);
+    else pl->pev_kind[cursor] = kind;
+    hipEventRecord(pl->pev[cursor], stream);
+    ++cursor;
+}
+
+static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double* L, const double* Lc,
+                         double* x, int nrhs, int ldx, hipStream_t stream) {
+    size_t cursor = 0;
+    for (const Launch& l : seq) {
+        profile_mark(pl, l.kind, stream, cursor);
+        switch (l.kind) {
+            case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, L, stream); break;
+            case kLaunchTiles: launch_chol_tiles(pl->dp, l.first, l.count, false, 0, L, stream); break;
+            case kLaunchInner: launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, L, stream); break;
+            case kLaunchPanel: launch_chol_panel(pl->dp, l.first, l.count, L, stream); break;
+            case kLaunchFixup: launch_chol_fixup(pl->dp, l.first, l.count, L, stream); break;
+            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
+            case kLaunchSolvePanel:
+                launch_solve_panel(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, stream);
+                break;
+            case kLaunchSolveFixup:
+                launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
+                break;
+        }
+    }
+    profile_mark(pl, -1, stream, cursor);
+    if (pl->profile) pl->pev_kind.resize(cursor);
+}
+
+int plan_collect_profile(parsy_plan* pl) {
+    // after a synchronised profiled run: add the elapsed time of each launch to its kind
+    if (!pl->profile || pl->pev_kind.size() < 2) return -1;
+    for (size_t i = 0; i + 1 < pl->pev_kind.size(); ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pl->pev[i], pl->pev[i + 1]) != hipSuccess) return -1;
+        const int k = pl->pev_kind[i];
+        if (k >= 0 && k < 8) {
+            pl->kind_ms[k] += ms;
+            pl->kind_launches[k] += 1;
+        }
+    }
+    pl->profiled_runs += 1;
+    return 0;
+}
+
+int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream) {
+    if (pl->device < 0) {
+        set_last_error("parsy_factor: plan was built without a device (device < 0)");
+        return -1;
+    }
+    if (pl->solve_only) {
+        set_last_error("parsy_factor: plan was built from L's pattern only (solve-only)");
+        return -1;
+    }
+    const Schedule& S = pl->S;
+    PARSY_HIP(hipEventRecord(pl->ev_f0, stream));
+    PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
+    // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)
+    PARSY_HIP(hipMemsetAsync(pl->dp.info, 0x7f, sizeof(int), stream));
+    launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
+    run_launches(pl, S.chol, d_L, d_L, nullptr, 0, 0, stream);
+    PARSY_HIP(hipGetLastError());
+    PARSY_HIP(hipEventRecord(pl->ev_f1, stream));
+    pl->have_f = true;
+    return 0;
+}
+
+int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx,
+               hipStream_t stream) {
+    if (pl->device < 0) {
+        set_last_error("parsy_solve: plan was built without a device (device < 0)");
+        return -1;
+    }
+    if (nrhs < 1 || ldx < pl->S.n) {
+        set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
+        return -1;
+    }
+    const int64_t need = (int64_t)ldx * nrhs;
+    if (!pl->S.solve_fix_list.empty() && pl->xscratch_len < need) {
+        // grows only when a larger right-hand-side block shows up (not per call)
+        if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
+        pl->xscratch = nullptr;
+        PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
+        pl->xscratch_len = need;
+    }
+    PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+    run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
+    PARSY_HIP(hipGetLastError());
+    PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+    pl->have_s = true;
+    return 0;
+}
+
+}  // namespace parsy

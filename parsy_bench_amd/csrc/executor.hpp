@@ -1,0 +1,56 @@
+// Device-resident plan: pattern + schedule in HBM, launch sequencing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "schedule.hpp"
+
+struct parsy_plan {
+    parsy::Schedule S;
+    int device = -1;          // < 0: host schedule only
+    bool solve_only = false;  // built from L's pattern alone (no A, no update lists)
+
+    // pattern arrays (uploaded once) and launch arrays (re-uploaded by set_active)
+    std::vector<void*> owned;        // every hipMalloc'd block, for destroy()
+    std::vector<void*> launch_owned; // the launch-array blocks
+    parsy::DevicePattern dp;
+    int64_t device_bytes = 0;
+
+    double* xscratch = nullptr;
+    int64_t xscratch_len = 0;
+
+    // buffers of the host-convenience calls
+    double* h_values_dev = nullptr;
+    double* h_L_dev = nullptr;
+    double* h_x_dev = nullptr;
+    int64_t h_x_len = 0;
+
+    hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    bool have_f = false, have_s = false;
+
+    // optional per-launch profiling (hipEvents on the launch stream)
+    bool profile = false;
+    std::vector<hipEvent_t> pev;
+    std::vector<int> pev_kind;
+    double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int kind_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int profiled_runs = 0;
+};
+
+namespace parsy {
+
+// Build a plan. A2p/A2i may be null => solve-only plan. device < 0 => no HIP calls.
+parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
+                       int device);
+void plan_free(parsy_plan* plan);
+int plan_upload_launches(parsy_plan* plan);
+int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream);
+int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
+               hipStream_t stream);
+int plan_collect_profile(parsy_plan* plan);
+
+}  // namespace parsy

@@ -1,0 +1,47 @@
+// Launch wrappers of the HIP kernels (chol_kernels.hip, trsv_kernels.hip).
+// All pointers are device pointers; launches are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "schedule.hpp"
+
+namespace parsy {
+
+struct DevicePattern {           // device copies of Schedule arrays
+    const SnDesc* sn = nullptr;
+    const UpdDesc* upd = nullptr;
+    const int32_t* relpos = nullptr;
+    const int64_t* a_dst = nullptr;
+    const int32_t* rows = nullptr;
+    const ColBlkEntry* colblk = nullptr;
+    const int32_t* small_list = nullptr;
+    const TileDesc* tiles = nullptr;
+    const PanelDesc* panels = nullptr;
+    const int32_t* fix_list = nullptr;
+    const int32_t* solve_small_list = nullptr;
+    const PanelDesc* solve_panels = nullptr;
+    const int32_t* solve_fix_list = nullptr;
+    double* dscratch = nullptr;  // parked 64x64 diagonal blocks
+    int* info = nullptr;         // first failed pivot column + 1 (INT_MAX = none)
+};
+
+// lValues[a_dst[q]] = values[q]
+void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int64_t nnz,
+                      hipStream_t stream);
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
+                       hipStream_t stream);
+void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, double* L,
+                       hipStream_t stream);
+void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+
+void launch_solve_small(const DevicePattern& P, int first, int count, const double* L, double* x,
+                        int nrhs, int ldx, hipStream_t stream);
+void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
+                        double* xscratch, int nrhs, int ldx, hipStream_t stream);
+void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
+                        const double* xscratch, int nrhs, int ldx, hipStream_t stream);
+
+}  // namespace parsy

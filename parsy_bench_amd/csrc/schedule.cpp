@@ -1,0 +1,253 @@
+// Host-side construction of the device schedule (see schedule.hpp).
+#include "schedule.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+
+namespace parsy {
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
+                    const uint8_t* active, Schedule& S) {
+    S = Schedule();
+    const int n = P.n, ns = P.nsuper;
+    S.n = n;
+    S.nsuper = ns;
+    S.solve_only = (A2p == nullptr);
+    S.nnzA = A2p ? A2p[n] : 0;
+    S.rows.assign(P.s, P.s + P.i_ptr[n]);
+    S.ssize = (int64_t)P.i_ptr[n];
+    S.xsize = (int64_t)lC[n];
+
+    // --- supernode descriptors ------------------------------------------------
+    S.sn.resize(ns);
+    for (int t = 0; t < ns; ++t) {
+        SnDesc& d = S.sn[t];
+        d.c0 = P.super[t];
+        d.w = P.super[t + 1] - P.super[t];
+        d.r = (int)(P.i_ptr[P.super[t + 1]] - P.i_ptr[P.super[t]]);
+        d.px = (int64_t)lC[d.c0];
+        d.pi = (int64_t)P.i_ptr[d.c0];
+        d.a0 = A2p ? A2p[d.c0] : 0;
+        d.a1 = A2p ? A2p[P.super[t + 1]] : 0;
+        d.upd0 = 0;
+        d.nupd = 0;
+        d.dslot = -1;
+        d.pad = 0;
+        if (d.w <= 0 || d.r < d.w) throw std::runtime_error("schedule: malformed supernode");
+        if ((int64_t)d.w * d.r > 0x7fffffffLL)
+            throw std::runtime_error("schedule: a single panel exceeds 2^31 entries");
+        for (int col = d.c0; col < d.c0 + d.w; ++col)
+            if (lC[col + 1] - lC[col] != (size_t)d.r || P.i_ptr[col] != P.i_ptr[d.c0])
+                throw std::runtime_error("schedule: lC / Li_ptr are not a column-major panel layout");
+        S.max_width = std::max(S.max_width, d.w);
+        S.max_rows = std::max(S.max_rows, d.r);
+        S.nnzL += (int64_t)d.w * d.r - (int64_t)d.w * (d.w - 1) / 2;
+        for (int k = 0; k < d.w; ++k) S.flops_stored += (double)(d.r - k) * (double)(d.r - k);
+        for (int k = 0; k < d.w; ++k)
+            if (S.rows[d.pi + k] != d.c0 + k)
+                throw std::runtime_error("schedule: supernode rows do not start with its own columns");
+    }
+
+    // --- update lists, relative indices, A scatter map ---------------------------
+    std::vector<int64_t> uptr(ns + 1, 0);
+    std::vector<int> usn, ulb, uub;
+    if (!S.solve_only) build_update_lists(P, uptr, usn, ulb, uub);
+    S.upd.resize(usn.size());
+    S.a_dst.assign((size_t)S.nnzA, 0);
+    std::vector<int> map(n, -1), stamp(n, -1);
+    for (int t = 0; t < ns; ++t) {
+        SnDesc& T = S.sn[t];
+        for (int k = 0; k < T.r; ++k) {
+            const int row = S.rows[T.pi + k];
+            map[row] = k;
+            stamp[row] = t;
+        }
+        for (int col = T.c0; !S.solve_only && col < T.c0 + T.w; ++col)
+            for (int q = A2p[col]; q < A2p[col + 1]; ++q) {
+                const int row = A2i[q];
+                if (stamp[row] != t) throw std::runtime_error("schedule: A entry outside the pattern of L");
+                S.a_dst[q] = (int64_t)lC[col] + map[row];
+            }
+        T.upd0 = uptr[t];
+        T.nupd = (int)(uptr[t + 1] - uptr[t]);
+        for (int64_t u = uptr[t]; u < uptr[t + 1]; ++u) {
+            const SnDesc& D = S.sn[usn[u]];
+            UpdDesc& U = S.upd[u];
+            U.src = D.px + ulb[u];
+            U.ld = D.r;
+            U.K = D.w;
+            U.m = D.r - ulb[u];
+            U.n1 = uub[u] - ulb[u] + 1;
+            U.rel = (int64_t)S.relpos.size();
+            for (int k = ulb[u]; k < D.r; ++k) {
+                const int row = S.rows[D.pi + k];
+                if (stamp[row] != t)
+                    throw std::runtime_error("schedule: descendant row missing from the target's pattern");
+                S.relpos.push_back(map[row]);
+            }
+            S.update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
+            S.reread_bytes += 8.0 * (double)U.K * U.m;
+        }
+    }
+
+    // --- tiled supernodes: scratch slots and per-block-column update lists ----------
+    S.sn_cb0.assign(ns, -1);
+    std::vector<std::vector<ColBlkEntry>> bucket;
+    for (int t = 0; t < ns; ++t) {
+        SnDesc& T = S.sn[t];
+        if (is_small(T)) {
+            S.n_small++;
+            continue;
+        }
+        S.n_big++;
+        const int nbc = ceil_div(T.w, kTile);
+        T.dslot = (int32_t)S.n_dslots;
+        S.n_dslots += nbc;
+        bucket.assign(nbc, {});
+        for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
+            const UpdDesc& U = S.upd[u];
+            const int32_t* rel = &S.relpos[U.rel];
+            const int jfirst = rel[0] / kTile, jlast = rel[U.n1 - 1] / kTile;
+            for (int J = jfirst; J <= jlast; ++J) {
+                ColBlkEntry e;
+                e.upd = (int32_t)u;
+                e.jlo = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile) - rel);
+                e.jmid = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile + kSub) - rel);
+                e.jhi = (int32_t)(std::lower_bound(rel, rel + U.n1, (J + 1) * kTile) - rel);
+                if (e.jhi > e.jlo) bucket[J].push_back(e);
+            }
+        }
+        S.sn_cb0[t] = (int64_t)S.cb_ptr.size();
+        for (int J = 0; J < nbc; ++J) {
+            S.cb_ptr.push_back((int64_t)S.colblk.size());
+            S.colblk.insert(S.colblk.end(), bucket[J].begin(), bucket[J].end());
+        }
+        S.cb_ptr.push_back((int64_t)S.colblk.size());
+    }
+    if (S.colblk.size() > 0x7fffffffULL) throw std::runtime_error("schedule: block-column lists exceed int32");
+
+    std::vector<int> tree(P.sparent, P.sparent + ns);
+    level_sets(tree, S.levelPtr, S.levelSet);
+    S.nlevels = (int)S.levelPtr.size() - 1;
+    build_launches(S, active);
+}
+
+void build_launches(Schedule& S, const uint8_t* active) {
+    const int ns = S.nsuper;
+    S.active.assign(ns, 1);
+    if (active) S.active.assign(active, active + ns);
+    S.small_list.clear();
+    S.tiles.clear();
+    S.panels.clear();
+    S.fix_list.clear();
+    S.chol.clear();
+    S.solve_small_list.clear();
+    S.solve_panels.clear();
+    S.solve_fix_list.clear();
+    S.solve.clear();
+
+    std::vector<int> bigs, sbigs;
+    for (int lev = 0; lev < S.nlevels; ++lev) {
+        bigs.clear();
+        sbigs.clear();
+        // ---- Cholesky -------------------------------------------------------------
+        if (!S.solve_only) {
+            Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (!S.active[t]) continue;
+                const SnDesc& T = S.sn[t];
+                if (is_small(T)) {
+                    S.small_list.push_back(t);
+                    L.lds_bytes = std::max<int32_t>(L.lds_bytes, T.w * T.r * (int)sizeof(double));
+                } else {
+                    bigs.push_back(t);
+                }
+            }
+            L.count = (int32_t)S.small_list.size() - L.first;
+            if (L.count > 0) S.chol.push_back(L);
+        }
+        if (!S.solve_only && !bigs.empty()) {
+            Launch L{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0};
+            int maxnb = 0;
+            for (int t : bigs) {
+                const SnDesc& T = S.sn[t];
+                const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+                maxnb = std::max(maxnb, nbc);
+                for (int J = 0; J < nbc; ++J) {
+                    const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + J], c1 = S.cb_ptr[S.sn_cb0[t] + J + 1];
+                    if (c1 == c0) continue;
+                    for (int I = J; I < nbr; ++I)
+                        S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, (int32_t)c0, (int32_t)c1, 0});
+                }
+            }
+            L.count = (int32_t)S.tiles.size() - L.first;
+            if (L.count > 0) S.chol.push_back(L);
+            for (int jb = 0; jb < maxnb; ++jb) {
+                if (jb > 0) {
+                    Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0};
+                    for (int t : bigs) {
+                        const SnDesc& T = S.sn[t];
+                        if (ceil_div(T.w, kTile) <= jb) continue;
+                        const int nbr = ceil_div(T.r, kTile);
+                        for (int I = jb; I < nbr; ++I)
+                            S.tiles.push_back(TileDesc{t, I * kTile, jb * kTile, 0, 0, 0});
+                    }
+                    Li.count = (int32_t)S.tiles.size() - Li.first;
+                    if (Li.count > 0) S.chol.push_back(Li);
+                }
+                Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0};
+                for (int t : bigs) {
+                    const SnDesc& T = S.sn[t];
+                    if (ceil_div(T.w, kTile) <= jb) continue;
+                    const int wb = std::min(kTile, T.w - jb * kTile);
+                    S.panels.push_back(PanelDesc{t, jb, -1, 0});
+                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
+                        S.panels.push_back(PanelDesc{t, jb, row0, 0});
+                }
+                Lp.count = (int32_t)S.panels.size() - Lp.first;
+                S.chol.push_back(Lp);
+            }
+            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0};
+            S.fix_list.insert(S.fix_list.end(), bigs.begin(), bigs.end());
+            S.chol.push_back(Lf);
+        }
+        // ---- forward solve ----------------------------------------------------------
+        {
+            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (!S.active[t]) continue;
+                if (S.sn[t].w <= kTile) S.solve_small_list.push_back(t);
+                else sbigs.push_back(t);
+            }
+            L.count = (int32_t)S.solve_small_list.size() - L.first;
+            if (L.count > 0) S.solve.push_back(L);
+        }
+        if (!sbigs.empty()) {
+            int maxnb = 0;
+            for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
+            for (int jb = 0; jb < maxnb; ++jb) {
+                Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0};
+                for (int t : sbigs) {
+                    const SnDesc& T = S.sn[t];
+                    if (ceil_div(T.w, kTile) <= jb) continue;
+                    const int wb = std::min(kTile, T.w - jb * kTile);
+                    S.solve_panels.push_back(PanelDesc{t, jb, -1, 0});
+                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
+                        S.solve_panels.push_back(PanelDesc{t, jb, row0, 0});
+                }
+                Lp.count = (int32_t)S.solve_panels.size() - Lp.first;
+                S.solve.push_back(Lp);
+            }
+            S.solve_fix_list.insert(S.solve_fix_list.end(), sbigs.begin(), sbigs.end());
+        }
+    }
+    if (!S.solve_fix_list.empty())
+        S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0});
+}
+
+}  // namespace parsy

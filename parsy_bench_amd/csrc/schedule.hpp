@@ -1,0 +1,136 @@
+// Device schedule of the supernodal Cholesky and the BCSC forward solve.
+//
+// Built once per pattern on the host from the reference-shaped symbolic arrays
+// (the argument lists of cholesky/parallel_PB_Cholesky_05.h:27-39 and
+// triangularSolve/Triangular_BCSC.h:115) and uploaded to HBM; the numeric kernels
+// only ever read flat descriptor arrays.
+//
+// Cholesky, one etree level (wavefront) at a time:
+//   SMALL   one workgroup per supernode whose panel (rows x width doubles) fits
+//           the LDS budget: assemble, apply every update, POTRF+TRSM, store.
+//   TILES   every other supernode is cut into 64x64 tiles of its panel (lower
+//           trapezoid only); one workgroup per tile applies the external updates
+//           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).
+//   then per 64-wide block column jb of those supernodes:
+//   INNER   (jb > 0) the in-supernode update of block column jb by block columns
+//           0..jb-1 (dense SYRK/GEMM, same MFMA kernel, identity row map)
+//   PANEL   POTRF of the 64x64 diagonal block (redundantly per workgroup, result
+//           parked in a scratch slab) + TRSM of 256-row chunks below it
+//   FIXUP   once per level: parked diagonal blocks are copied into the panels.
+// The solve mirrors it (SOLVE_SMALL: width <= 64; SOLVE_PANEL per block column;
+// one SOLVE_FIXUP at the end).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "inspector.hpp"
+
+namespace parsy {
+
+constexpr int kTile = 64;             // tile edge of the tiled path / block-column width
+constexpr int kSub = 32;              // per-wave sub-tile edge
+constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
+constexpr int kSmallMaxWidth = 64;
+constexpr int kPanelRows = 256;       // TRSM / solve row chunk per workgroup
+
+struct SnDesc {       // one per supernode
+    int64_t px;       // offset of the panel in lValues
+    int64_t pi;       // offset of the row ids in lR
+    int64_t upd0;     // first update descriptor
+    int32_t c0, w, r; // first column, width, rows (incl. the w diagonal rows)
+    int32_t nupd;     // number of update descriptors
+    int32_t a0, a1;   // entries [a0,a1) of A2 belong to this supernode's columns
+    int32_t dslot;    // first 64x64 scratch slot for parked diagonal blocks (-1: SMALL)
+    int32_t pad;
+};
+
+struct UpdDesc {      // one per (target, descendant) pair, in the reference's update order
+    int64_t src;      // offset in lValues of row lb of the descendant's panel
+    int64_t rel;      // offset into relpos: position in the target's row list of
+                      // descendant rows lb, lb+1, ...  (the reference's map[lR[..]])
+    int32_t ld;       // rows of the descendant (leading dimension)
+    int32_t K;        // width of the descendant
+    int32_t m;        // nSupRs: descendant rows from lb to the end
+    int32_t n1;       // ndrow1: of those, rows inside the target's columns
+};
+
+struct ColBlkEntry {  // update restricted to one 64-wide block column of a target
+    int32_t upd;      // index into UpdDesc
+    int32_t jlo, jmid, jhi;  // descendant rows [jlo,jmid) hit columns [col0,col0+32), [jmid,jhi) the next 32
+};
+
+struct TileDesc {     // one workgroup of the TILES / INNER kernels
+    int32_t sn;
+    int32_t row0, col0;   // tile origin inside the panel (multiples of 64, row0 >= col0)
+    int32_t cb0, cb1;     // ColBlkEntry range (TILES only)
+    int32_t pad;
+};
+
+struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
+    int32_t sn;
+    int32_t jb;       // block column
+    int32_t row0;     // first panel row of this workgroup's chunk (>= 64*(jb+1)), or -1:
+                      // the workgroup that parks the factored diagonal block / solved x block
+    int32_t pad;
+};
+
+enum LaunchKind : int32_t {
+    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchInner = 2, kLaunchPanel = 3, kLaunchFixup = 4,
+    kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7,
+};
+
+struct Launch {
+    int32_t kind;
+    int32_t first, count;  // range in the kind's descriptor array
+    int32_t level;
+    int32_t jb;            // block column (INNER / PANEL / SOLVE_PANEL)
+    int32_t lds_bytes;     // dynamic LDS (SMALL)
+};
+
+struct Schedule {
+    int n = 0, nsuper = 0, nlevels = 0;
+    bool solve_only = false;       // built without A / update lists: only the solve launches exist
+    int64_t nnzA = 0, ssize = 0, xsize = 0, nnzL = 0;
+    int max_width = 0, max_rows = 0, n_small = 0, n_big = 0;
+    int64_t n_dslots = 0;          // parked diagonal blocks (64*64 doubles each)
+    double flops_stored = 0, update_flops = 0, reread_bytes = 0;
+
+    std::vector<SnDesc> sn;
+    std::vector<UpdDesc> upd;
+    std::vector<int32_t> relpos;
+    std::vector<int64_t> a_dst;     // destination in lValues of every A2 entry
+    std::vector<int32_t> rows;      // lR
+    std::vector<ColBlkEntry> colblk;
+
+    // Cholesky launch data
+    std::vector<int32_t> small_list;
+    std::vector<TileDesc> tiles;       // TILES and INNER descriptors
+    std::vector<PanelDesc> panels;
+    std::vector<int32_t> fix_list;     // big supernodes per level (FIXUP)
+    std::vector<Launch> chol;
+
+    // solve launch data
+    std::vector<int32_t> solve_small_list;
+    std::vector<PanelDesc> solve_panels;
+    std::vector<int32_t> solve_fix_list;  // all big-for-solve supernodes
+    std::vector<Launch> solve;
+
+    std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches
+    std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow
+    std::vector<int64_t> sn_cb0;       // per supernode: first index into cb_ptr (-1: SMALL)
+    std::vector<int64_t> cb_ptr;       // ColBlkEntry ranges per (tiled supernode, block column)
+};
+
+// Build descriptors + launch lists. `active` (nsuper bytes or null = all) restricts
+// the LAUNCHES to a subset of supernodes (multi-GPU shards); descriptors always
+// cover the whole pattern.
+void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
+                    const uint8_t* active, Schedule& out);
+// Recompute only the launch lists for a new active set.
+void build_launches(Schedule& S, const uint8_t* active);
+inline bool is_small(const SnDesc& d) {
+    return d.w <= kSmallMaxWidth && (int64_t)d.w * d.r <= kSmallMaxEntries;
+}
+
+}  // namespace parsy
