@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: supernodal Cholesky factorizations/s (+ BCSC forward
+solves/s) on a SuiteSparse-class SPD matrix, numeric phase only, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one numeric factorization of the workload matrix (pattern analysed and
+uploaded once, outside the timed region -- the reference times only the executor call
+too: examples/choleskyTest01.cpp:209-229).  After the K factorization steps, K forward
+solves are timed the same way and reported as `solves_per_sec`.
+
+N = 1 workload: the nd24k-class stand-in (BASELINE.json configs[1]; the SuiteSparse
+file itself cannot be fetched offline): 3-D 27-point stencil 42^3, geometric nested
+dissection.  N > 1: the same matrix, etree subtrees sharded over the ranks, ONE
+exchange step (RCCL point-to-point gather of the subtree panels onto rank 0), root
+part on rank 0 -- strong scaling, as north_star describes it.
+
+PyTorch is plumbing here: device buffers, the HIP stream, torch.distributed.  All
+numerics run in libparsy_amd.so through its C ABI.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, datasheet (the microarch guide lists no f64 row)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sym, threads_all: int, want_solve: bool = True):
+    """Time the CPU port (oracle/, test infrastructure) on this host: one factorization of
+    the same matrix at 1 thread and at all threads; the faster one is reported."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as O
+    from parsy_bench_amd import inspector as I
+    O.lib()
+    blas = O.bind_system_blas()
+    hl = I.trivial_hlevel(sym)
+    best = None
+    lo = None
+    for th in sorted({1, threads_all}):
+        t0 = time.perf_counter()
+        ok, lv, _ = O.cholesky_05(sym, sym.A2x, hl, threads=th)
+        dt = time.perf_counter() - t0
+        if not ok:
+            raise RuntimeError("CPU port reported a non-positive pivot")
+        lo = lv
+        if best is None or dt < best[0]:
+            best = (dt, th)
+        if dt > 40:
+            break
+    out = {"value": 1.0 / best[0], "unit": "factorizations/s", "cores": best[1], "kind": "port",
+           "sample": f"1 factorization of the same matrix per thread count (1 and {threads_all}), "
+                     f"best of the two; oracle/parsy_oracle.c -O3 -fopenmp, dense kernels: "
+                     f"{blas or 'built-in loops'}",
+           "seconds": best[0]}
+    if want_solve:
+        b = O.rhs_init_blocked(sym, lo)
+        t0 = time.perf_counter()
+        x = O.blocked_lsolve(sym, lo, b, "H1", threads=threads_all)
+        out["solves_per_sec"] = 1.0 / (time.perf_counter() - t0)
+        out["solve_max_abs_err"] = float(np.abs(x - 1.0).max())
+    O.unbind_blas()
+    return out, lo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="nd24k")
+    ap.add_argument("--nrhs", type=int, default=1)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the executor has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
+
+    t0 = time.perf_counter()
+    A, perm = M.workload(args.workload)
+    sym = I.analyze(A, perm)
+    t_inspect = time.perf_counter() - t0
+    plan = api.Plan(sym, local_rank)
+    info = plan.info
+    if rank == 0:
+        log(f"[bench] workload={args.workload} n={sym.n} nnz(A)={sym.nnzA} nsuper={sym.nsuper} "
+            f"nnz(L)={sym.nnzL} xsize={sym.xsize} F={sym.flops_colcount:.4e} "
+            f"executed={sym.flops_stored:.4e} levels={sym.nlevels} maxw={sym.maxSupWid} "
+            f"launches/factor={info['chol_launches']} inspect={t_inspect:.2f}s")
+
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    cut = None
+    plan_root = None
+    if world > 1:
+        cut = MG.cut_subtrees(sym, world)
+        plan.set_active(cut.mask(rank))
+        if rank == 0:
+            plan_root = api.Plan(sym, local_rank)
+            plan_root.set_active(cut.root_mask())
+            log(f"[bench] subtree cut: {len(cut.subtrees)} subtrees, {len(cut.root_nodes)} root-part "
+                f"supernodes, rank cost share {np.round(cut.rank_cost / cut.cost.sum(), 3).tolist()}, "
+                f"root share {cut.cost[cut.root_nodes].sum() / cut.cost.sum():.3f}")
+
+    def factor_step():
+        plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
+        if world > 1:
+            MG.gather_to_root(L, cut, sym, rank, dist)
+            if rank == 0:
+                plan_root.factor_device(values.data_ptr(), L.data_ptr(), stream, init=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---- factorizations ------------------------------------------------------------
+    dt_f = timed(factor_step, args.warmup, args.steps)
+    status = plan.status() if world == 1 else (plan_root.status() if rank == 0 else 0)
+    if status != 0:
+        raise SystemExit(f"factorization reported a non-positive pivot at column {status}")
+
+    # ---- forward solves (rank 0 holds the whole factor) --------------------------------
+    dt_s = None
+    nrhs = args.nrhs
+    solve_plan = None
+    if rank == 0:
+        solve_plan = plan
+        if world > 1:
+            solve_plan = api.Plan(sym, local_rank)  # all supernodes active
+        ones = torch.ones(sym.n, dtype=torch.float64, device=dev)
+        # b = L * 1 on the stored structure (common/Util.h:277), built with torch plumbing only
+        rows = torch.from_numpy(sym.s.astype(np.int64)).to(dev)
+        w = np.diff(sym.super)
+        r = np.diff(sym.i_ptr[sym.super].astype(np.int64))
+        b = torch.zeros(sym.n, dtype=torch.float64, device=dev)
+        # per supernode: b[rows] += sum over columns of the panel
+        for sn in np.argsort(-w * r)[: sym.nsuper]:
+            c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
+            rs = slice(int(sym.i_ptr[c0]), int(sym.i_ptr[c0]) + int(r[sn]))
+            panel = L[int(sym.p[c0]): int(sym.p[c0]) + int(w[sn] * r[sn])].view(int(w[sn]), int(r[sn]))
+            b.index_add_(0, rows[rs], panel.sum(dim=0))
+        B = b.repeat(nrhs).contiguous()
+        X = torch.empty_like(B)
+
+        def solve_step():
+            X.copy_(B)
+            solve_plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+
+        for _ in range(args.warmup):
+            solve_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            solve_step()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        solve_err = float((X.view(nrhs, sym.n) - ones).abs().max().item())
+    if world > 1:
+        dist.barrier()
+
+    # ---- per-kernel timing (hipEvents on the launch stream) for the roofline ---------
+    prof = None
+    if rank == 0 and world == 1 and args.profile_steps > 0:
+        plan.profile(2)
+        for _ in range(args.profile_steps):
+            plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
+            torch.cuda.synchronize()
+            plan.profile_collect()
+        prof_f = plan.profile_get()
+        plan.profile(2)
+        for _ in range(args.profile_steps):
+            X.copy_(B)
+            plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+            torch.cuda.synchronize()
+            plan.profile_collect()
+        prof_s = plan.profile_get()
+        plan.profile(0)
+        prof = (prof_f, prof_s)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt_f / args.steps * 1e3
+    fact_per_s = args.steps / dt_f
+    out = {
+        "metric": "Cholesky factorizations/sec (+ SpTRSV solves/sec), SuiteSparse SPD set",
+        "value": fact_per_s,
+        "unit": "factorizations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}-class stand-in: grid {M.WORKLOADS[args.workload][:3]} "
+                        f"{M.WORKLOADS[args.workload][3]}-point stencil, geometric nested dissection",
+            "n": sym.n, "nnz_A_lower": int(sym.nnzA), "nsuper": sym.nsuper, "nnz_L": int(sym.nnzL),
+            "xsize": int(sym.xsize), "flops_F": sym.flops_colcount, "flops_executed": sym.flops_stored,
+            "etree_levels": sym.nlevels, "launches_per_factorization": info["chol_launches"],
+            "parallelism": "1 GPU" if world == 1 else f"etree subtrees over {world} GPUs + root part on rank 0",
+        },
+        "gflops_F": sym.flops_colcount / (dt_f / args.steps) / 1e9,
+        "solves_per_sec": (args.steps * nrhs / dt_s) if dt_s else None,
+        "solve_nrhs": nrhs,
+        "solve_ms": (dt_s / args.steps * 1e3) if dt_s else None,
+        "solve_max_abs_err_vs_ones": solve_err,
+    }
+
+    if prof is not None:
+        pf, ps = prof
+        runs = pf["runs"]
+        tile_ms = (pf["ms"]["TILES"] + pf["ms"]["INNER"]) / runs
+        tile_launches = (pf["launches"]["TILES"] + pf["launches"]["INNER"]) // runs
+        tile_flops = info["tile_update_flops"] + info["inner_flops"]
+        achieved = tile_flops / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "k_chol_tiles (TILES + INNER launches: FP64-MFMA SYRK/GEMM updates)",
+            "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+            "launches_per_factorization": int(tile_launches),
+            "algorithmic_flops_per_factorization": tile_flops,
+            "avg_launch_ms": tile_ms / max(tile_launches, 1),
+            "kernel_ms_per_factorization": tile_ms,
+            "whole_job": {"flops_F": sym.flops_colcount, "achieved": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12,
+                          "frac": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+            "kind_ms_per_factorization": {k: v / runs for k, v in pf["ms"].items() if v > 0},
+        }
+        sruns = ps["runs"]
+        solve_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
+        s_ms = sum(ps["ms"].values()) / sruns
+        out["roofline_solve"] = {
+            "bound": "hbm", "achieved": solve_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (solve_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms > 0 else 0.0,
+            "algorithmic_bytes_per_solve": solve_bytes, "traffic": None,
+            "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
+        }
+
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            cb, lo = cpu_baseline(sym, os.cpu_count() or 1)
+            out["cpu_baseline"] = cb
+            plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
+            torch.cuda.synchronize()
+            lv = L.cpu().numpy()
+            out["parity"] = {"max_abs_diff_vs_cpu_port_rel": float(np.abs(lv - lo).max() / np.abs(lo).max())}
+        except Exception as e:  # the baseline is reporting only; never lose the GPU numbers to it
+            out["cpu_baseline"] = {"value": None, "unit": "factorizations/s", "cores": 0, "kind": "port",
+                                   "sample": f"failed: {e}"}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,8 @@ typedef struct parsy_plan_info {
     double flops_stored;           /* executed flops on the stored structure */
     double update_flops;           /* flops in the SYRK/GEMM update kernels */
     double reread_bytes;           /* left-looking re-read traffic 8*sum K*nSupRs */
+    double inner_flops;            /* in-supernode SYRK/GEMM flops of the tiled path */
+    double tile_update_flops;      /* external-update flops applied by the tile kernel */
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).
@@ -142,6 +144,12 @@ int parsy_plan_set_active(parsy_plan* plan, const uint8_t* mask);
  * Returns 0 when the launches were enqueued, <0 on a HIP error. */
 int parsy_factor_device(parsy_plan* plan, const double* d_values, double* d_lValues,
                         void* stream);
+/* As parsy_factor_device with flags: PARSY_FACTOR_NO_INIT skips the zero-fill and the
+ * A scatter (multi-GPU: the root-part pass on a buffer that already holds A and the
+ * gathered subtree panels). */
+#define PARSY_FACTOR_NO_INIT 1
+int parsy_factor_device_ex(parsy_plan* plan, const double* d_values, double* d_lValues,
+                           void* stream, int flags);
 /* After the stream has been synchronised: 0 = factor ok, k > 0 = first
  * non-positive pivot seen at (1-based) column k, as LAPACK's dpotrf info. */
 int parsy_factor_status(parsy_plan* plan);

@@ -182,6 +182,10 @@ def bind_system_blas() -> str:
     """Point the oracle's four dense operations at a Fortran-convention BLAS/LAPACK
     present on this machine (MKL first -- what the reference links -- then scipy's
     OpenBLAS).  Returns a label of what was bound ('' = built-in loops kept)."""
+    import os
+    # MKL's default (Intel OpenMP) threading layer next to libgomp computes garbage
+    # (SURVEY.md 8c trap 2): make MKL use the GNU runtime this oracle is built with.
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
     cands = [("/opt/conda/lib/libmkl_rt.so", ("dsyrk", "dgemm", "dpotrf", "dtrsm"), "mkl_rt")]
     try:
         import scipy

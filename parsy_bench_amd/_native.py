@@ -48,6 +48,7 @@ class PlanInfo(C.Structure):
         ("nnzA", C.c_int64), ("ssize", C.c_int64), ("xsize", C.c_int64), ("nnzL", C.c_int64),
         ("n_updates", C.c_int64), ("relpos_len", C.c_int64), ("device_bytes", C.c_int64),
         ("flops_stored", C.c_double), ("update_flops", C.c_double), ("reread_bytes", C.c_double),
+        ("inner_flops", C.c_double), ("tile_update_flops", C.c_double),
     ]
 
     def as_dict(self):
@@ -64,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
     "parsy_grid_nested_dissection", "parsy_plan_profile", "parsy_plan_profile_collect",
-    "parsy_plan_profile_get",
+    "parsy_plan_profile_get", "parsy_factor_device_ex",
 ]
 
 
@@ -87,6 +88,7 @@ def _declare(lib):
     lib.parsy_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
     lib.parsy_plan_set_active.argtypes = [vp, vp]
     lib.parsy_factor_device.argtypes = [vp, vp, vp, vp]
+    lib.parsy_factor_device_ex.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.parsy_factor_status.argtypes = [vp]
     lib.parsy_solve_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.parsy_factor_host.argtypes = [vp, vp, vp, vp]

@@ -180,8 +180,8 @@ class Plan:
         return (X[:, 0].copy() if one else np.ascontiguousarray(X)), sec.value
 
     # device-pointer API ---------------------------------------------------------
-    def factor_device(self, d_values: int, d_lValues: int, stream: int = 0) -> None:
-        if N.lib().parsy_factor_device(self._h, d_values, d_lValues, stream) != 0:
+    def factor_device(self, d_values: int, d_lValues: int, stream: int = 0, init: bool = True) -> None:
+        if N.lib().parsy_factor_device_ex(self._h, d_values, d_lValues, stream, 0 if init else 1) != 0:
             raise RuntimeError("parsy_factor_device failed: " + N.last_error())
 
     def solve_device(self, d_lValues: int, d_x: int, nrhs: int, ldx: int, stream: int = 0) -> None:

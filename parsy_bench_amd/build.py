@@ -37,11 +37,27 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> Path:
+def build_native(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None,
+                 objdir: Path | None = None) -> Path:
+    """extra_flags/out/objdir exist for diagnostic builds (tools/); the product is the default."""
+    global OBJ, LIB
     hipcc = _hipcc()
+    saved = (OBJ, LIB)
+    if objdir is not None:
+        OBJ = Path(objdir)
+    if out is not None:
+        LIB = Path(out)
+    try:
+        return _build(hipcc, force, verbose, list(extra_flags))
+    finally:
+        OBJ, LIB = saved
+
+
+def _build(hipcc, force, verbose, extra_flags) -> Path:
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.h")) + [PKG.parent / "include" / "parsy_amd.h"]
-    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", str(PKG.parent / "include")]
+    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", str(PKG.parent / "include"),
+              *extra_flags]
     jobs = []
     for src in HOST_SOURCES + HIP_SOURCES:
         sp = CSRC / src

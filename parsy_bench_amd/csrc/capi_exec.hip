@@ -248,6 +248,8 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->flops_stored = S.flops_stored;
     o->update_flops = S.update_flops;
     o->reread_bytes = S.reread_bytes;
+    o->inner_flops = S.inner_flops;
+    o->tile_update_flops = S.tile_update_flops;
     return 0;
 }
 
@@ -263,6 +265,16 @@ int parsy_factor_device(parsy_plan* pl, const double* d_values, double* d_lValue
         return -1;
     }
     return parsy::plan_factor(pl, d_values, d_lValues, (hipStream_t)stream);
+}
+
+int parsy_factor_device_ex(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream,
+                           int flags) {
+    if (!pl || !d_values || !d_lValues) {
+        set_last_error("parsy_factor_device_ex: null argument");
+        return -1;
+    }
+    return parsy::plan_factor(pl, d_values, d_lValues, (hipStream_t)stream,
+                              (flags & PARSY_FACTOR_NO_INIT) == 0);
 }
 
 int parsy_factor_status(parsy_plan* pl) {
@@ -355,7 +367,7 @@ int parsy_solve_host(parsy_plan* pl, const double* lValues, double* x, int nrhs,
     if (!pl->h_L_dev) CAPI_HIP(hipMalloc((void**)&pl->h_L_dev, std::max<int64_t>(S.xsize, 1) * 8), -1);
     const int64_t need = (int64_t)ldx * nrhs;
     if (pl->h_x_len < need) {
-        if (pl->h_x_dev) hipFree(pl->h_x_dev);
+        if (pl->h_x_dev) (void)hipFree(pl->h_x_dev);
         pl->h_x_dev = nullptr;
         CAPI_HIP(hipMalloc((void**)&pl->h_x_dev, (size_t)need * 8), -1);
         pl->h_x_len = need;

@@ -23,6 +23,15 @@ static constexpr int kLdSub = kSub + 1;   // padded leading dimension of a wave'
 static constexpr int kLdDiag = kTile + 1; // padded leading dimension of a diagonal block in LDS
 static constexpr int kChunk = 256;        // update entries staged per pass of the tile kernel
 
+#ifdef PARSY_STAMPS
+// diagnostic build only: phase stamps (100 MHz wall clock) of the last PANEL workgroup 0
+// and the last potrf-ing tile workgroup; read back with parsy_debug_stamps().
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { if (threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // A -> L scatter (reference :104-112, hoisted: the destination of every entry
 // is precomputed).  HBM-bound, 16 B read + 8 B written per entry.
@@ -138,14 +147,72 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
     r2 = l2;
 }
 
+// ---------------------------------------------------------------------------
+// POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked:
+// thread (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers; per column
+// j one LDS broadcast of the pivot column (double-buffered: one barrier per column)
+// and a rank-1 update in registers.  Entries outside the block (nb < 64) must be an
+// identity so that the loop is uniform.  Strictly-upper entries pick up garbage
+// that is never stored.  `colbuf` is 2 x 64 doubles of LDS.  On return a[][] holds the
+// factor; `bad` receives (1-based) the first column whose pivot was not positive.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double (*colbuf)[kTile], int ti,
+                                             int tj, int nb, int& bad) {
+    const bool lower = ti >= tj;
+    bad = 0;
+    for (int tjj = 0; tjj < kTile / 4; ++tjj) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * tjj + jj;
+            double* __restrict__ buf = colbuf[j & 1];
+            if (tj == tjj && lower) {
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) buf[4 * ti + ri] = a[ri][jj];
+            }
+            __syncthreads();
+            const double d = buf[j];
+            if (j < nb && !(d > 0.0) && bad == 0) bad = j + 1;
+            if (lower && tj >= tjj) {
+                // 1/sqrt(d) directly (one rsq + refinement instead of sqrt then divide: this
+                // chain is the critical path of every block step); l_jj = d * rsqrt(d)
+                const double inv = rsqrt(d);
+                const double sq = d * inv;
+                double li[4], lc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    li[q] = buf[4 * ti + q] * inv;
+                    lc[q] = buf[4 * tj + q] * inv;
+                }
+                if (tj > tjj) {
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) a[ri][ci] = fma(-li[ri], lc[ci], a[ri][ci]);
+                } else {
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) {
+#pragma unroll
+                        for (int ci = jj + 1; ci < 4; ++ci) a[ri][ci] = fma(-li[ri], lc[ci], a[ri][ci]);
+                        const int row = 4 * ti + ri;
+                        a[ri][jj] = (row == j) ? sq : li[ri];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool INNER>
 __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restrict__ sn,
                                                          const UpdDesc* __restrict__ upd,
                                                          const int32_t* __restrict__ relpos,
                                                          const ColBlkEntry* __restrict__ colblk,
                                                          const TileDesc* __restrict__ tiles, int jb,
-                                                         double* __restrict__ L) {
+                                                         double* __restrict__ L,
+                                                         double* __restrict__ dscratch,
+                                                         int* __restrict__ info) {
     __shared__ double T[4][kSub * kLdSub];
+    __shared__ double colbuf[2][kTile];
     __shared__ int64_t e_src[kChunk];
     __shared__ int64_t e_rel[kChunk];
     __shared__ int32_t e_ld[kChunk], e_K[kChunk];
@@ -157,6 +224,8 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
     const SnDesc D = sn[td.sn];
     const int r = D.r, w = D.w;
     double* __restrict__ G = L + D.px;
+    const bool stamp_wg = td.row0 == td.col0 && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
+    if (stamp_wg) STAMP(8);
 
     const int wa = wave >> 1, wb = wave & 1;
     const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
@@ -165,10 +234,19 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
     double* __restrict__ Tw = T[wave];
 
     if (wave_on) {
-        for (int e = lane; e < kSub * kSub; e += 64) {
+        // all 16 loads of the lane are issued before the first LDS store
+        double tv[kSub * kSub / 64];
+#pragma unroll
+        for (int q = 0; q < kSub * kSub / 64; ++q) {
+            const int e = q * 64 + lane;
             const int cc = e >> 5, rr = e & 31;
             const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
-            Tw[cc * kLdSub + rr] = in ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+            tv[q] = in ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kSub * kSub / 64; ++q) {
+            const int e = q * 64 + lane;
+            Tw[(e >> 5) * kLdSub + (e & 31)] = tv[q];
         }
     }
 
@@ -178,10 +256,10 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
         __syncthreads();  // previous chunk fully consumed
         if (INNER) {
             if (tid == 0) {
-                e_src[0] = D.px;
+                e_src[0] = D.px + (int64_t)jb * kTile * r;  // block column jb of the same panel
                 e_rel[0] = -1;
                 e_ld[0] = r;
-                e_K[0] = jb * kTile;
+                e_K[0] = min(kTile, w - jb * kTile);
                 e_i0[0] = td.row0;
                 e_i1[0] = min(td.row0 + kSub, r);
                 e_i2[0] = min(td.row0 + kTile, r);
@@ -243,17 +321,45 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
             const double* pb0 = src + min(ja + l15, jbnd - 1);
             const double* pb1 = src + min(ja + 16 + l15, jbnd - 1);
             double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-            for (int k0 = 0; k0 < K; k0 += 4) {
-                const int k = k0 + kq;
-                const bool kv = k < K;
-                const int64_t off = (int64_t)(kv ? k : 0) * ld;
-                double a0 = pa0[off], b0 = pb0[off];
-                double a1 = two_r ? pa1[off] : 0.0, b1 = two_c ? pb1[off] : 0.0;
-                if (!kv) { a0 = 0.0; a1 = 0.0; b0 = 0.0; b1 = 0.0; }
-                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
-                if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
-                if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
-                if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+            // 16 k per trip, software-pipelined: the 16 loads of trip t+1 are in flight
+            // while the 16 MFMAs of trip t issue.
+            double a0[4], a1[4], b0[4], b1[4], na0[4], na1[4], nb0[4], nb1[4];
+            auto load_trip = [&](int k0, double (&xa0)[4], double (&xa1)[4], double (&xb0)[4],
+                                 double (&xb1)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 4 * u + kq;
+                    const bool kv = k < K;
+                    const int64_t off = (int64_t)(kv ? k : 0) * ld;
+                    const double va0 = pa0[off], vb0 = pb0[off];
+                    const double va1 = two_r ? pa1[off] : 0.0, vb1 = two_c ? pb1[off] : 0.0;
+                    xa0[u] = kv ? va0 : 0.0;
+                    xb0[u] = kv ? vb0 : 0.0;
+                    xa1[u] = kv ? va1 : 0.0;
+                    xb1[u] = kv ? vb1 : 0.0;
+                }
+            };
+            load_trip(0, a0, a1, b0, b1);
+            for (int k0 = 0; k0 < K; k0 += 16) {
+                const bool more = k0 + 16 < K;
+                if (more) load_trip(k0 + 16, na0, na1, nb0, nb1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + 4 * u >= K) break;
+                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c00, 0, 0, 0);
+                    if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], c01, 0, 0, 0);
+                    if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], c10, 0, 0, 0);
+                    if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c11, 0, 0, 0);
+                }
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0[u] = na0[u];
+                        a1[u] = na1[u];
+                        b0[u] = nb0[u];
+                        b1[u] = nb1[u];
+                    }
+                }
             }
             // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
             const bool diag_sub = subrow0 == subcol0;
@@ -269,6 +375,7 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
         }
     }
 
+    if (stamp_wg) STAMP(9);
     if (wave_on) {
         for (int e = lane; e < kSub * kSub; e += 64) {
             const int cc = e >> 5, rr = e & 31;
@@ -276,109 +383,152 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
                 G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] = Tw[cc * kLdSub + rr];
         }
     }
+
+    // A diagonal tile that has just received its last update is factored on the spot and
+    // parked in its scratch slot (PANEL's TRSM reads it there, FIXUP copies it into the
+    // panel): block column 0 after the external updates, block column jb+1 after the
+    // right-looking update by block column jb.
+    const bool final_diag = td.row0 == td.col0 && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
+    if (final_diag) {
+        __syncthreads();
+        STAMP(10);
+        const int ti = tid & 15, tj = tid >> 4;
+        const int nb = min(kTile, w - td.col0);
+        double a[4][4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = 4 * ti + ri, c = 4 * tj + ci;
+                double v = (i == c) ? 1.0 : 0.0;
+                if (c < nb && i < nb && i >= c) v = T[(i >> 5) * 2 + (c >> 5)][(c & 31) * kLdSub + (i & 31)];
+                a[ri][ci] = v;
+            }
+        int bad;
+        STAMP(11);
+        potrf64_regs(a, colbuf, ti, tj, nb, bad);
+        STAMP(12);
+        if (tid == 0 && bad) atomicMin(info, D.c0 + td.col0 + bad);
+        double* __restrict__ slot = dscratch + (int64_t)(D.dslot + td.col0 / kTile) * (kTile * kTile);
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = 4 * ti + ri, c = 4 * tj + ci;
+                slot[c * kTile + i] = (c < nb && i < nb && i >= c) ? a[ri][ci] : 0.0;
+            }
+        STAMP(13);
+    }
 }
+
+#ifdef PARSY_STAMPS
+extern "C" void parsy_debug_stamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
     if (inner)
         hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L);
+                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info);
     else
         hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L);
+                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info);
 }
 
 // ---------------------------------------------------------------------------
-// PANEL: POTRF of diagonal block jb (every workgroup factors its own LDS copy;
-// the designated one parks the result in scratch so nobody reads a half-written
-// block) and TRSM of one 256-row chunk below it, one thread per row.
+// PANEL: TRSM of one 128-row chunk below diagonal block jb, staged in LDS.  The
+// factored diagonal block is read from its scratch slot, where the tile kernel parked
+// it (nobody rewrites the slot during this launch).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_chol_panel(const SnDesc* __restrict__ sn,
                                                          const PanelDesc* __restrict__ pds,
                                                          double* __restrict__ L,
-                                                         double* __restrict__ dscratch,
-                                                         int* __restrict__ info) {
+                                                         const double* __restrict__ dscratch) {
     __shared__ double Dg[kTile * kLdDiag];
     __shared__ double invd[kTile];
+    __shared__ double Bs[kTile][kPanelRows + 1];
     const int tid = threadIdx.x;
     const PanelDesc pd = pds[blockIdx.x];
     const SnDesc D = sn[pd.sn];
     const int r = D.r, cb = pd.jb * kTile, wbk = min(kTile, D.w - cb);
     double* __restrict__ G = L + D.px;
+    if (blockIdx.x == 0) STAMP(0);
 
-    for (int e = tid; e < kTile * kTile; e += kThreads) {
-        const int c = e >> 6, i = e & 63;
-        double v = (i == c) ? 1.0 : 0.0;
-        if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
-        Dg[c * kLdDiag + i] = v;
+    // all loads of the chunk are issued before the first LDS store (one latency, not 32)
+    const double* __restrict__ slot = dscratch + (int64_t)(D.dslot + pd.jb) * (kTile * kTile);
+    {
+        constexpr int kPer = kTile * kPanelRows / kThreads;  // 32
+        double tmp[kPer], dtmp[kTile * kTile / kThreads];
+        const int rr = tid & (kPanelRows - 1), chalf = tid >> 7;
+        const int row = pd.row0 + rr;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int c = 2 * q + chalf;
+            tmp[q] = (c < wbk && row < r) ? G[(int64_t)(cb + c) * r + row] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kTile * kTile / kThreads; ++q) dtmp[q] = slot[q * kThreads + tid];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) Bs[2 * q + chalf][rr] = tmp[q];
+#pragma unroll
+        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+            const int e = q * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
+        }
     }
+    if (tid < kTile) invd[tid] = (tid < wbk) ? 1.0 / slot[tid * kTile + tid] : 1.0;
     __syncthreads();
-    for (int j = 0; j < wbk; ++j) {
-        const double d = Dg[j * kLdDiag + j];
-        const double s = sqrt(d);
-        const double inv = 1.0 / s;
+    if (blockIdx.x == 0) STAMP(1);
+
+    // X := B * inv(Ljj') by forward substitution, 16 columns at a time: the low half of
+    // the workgroup solves the 16x16 triangle of its row, then both halves apply the
+    // rank-16 update to the remaining columns (odd / even columns).
+    const int row = tid & (kPanelRows - 1), half = tid >> 7;
+    for (int c0 = 0; c0 < wbk; c0 += 16) {
+        if (half == 0) {
+            double xb[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xb[j] = Bs[c0 + j][row];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double acc = xb[j];
+#pragma unroll
+                for (int i = 0; i < j; ++i) acc = fma(-xb[i], Dg[(c0 + i) * kLdDiag + c0 + j], acc);
+                xb[j] = acc * invd[c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Bs[c0 + j][row] = xb[j];
+        }
         __syncthreads();
-        if (tid < kTile) {
-            if (tid == j) {
-                Dg[j * kLdDiag + j] = s;
-                invd[j] = inv;
-                if (!(d > 0.0) && pd.row0 < 0) atomicMin(info, D.c0 + cb + j + 1);
-            } else if (tid > j && tid < wbk) {
-                Dg[j * kLdDiag + tid] *= inv;
+        if (c0 + 16 < wbk) {
+            double xk[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xk[k] = Bs[c0 + k][row];
+            for (int j = c0 + 16 + half; j < wbk; j += 2) {
+                double acc = Bs[j][row];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fma(-xk[k], Dg[(c0 + k) * kLdDiag + j], acc);
+                Bs[j][row] = acc;
             }
         }
         __syncthreads();
-        const int nc = wbk - j - 1;  // trailing columns j+1 .. wbk-1
-        for (int e = tid; e < nc * kTile; e += kThreads) {
-            const int c = j + 1 + (e >> 6), i = e & 63;
-            if (i >= c && i < wbk)
-                Dg[c * kLdDiag + i] = fma(-Dg[j * kLdDiag + i], Dg[j * kLdDiag + c], Dg[c * kLdDiag + i]);
-        }
-        __syncthreads();
     }
-
-    if (pd.row0 < 0) {
-        double* __restrict__ slot = dscratch + (int64_t)(D.dslot + pd.jb) * (kTile * kTile);
-        for (int e = tid; e < kTile * kTile; e += kThreads) {
-            const int c = e >> 6, i = e & 63;
-            slot[e] = (c < wbk && i < wbk && i >= c) ? Dg[c * kLdDiag + i] : 0.0;
-        }
-        return;
+    if (blockIdx.x == 0) STAMP(2);
+    for (int e = tid; e < kTile * kPanelRows; e += kThreads) {
+        const int c = e >> 7, rr = e & (kPanelRows - 1);
+        const int grow = pd.row0 + rr;
+        if (c < wbk && grow < r) G[(int64_t)(cb + c) * r + grow] = Bs[c][rr];
     }
-
-    const int row = pd.row0 + tid;
-    if (row >= r) return;
-    // x := x * inv(Ljj'):  x[c] = (x[c] - sum_{k<c} x[k] Ljj[c][k]) / Ljj[c][c], 16 columns at a
-    // time in registers; columns already solved are re-read from the panel (own writes).
-    double* __restrict__ xr = G + (int64_t)cb * r + row;
-    for (int c0 = 0; c0 < wbk; c0 += 16) {
-        double xb[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xb[j] = (c0 + j < wbk) ? xr[(int64_t)(c0 + j) * r] : 0.0;
-        for (int k = 0; k < c0; ++k) {
-            const double xk = xr[(int64_t)k * r];
-            const double* __restrict__ lk = &Dg[k * kLdDiag + c0];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = fma(-xk, lk[j], xb[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double acc = xb[j];
-#pragma unroll
-            for (int i = 0; i < j; ++i) acc = fma(-xb[i], Dg[(c0 + i) * kLdDiag + c0 + j], acc);
-            xb[j] = acc * invd[min(c0 + j, wbk - 1)];
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (c0 + j < wbk) xr[(int64_t)(c0 + j) * r] = xb[j];
-    }
+    if (blockIdx.x == 0) STAMP(3);
 }
 
 void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_chol_panel, dim3(count), dim3(kThreads), 0, stream, P.sn, P.panels + first, L,
-                       P.dscratch, P.info);
+                       P.dscratch);
 }
 
 // FIXUP: copy parked diagonal blocks into their panels (lower triangle only).

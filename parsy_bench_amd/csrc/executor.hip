@@ -34,7 +34,7 @@ static int upload(parsy_plan* pl, const std::vector<T>& v, const T*& dptr, bool 
 int plan_upload_launches(parsy_plan* pl) {
     if (pl->device < 0) return 0;
     PARSY_HIP(hipSetDevice(pl->device));
-    for (void* d : pl->launch_owned) hipFree(d);
+    for (void* d : pl->launch_owned) (void)hipFree(d);
     pl->launch_owned.clear();
     const Schedule& S = pl->S;
     if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
@@ -97,17 +97,17 @@ parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, co
 void plan_free(parsy_plan* pl) {
     if (!pl) return;
     if (pl->device >= 0) {
-        hipSetDevice(pl->device);
-        hipDeviceSynchronize();
-        for (void* d : pl->owned) hipFree(d);
-        for (void* d : pl->launch_owned) hipFree(d);
-        if (pl->xscratch) hipFree(pl->xscratch);
-        if (pl->h_values_dev) hipFree(pl->h_values_dev);
-        if (pl->h_L_dev) hipFree(pl->h_L_dev);
-        if (pl->h_x_dev) hipFree(pl->h_x_dev);
+        (void)hipSetDevice(pl->device);
+        (void)hipDeviceSynchronize();
+        for (void* d : pl->owned) (void)hipFree(d);
+        for (void* d : pl->launch_owned) (void)hipFree(d);
+        if (pl->xscratch) (void)hipFree(pl->xscratch);
+        if (pl->h_values_dev) (void)hipFree(pl->h_values_dev);
+        if (pl->h_L_dev) (void)hipFree(pl->h_L_dev);
+        if (pl->h_x_dev) (void)hipFree(pl->h_x_dev);
         for (hipEvent_t e : {pl->ev_f0, pl->ev_f1, pl->ev_s0, pl->ev_s1})
-            if (e) hipEventDestroy(e);
-        for (hipEvent_t e : pl->pev) hipEventDestroy(e);
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : pl->pev) (void)hipEventDestroy(e);
     }
     delete pl;
 }
@@ -116,12 +116,12 @@ static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& c
     if (!pl->profile) return;
     if (cursor >= pl->pev.size()) {
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         pl->pev.push_back(e);
     }
     if (cursor >= pl->pev_kind.size()) pl->pev_kind.push_back(kind);
     else pl->pev_kind[cursor] = kind;
-    hipEventRecord(pl->pev[cursor], stream);
+    (void)hipEventRecord(pl->pev[cursor], stream);
     ++cursor;
 }
 
@@ -165,7 +165,7 @@ int plan_collect_profile(parsy_plan* pl) {
     return 0;
 }
 
-int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream) {
+int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream, bool init) {
     if (pl->device < 0) {
         set_last_error("parsy_factor: plan was built without a device (device < 0)");
         return -1;
@@ -176,10 +176,10 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
     }
     const Schedule& S = pl->S;
     PARSY_HIP(hipEventRecord(pl->ev_f0, stream));
-    PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
+    if (init) PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
     // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)
     PARSY_HIP(hipMemsetAsync(pl->dp.info, 0x7f, sizeof(int), stream));
-    launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
+    if (init) launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
     run_launches(pl, S.chol, d_L, d_L, nullptr, 0, 0, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_f1, stream));

@@ -48,7 +48,8 @@ parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, co
                        int device);
 void plan_free(parsy_plan* plan);
 int plan_upload_launches(parsy_plan* plan);
-int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream);
+int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream,
+                bool init = true);
 int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
                hipStream_t stream);
 int plan_collect_profile(parsy_plan* plan);

@@ -106,9 +106,14 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         const int nbc = ceil_div(T.w, kTile);
         T.dslot = (int32_t)S.n_dslots;
         S.n_dslots += nbc;
+        for (int jb = 1; jb < nbc; ++jb) {
+            const double K = (double)jb * kTile, wb = std::min(kTile, T.w - jb * kTile);
+            S.inner_flops += K * wb * (wb + 1) + 2.0 * K * (double)(T.r - jb * kTile - wb) * wb;
+        }
         bucket.assign(nbc, {});
         for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
             const UpdDesc& U = S.upd[u];
+            S.tile_update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
             const int32_t* rel = &S.relpos[U.rel];
             const int jfirst = rel[0] / kTile, jlast = rel[U.n1 - 1] / kTile;
             for (int J = jfirst; J <= jlast; ++J) {
@@ -179,37 +184,37 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 maxnb = std::max(maxnb, nbc);
                 for (int J = 0; J < nbc; ++J) {
                     const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + J], c1 = S.cb_ptr[S.sn_cb0[t] + J + 1];
-                    if (c1 == c0) continue;
-                    for (int I = J; I < nbr; ++I)
+                    // the diagonal tile of block column 0 is always scheduled: it factors
+                    // the block once its (possibly empty) update list is applied
+                    if (c1 == c0 && J > 0) continue;
+                    for (int I = J; I < (c1 == c0 ? J + 1 : nbr); ++I)
                         S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, (int32_t)c0, (int32_t)c1, 0});
                 }
             }
             L.count = (int32_t)S.tiles.size() - L.first;
             if (L.count > 0) S.chol.push_back(L);
             for (int jb = 0; jb < maxnb; ++jb) {
-                if (jb > 0) {
-                    Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0};
-                    for (int t : bigs) {
-                        const SnDesc& T = S.sn[t];
-                        if (ceil_div(T.w, kTile) <= jb) continue;
-                        const int nbr = ceil_div(T.r, kTile);
-                        for (int I = jb; I < nbr; ++I)
-                            S.tiles.push_back(TileDesc{t, I * kTile, jb * kTile, 0, 0, 0});
-                    }
-                    Li.count = (int32_t)S.tiles.size() - Li.first;
-                    if (Li.count > 0) S.chol.push_back(Li);
-                }
                 Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0};
                 for (int t : bigs) {
                     const SnDesc& T = S.sn[t];
                     if (ceil_div(T.w, kTile) <= jb) continue;
                     const int wb = std::min(kTile, T.w - jb * kTile);
-                    S.panels.push_back(PanelDesc{t, jb, -1, 0});
                     for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
                         S.panels.push_back(PanelDesc{t, jb, row0, 0});
                 }
                 Lp.count = (int32_t)S.panels.size() - Lp.first;
-                S.chol.push_back(Lp);
+                if (Lp.count > 0) S.chol.push_back(Lp);
+                // right-looking update of everything to the right of block column jb
+                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0};
+                for (int t : bigs) {
+                    const SnDesc& T = S.sn[t];
+                    const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+                    for (int J = jb + 1; J < nbc; ++J)
+                        for (int I = J; I < nbr; ++I)
+                            S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, 0, 0});
+                }
+                Li.count = (int32_t)S.tiles.size() - Li.first;
+                if (Li.count > 0) S.chol.push_back(Li);
             }
             Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0};
             S.fix_list.insert(S.fix_list.end(), bigs.begin(), bigs.end());
@@ -237,7 +242,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     if (ceil_div(T.w, kTile) <= jb) continue;
                     const int wb = std::min(kTile, T.w - jb * kTile);
                     S.solve_panels.push_back(PanelDesc{t, jb, -1, 0});
-                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
+                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kSolveRows)
                         S.solve_panels.push_back(PanelDesc{t, jb, row0, 0});
                 }
                 Lp.count = (int32_t)S.solve_panels.size() - Lp.first;

@@ -12,10 +12,11 @@
 //           trapezoid only); one workgroup per tile applies the external updates
 //           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).
 //   then per 64-wide block column jb of those supernodes:
-//   INNER   (jb > 0) the in-supernode update of block column jb by block columns
-//           0..jb-1 (dense SYRK/GEMM, same MFMA kernel, identity row map)
 //   PANEL   POTRF of the 64x64 diagonal block (redundantly per workgroup, result
-//           parked in a scratch slab) + TRSM of 256-row chunks below it
+//           parked in a scratch slab) + TRSM of 128-row chunks below it
+//   INNER   right-looking in-supernode update: every tile right of block column jb
+//           gets -= L(I,jb) L(J,jb)' (dense SYRK/GEMM, K = 64, same MFMA kernel,
+//           identity row map)
 //   FIXUP   once per level: parked diagonal blocks are copied into the panels.
 // The solve mirrors it (SOLVE_SMALL: width <= 64; SOLVE_PANEL per block column;
 // one SOLVE_FIXUP at the end).
@@ -32,7 +33,8 @@ constexpr int kTile = 64;             // tile edge of the tiled path / block-col
 constexpr int kSub = 32;              // per-wave sub-tile edge
 constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
 constexpr int kSmallMaxWidth = 64;
-constexpr int kPanelRows = 256;       // TRSM / solve row chunk per workgroup
+constexpr int kPanelRows = 128;       // TRSM row chunk per workgroup (staged in LDS)
+constexpr int kSolveRows = 256;       // solve row chunk per workgroup
 
 struct SnDesc {       // one per supernode
     int64_t px;       // offset of the panel in lValues
@@ -95,6 +97,8 @@ struct Schedule {
     int max_width = 0, max_rows = 0, n_small = 0, n_big = 0;
     int64_t n_dslots = 0;          // parked diagonal blocks (64*64 doubles each)
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;
+    double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)
+    double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (INNER launches)
 
     std::vector<SnDesc> sn;
     std::vector<UpdDesc> upd;
