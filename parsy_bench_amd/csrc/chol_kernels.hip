@@ -21,7 +21,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 static constexpr int kThreads = 256;
 static constexpr int kLdSub = kSub + 1;   // padded leading dimension of a wave's sub-tile in LDS
 static constexpr int kLdDiag = kTile + 1; // padded leading dimension of a diagonal block in LDS
-static constexpr int kChunk = 256;        // update entries staged per pass of the tile kernel
 
 #ifdef PARSY_STAMPS
 // diagnostic build only: phase stamps (100 MHz wall clock) of the last PANEL workgroup 0
@@ -128,6 +127,10 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
 // (rows of a 16-row fragment are contiguous: 128-B segments per k), then
 // scatter-subtracted through the relative indices.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void lds_sub(double* p, double v) {
+    __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int n, int k0, int k1,
                                              int k2, int& r0, int& r1, int& r2) {
     int l0 = 0, l1 = 0, l2 = 0;
@@ -202,22 +205,36 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double (*colbuf)
     }
 }
 
+static constexpr int kKC = 16;        // k extent of one staged operand chunk
+static constexpr int kLdK = kKC + 1;  // padded row length of a staged chunk (bank-conflict free)
+static constexpr int kPass = 128;     // update entries evaluated per pass
+
+// One workgroup per 64x64 tile of a panel.  The update stream of the tile -- every
+// (descendant, 16-wide k chunk) pair that touches it, in update order -- is pumped through
+// a double-buffered LDS stage by all 256 threads with coalesced loads (rows of a panel
+// column are contiguous), three chunks deep (two in registers, one landing in LDS), while
+// each wave multiplies its 32x32 sub-tile's rows out of the stage with
+// v_mfma_f64_16x16x4_f64 and, at the end of a descendant, scatter-subtracts the product
+// into its private LDS sub-tile through the relative indices (ds_add_f64, in order).
 template <bool INNER>
-__global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restrict__ sn,
-                                                         const UpdDesc* __restrict__ upd,
-                                                         const int32_t* __restrict__ relpos,
-                                                         const ColBlkEntry* __restrict__ colblk,
-                                                         const TileDesc* __restrict__ tiles, int jb,
-                                                         double* __restrict__ L,
-                                                         double* __restrict__ dscratch,
-                                                         int* __restrict__ info) {
+__global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
+                                                            const UpdDesc* __restrict__ upd,
+                                                            const int32_t* __restrict__ relpos,
+                                                            const ColBlkEntry* __restrict__ colblk,
+                                                            const TileDesc* __restrict__ tiles, int jb,
+                                                            double* __restrict__ L,
+                                                            double* __restrict__ dscratch,
+                                                            int* __restrict__ info) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[2][kTile];
-    __shared__ int64_t e_src[kChunk];
-    __shared__ int64_t e_rel[kChunk];
-    __shared__ int32_t e_ld[kChunk], e_K[kChunk];
-    __shared__ int32_t e_i0[kChunk], e_i1[kChunk], e_i2[kChunk];
-    __shared__ int32_t e_j0[kChunk], e_j1[kChunk], e_j2[kChunk];
+    __shared__ double As[2][kTile * kLdK], Bs[2][kTile * kLdK];
+    __shared__ int32_t relA[4][kTile], relB[4][kTile];
+    __shared__ int64_t e_src[kPass];
+    __shared__ int64_t e_rel[kPass];
+    __shared__ int32_t e_ld[kPass], e_K[kPass];
+    __shared__ int32_t e_i0[kPass], e_i1[kPass], e_i2[kPass];
+    __shared__ int32_t e_j0[kPass], e_j1[kPass], e_j2[kPass];
+    __shared__ int32_t wcount[2];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const TileDesc td = tiles[blockIdx.x];
@@ -250,10 +267,17 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
         }
     }
 
+    // loader role of this thread: operand (A rows / B rows), row of the stage, k half
+    const int ld_which = tid >> 7, ld_row = tid & 63, ld_kh = (tid >> 6) & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool diag_sub = subrow0 == subcol0;
+
     const int n_entries = INNER ? 1 : (td.cb1 - td.cb0);
-    for (int base = 0; base < n_entries; base += kChunk) {
-        const int cnt = min(kChunk, n_entries - base);
-        __syncthreads();  // previous chunk fully consumed
+    for (int base = 0; base < n_entries; base += kPass) {
+        const int cnt_raw = min(kPass, n_entries - base);
+        __syncthreads();  // previous pass fully consumed
+        // ---- evaluate the entries of this pass; keep (in order) those with rows in the tile
+        int cnt;
         if (INNER) {
             if (tid == 0) {
                 e_src[0] = D.px + (int64_t)jb * kTile * r;  // block column jb of the same panel
@@ -267,112 +291,178 @@ __global__ __launch_bounds__(kThreads) void k_chol_tiles(const SnDesc* __restric
                 e_j1[0] = min(td.col0 + kSub, w);
                 e_j2[0] = min(td.col0 + kTile, w);
             }
-        } else if (tid < cnt) {
-            const ColBlkEntry ce = colblk[td.cb0 + base + tid];
-            const UpdDesc U = upd[ce.upd];
-            int i0, i1, i2;
-            lower_bound3(relpos + U.rel, U.m, td.row0, td.row0 + kSub, td.row0 + kTile, i0, i1, i2);
-            e_src[tid] = U.src;
-            e_rel[tid] = U.rel;
-            e_ld[tid] = U.ld;
-            e_K[tid] = U.K;
-            e_i0[tid] = i0;
-            e_i1[tid] = i1;
-            e_i2[tid] = i2;
-            e_j0[tid] = ce.jlo;
-            e_j1[tid] = ce.jmid;
-            e_j2[tid] = ce.jhi;
-        }
-        __syncthreads();
-        if (!wave_on) continue;
-
-        for (int e = 0; e < cnt; ++e) {
-            const int ia = wa ? e_i1[e] : e_i0[e], ib = wa ? e_i2[e] : e_i1[e];
-            const int ja = wb ? e_j1[e] : e_j0[e], jbnd = wb ? e_j2[e] : e_j1[e];
-            const int mi = ib - ia, nj = jbnd - ja;
-            if (mi <= 0 || nj <= 0) continue;
-            const double* __restrict__ src = L + e_src[e];
-            const int32_t* __restrict__ rel = relpos + (INNER ? 0 : e_rel[e]);
-            const int ld = e_ld[e], K = e_K[e];
-            const bool two_r = mi > 16, two_c = nj > 16;
-            const int l15 = lane & 15, kq = lane >> 4;
-
-            // relative indices this lane will scatter through (issued before the K loop)
-            int rR[2][4], rC[2];
-#pragma unroll
-            for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int il = tr * 16 + kq + 4 * v;
-                    int pos = -1;
-                    if (il < mi) pos = INNER ? (ia + il) : rel[ia + il];
-                    rR[tr][v] = pos - subrow0;
-                }
-#pragma unroll
-            for (int tc = 0; tc < 2; ++tc) {
-                const int jl = tc * 16 + l15;
-                int pos = -1;
-                if (jl < nj) pos = INNER ? (ja + jl) : rel[ja + jl];
-                rC[tc] = pos < 0 ? -1 : pos - subcol0;
+            __syncthreads();
+            cnt = 1;
+        } else {
+            bool keep = false;
+            ColBlkEntry ce;
+            UpdDesc U;
+            int i0 = 0, i1 = 0, i2 = 0;
+            if (tid < cnt_raw) {
+                ce = colblk[td.cb0 + base + tid];
+                U = upd[ce.upd];
+                lower_bound3(relpos + U.rel, U.m, td.row0, td.row0 + kSub, td.row0 + kTile, i0, i1, i2);
+                keep = i2 > i0;
             }
+            const unsigned long long bal = __ballot(keep);
+            if (wave < 2 && lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            if (keep) {
+                const int pos = (wave ? wcount[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
+                e_src[pos] = U.src;
+                e_rel[pos] = U.rel;
+                e_ld[pos] = U.ld;
+                e_K[pos] = U.K;
+                e_i0[pos] = i0;
+                e_i1[pos] = i1;
+                e_i2[pos] = i2;
+                e_j0[pos] = ce.jlo;
+                e_j1[pos] = ce.jmid;
+                e_j2[pos] = ce.jhi;
+            }
+            cnt = wcount[0] + wcount[1];
+            __syncthreads();
+        }
+        if (cnt == 0) continue;
 
-            const double* pa0 = src + min(ia + l15, ib - 1);
-            const double* pa1 = src + min(ia + 16 + l15, ib - 1);
-            const double* pb0 = src + min(ja + l15, jbnd - 1);
-            const double* pb1 = src + min(ja + 16 + l15, jbnd - 1);
-            double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-            // 16 k per trip, software-pipelined: the 16 loads of trip t+1 are in flight
-            // while the 16 MFMAs of trip t issue.
-            double a0[4], a1[4], b0[4], b1[4], na0[4], na1[4], nb0[4], nb1[4];
-            auto load_trip = [&](int k0, double (&xa0)[4], double (&xa1)[4], double (&xb0)[4],
-                                 double (&xb1)[4]) {
+        // ---- loader: chunk (e, k0) -> 8 doubles (+ one relative index) per thread
+        struct Chunk {
+            double v[8];
+            int32_t rel;
+            int32_t e, k0;  // e < 0: nothing to store
+        };
+        int le = 0, lk = 0;  // next chunk of the stream to load
+        auto issue = [&](Chunk& c) {
+            c.e = -1;
+            if (le >= cnt) return;
+            const int e = le, k0 = lk;
+            c.e = e;
+            c.k0 = k0;
+            const int base_row = ld_which ? e_j0[e] : e_i0[e];
+            const int nrow = (ld_which ? e_j2[e] : e_i2[e]) - base_row;
+            const int K = e_K[e], ld = e_ld[e];
+            const double* __restrict__ src = L + e_src[e] + base_row + ld_row;
+            const bool rv = ld_row < nrow;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + 4 * u + kq;
-                    const bool kv = k < K;
-                    const int64_t off = (int64_t)(kv ? k : 0) * ld;
-                    const double va0 = pa0[off], vb0 = pb0[off];
-                    const double va1 = two_r ? pa1[off] : 0.0, vb1 = two_c ? pb1[off] : 0.0;
-                    xa0[u] = kv ? va0 : 0.0;
-                    xb0[u] = kv ? vb0 : 0.0;
-                    xa1[u] = kv ? va1 : 0.0;
-                    xb1[u] = kv ? vb1 : 0.0;
-                }
-            };
-            load_trip(0, a0, a1, b0, b1);
-            for (int k0 = 0; k0 < K; k0 += 16) {
-                const bool more = k0 + 16 < K;
-                if (more) load_trip(k0 + 16, na0, na1, nb0, nb1);
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + ld_kh * 8 + q;
+                c.v[q] = (rv && k < K) ? src[(int64_t)k * ld] : 0.0;
+            }
+            c.rel = -1;
+            if (k0 == 0 && ld_kh == 0 && rv)
+                c.rel = INNER ? (base_row + ld_row) : relpos[e_rel[e] + base_row + ld_row];
+            lk += kKC;
+            if (lk >= K) {
+                lk = 0;
+                ++le;
+            }
+        };
+        auto store = [&](const Chunk& c, int stage) {
+            if (c.e < 0) return;
+            double* __restrict__ S = (ld_which ? Bs[stage] : As[stage]) + ld_row * kLdK + ld_kh * 8;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (k0 + 4 * u >= K) break;
-                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c00, 0, 0, 0);
-                    if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], c01, 0, 0, 0);
-                    if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], c10, 0, 0, 0);
-                    if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c11, 0, 0, 0);
-                }
-                if (more) {
+            for (int q = 0; q < 8; ++q) S[q] = c.v[q];
+            if (c.k0 == 0 && ld_kh == 0) (ld_which ? relB : relA)[c.e & 3][ld_row] = c.rel;
+        };
+
+        // ---- consumer state of this wave
+        int ce_ = 0, ck = 0;  // chunk of the stream being multiplied
+        double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+        auto consume = [&](int stage) {
+            const int e = ce_;
+            const int K = e_K[e];
+            if (wave_on) {
+                const int i0 = e_i0[e], j0 = e_j0[e];
+                const int ia = wa ? e_i1[e] : i0, ib = wa ? e_i2[e] : e_i1[e];
+                const int ja = wb ? e_j1[e] : j0, jbnd = wb ? e_j2[e] : e_j1[e];
+                const int mi = ib - ia, nj = jbnd - ja;
+                if (mi > 0 && nj > 0) {
+                    const bool two_r = mi > 16, two_c = nj > 16;
+                    const int offA = ia - i0, offB = ja - j0;
+                    const double* __restrict__ pa0 = As[stage] + min(offA + l15, kTile - 1) * kLdK + kq;
+                    const double* __restrict__ pa1 = As[stage] + min(offA + 16 + l15, kTile - 1) * kLdK + kq;
+                    const double* __restrict__ pb0 = Bs[stage] + min(offB + l15, kTile - 1) * kLdK + kq;
+                    const double* __restrict__ pb1 = Bs[stage] + min(offB + 16 + l15, kTile - 1) * kLdK + kq;
+                    const int kend = min(kKC, K - ck);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        a0[u] = na0[u];
-                        a1[u] = na1[u];
-                        b0[u] = nb0[u];
-                        b1[u] = nb1[u];
+                    for (int u = 0; u < kKC / 4; ++u) {
+                        if (4 * u >= kend) break;
+                        const double a0 = pa0[4 * u], b0 = pb0[4 * u];
+                        const double a1 = pa1[4 * u], b1 = pb1[4 * u];
+                        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+                        if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+                        if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+                        if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+                    }
+                    if (ck + kKC >= K) {
+                        // last chunk of this descendant: scatter-subtract through the relative
+                        // indices (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
+                        // row = (lane >> 4) + 4 * reg).  ds_add_f64 without return: the wave owns
+                        // Tw and its LDS operations execute in order, so the sum order is fixed.
+                        const int32_t* __restrict__ ra = relA[e & 3] + offA;
+                        const int32_t* __restrict__ rb = relB[e & 3] + offB;
+                        int rC[2];
+#pragma unroll
+                        for (int tc = 0; tc < 2; ++tc) {
+                            const int jl = tc * 16 + l15;
+                            rC[tc] = (jl < nj) ? rb[jl] - subcol0 : -1;
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int il0 = kq + 4 * v, il1 = 16 + kq + 4 * v;
+                            const int R0 = (il0 < mi) ? ra[il0] - subrow0 : -1;
+                            const int R1 = (il1 < mi) ? ra[il1] - subrow0 : -1;
+                            const int C0 = rC[0], C1 = rC[1];
+                            if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) lds_sub(&Tw[C0 * kLdSub + R0], c00[v]);
+                            if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) lds_sub(&Tw[C1 * kLdSub + R0], c01[v]);
+                            if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) lds_sub(&Tw[C0 * kLdSub + R1], c10[v]);
+                            if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) lds_sub(&Tw[C1 * kLdSub + R1], c11[v]);
+                        }
+                        c00 = {0, 0, 0, 0};
+                        c01 = {0, 0, 0, 0};
+                        c10 = {0, 0, 0, 0};
+                        c11 = {0, 0, 0, 0};
                     }
                 }
             }
-            // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-            const bool diag_sub = subrow0 == subcol0;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int R0 = rR[0][v], R1 = rR[1][v];
-                const int C0 = rC[0], C1 = rC[1];
-                if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) Tw[C0 * kLdSub + R0] -= c00[v];
-                if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) Tw[C1 * kLdSub + R0] -= c01[v];
-                if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) Tw[C0 * kLdSub + R1] -= c10[v];
-                if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) Tw[C1 * kLdSub + R1] -= c11[v];
+            ck += kKC;
+            if (ck >= K) {
+                ck = 0;
+                ++ce_;
             }
+        };
+
+        // ---- pump: chunk p is multiplied from stage p & 1 while chunk p+1 is written to the
+        // other stage and chunks p+2, p+3 are in flight in registers
+        Chunk q0, q1, q2;
+        issue(q0);
+        issue(q1);
+        issue(q2);
+        store(q0, 0);
+        __syncthreads();
+        int p = 0;
+#ifdef PARSY_STAMPS
+        unsigned long long ts = 0, ti = 0, tc = 0, tb = 0, t0, t1, t2, t3, t4, tl0 = wall_clock64();
+#define PH(a, b, c, d) do { t0 = wall_clock64(); a; t1 = wall_clock64(); b; t2 = wall_clock64(); c; t3 = wall_clock64(); d; t4 = wall_clock64(); ts += t1 - t0; ti += t2 - t1; tc += t3 - t2; tb += t4 - t3; } while (0)
+#else
+#define PH(a, b, c, d) do { a; b; c; d; } while (0)
+#endif
+        while (ce_ < cnt) {
+            PH(store(q1, (p + 1) & 1), issue(q0), consume(p & 1), __syncthreads());
+            ++p;
+            if (ce_ >= cnt) break;
+            PH(store(q2, (p + 1) & 1), issue(q1), consume(p & 1), __syncthreads());
+            ++p;
+            if (ce_ >= cnt) break;
+            PH(store(q0, (p + 1) & 1), issue(q2), consume(p & 1), __syncthreads());
+            ++p;
         }
+#ifdef PARSY_STAMPS
+        if (!INNER && stamp_wg && tid == 0) {
+            g_stamps[16] = ts; g_stamps[17] = ti; g_stamps[18] = tc; g_stamps[19] = tb;
+            g_stamps[20] = wall_clock64() - tl0; g_stamps[21] = p; g_stamps[22] = cnt;
+        }
+#endif
     }
 
     if (stamp_wg) STAMP(9);

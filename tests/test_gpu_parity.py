@@ -75,3 +75,238 @@ def test_solve_matches_oracle(api, oracle, name, nrhs):
         assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
     assert np.abs(X[:, 0] - 1.0).max() <= 1e-9
     assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(np.ascontiguousarray(X[:, 0]))) == 1
+
+
+# ---------------------------------------------------------------------------
+# drop-in operators: the reference's own argument lists (host pointers)
+# ---------------------------------------------------------------------------
+def _dropin_args(sym):
+    from parsy_bench_amd import inspector as I
+    nl, levelPtr, parPtr, partition = I.trivial_hlevel(sym)
+    return nl, levelPtr, parPtr, partition
+
+
+@pytest.mark.parametrize("name", ["small3d", "mid3d"])
+def test_dropin_cholesky_operators(api, oracle, name):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    nl, levelPtr, parPtr, partition = _dropin_args(sym)
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, (nl, levelPtr, parPtr, partition))
+    timing = np.zeros(8)
+    lv = np.zeros(int(sym.xsize))
+    assert api.cholesky_left_par_05(sym.n, sym.A2p, sym.A2i, sym.A2x, sym.p, sym.s, sym.i_ptr, lv, sym.super,
+                                    sym.nsuper, timing, sym.sParent, sym.A1p, sym.A1i, sym.col2Sup, nl, levelPtr,
+                                    None, 0, parPtr, partition, 1, 4, sym.maxSupWid + 1, sym.maxCol + 1) is True
+    assert np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+    assert timing[0] > 0 and timing[2] > 0 and timing[1] == 0
+    lw = np.zeros(int(sym.xsize))
+    assert api.cholesky_left_par_waveFront(sym.n, sym.A2p, sym.A2i, sym.A2x, sym.p, sym.s, sym.i_ptr, lw,
+                                           sym.super, sym.nsuper, timing, sym.sParent, sym.A1p, sym.A1i,
+                                           sym.col2Sup, sym.nlevels, sym.levelPtr, sym.levelSet, 1, 4,
+                                           sym.maxSupWid + 1, sym.maxCol + 1) is True
+    assert np.array_equal(lw, lv)  # same plan, same schedule: bitwise
+    # a partition that is not a permutation of the supernodes is refused
+    bad = partition.copy()
+    bad[0] = bad[1]
+    lz = np.zeros(int(sym.xsize))
+    assert api.cholesky_left_par_05(sym.n, sym.A2p, sym.A2i, sym.A2x, sym.p, sym.s, sym.i_ptr, lz, sym.super,
+                                    sym.nsuper, timing, sym.sParent, sym.A1p, sym.A1i, sym.col2Sup, nl, levelPtr,
+                                    None, 0, parPtr, bad, 1, 4, sym.maxSupWid + 1, sym.maxCol + 1) is False
+    api.dropin_reset()
+
+
+@pytest.mark.parametrize("name", ["small3d", "lap30"])
+def test_dropin_solve_operators(api, oracle, name):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    nl, levelPtr, parPtr, partition = _dropin_args(sym)
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, (nl, levelPtr, parPtr, partition))
+    b = oracle.rhs_init_blocked(sym, lo)
+    xo = oracle.blocked_lsolve(sym, lo, b, "serial")
+    base = (sym.n, sym.p, sym.s, lo, int(sym.xsize), sym.i_ptr, sym.col2Sup, sym.super, sym.nsuper)
+    x1 = b.copy()
+    assert api.blockedLsolve(*base, x1) == 1
+    x2 = b.copy()
+    assert api.leveledBlockedLsolve(*base, x2, sym.nlevels, sym.levelPtr, sym.levelSet, 1) == 1
+    x3 = b.copy()
+    assert api.H2LeveledBlockedLsolve(*base, x3, nl, levelPtr, None, 0, parPtr, partition, 1) == 1
+    x4 = b.copy()
+    assert api.H2LeveledBlockedLsolve_Peeled(*base, x4, nl, levelPtr, None, 0, parPtr, partition, 1, 4) == 1
+    for x in (x1, x2, x3, x4):
+        assert np.abs(x - xo).max() <= SOLVE_TOL
+        assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(x)) == 1
+    # NULL inputs: 0, as the reference (Triangular_BCSC.h:24)
+    assert api.blockedLsolve(sym.n, None, sym.s, lo, 0, sym.i_ptr, sym.col2Sup, sym.super, sym.nsuper, x1) == 0
+    api.dropin_reset()
+
+
+# ---------------------------------------------------------------------------
+# failure reporting and edge cases
+# ---------------------------------------------------------------------------
+def test_not_positive_definite_reports_the_column(api, oracle):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("small3d")
+    vals = sym.A2x.copy()
+    # make one diagonal entry of P A P' negative: find the diagonal of column 700
+    col = 700
+    d = int(sym.A2p[col])
+    assert sym.A2i[d] == col
+    vals[d] = -5.0
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(vals)
+    st = plan.status()
+    ok, lo, _ = oracle.cholesky_05(sym, vals, I.trivial_hlevel(sym))
+    assert not ok
+    assert st == col + 1, f"status {st}, expected first failing column {col + 1}"
+    # and a clean re-factorization afterwards resets it
+    lv2, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+
+
+def _check_small(api, oracle, A, perm, nrhs=2):
+    from parsy_bench_amd import inspector as I
+    sym = I.analyze(A, perm)
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok and np.abs(lv - lo).max() <= FACTOR_TOL * max(1.0, np.abs(lo).max())
+    Ld = I.bcsc_to_dense(sym, lv)
+    Ad = A.to_dense()[np.ix_(sym.Perm, sym.Perm)]
+    assert np.abs(Ld @ Ld.T - Ad).max() <= RESID_TOL * np.abs(Ad).max()
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((sym.n, nrhs))
+    X, _ = plan.solve(lv, B)
+    assert np.abs(Ld @ X - B).max() <= 1e-10 * max(1.0, np.abs(X).max())
+    return sym
+
+
+def test_edge_one_by_one(api, oracle):
+    from parsy_bench_amd.matrices import LowerCSC
+    A = LowerCSC(1, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([9.0]))
+    sym = _check_small(api, oracle, A, None)
+    assert sym.nsuper == 1
+
+
+def test_edge_diagonal_matrix(api, oracle):
+    from parsy_bench_amd.matrices import LowerCSC
+    n = 37
+    A = LowerCSC(n, np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.linspace(1.0, 5.0, n))
+    _check_small(api, oracle, A, None)
+
+
+def test_edge_dense_matrix_one_wide_supernode(api, oracle):
+    """A dense SPD matrix is a single supernode wider than a tile: TILES is empty, the
+    PANEL / INNER chain does all the work (incl. a last block column narrower than 64)."""
+    from parsy_bench_amd.matrices import random_spd
+    A = random_spd(150, density=1.0, seed=4)
+    sym = _check_small(api, oracle, A, None, nrhs=5)
+    assert sym.nsuper == 1 and sym.maxSupWid == 150
+
+
+def test_edge_banded_chain_etree(api, oracle):
+    """Tridiagonal matrix in natural order: the etree is a chain (no level parallelism)."""
+    from parsy_bench_amd.matrices import LowerCSC
+    n = 300
+    Ap = np.zeros(n + 1, np.int32)
+    Ai, Ax = [], []
+    for j in range(n):
+        Ai.append(j); Ax.append(4.0)
+        if j + 1 < n:
+            Ai.append(j + 1); Ax.append(-1.0)
+        Ap[j + 1] = len(Ai)
+    A = LowerCSC(n, Ap, np.array(Ai, np.int32), np.array(Ax))
+    _check_small(api, oracle, A, None)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ragged_random_patterns(api, oracle, seed):
+    from parsy_bench_amd.matrices import random_spd
+    A = random_spd(220, density=0.03, seed=seed)
+    perm = np.random.default_rng(seed).permutation(220).astype(np.int32)
+    _check_small(api, oracle, A, perm, nrhs=9)
+
+
+def test_new_values_same_pattern(api, oracle):
+    """Refactorisation: same plan, new numeric values (the executor holds no numeric state)."""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("mid3d")
+    plan = api.Plan(sym, 0)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        Ax = A.Ax * rng.uniform(0.9, 1.1)
+        Ax[A.Ap[:-1]] += rng.uniform(0.0, 1.0, A.n)  # keep it diagonally dominant
+        vals = sym.permute_values(Ax)
+        lv, _ = plan.factor(vals)
+        ok, lo, _ = oracle.cholesky_05(sym, vals, I.trivial_hlevel(sym))
+        assert ok and plan.status() == 0
+        assert np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+# ---------------------------------------------------------------------------
+# subtree shards on one device (what two ranks do, minus the wire)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_factorization_on_one_device(api, oracle, nranks):
+    import torch
+    from parsy_bench_amd import inspector as I, multigpu as MG
+    A, perm, sym = problem("lap30")
+    cut = MG.cut_subtrees(sym, nranks)
+    dev = torch.device("cuda", 0)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    Lfull = torch.zeros(int(sym.xsize), dtype=torch.float64, device=dev)
+    plan = api.Plan(sym, 0)
+    # each "rank" factors its subtrees into its own buffer; its slices are then copied over
+    for rk in range(nranks):
+        Lr = torch.empty_like(Lfull)
+        plan.set_active(cut.mask(rk))
+        plan.factor_device(values.data_ptr(), Lr.data_ptr(), 0)
+        torch.cuda.synchronize()
+        if rk == 0:
+            Lfull.copy_(Lr)  # rank 0's buffer also holds A scattered into the root panels
+        else:
+            for owner, a, b in cut.slices(sym):
+                if owner == rk:
+                    Lfull[a:b] = Lr[a:b]
+    plan.set_active(cut.root_mask())
+    plan.factor_device(values.data_ptr(), Lfull.data_ptr(), 0, init=False)
+    torch.cuda.synchronize()
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    got = Lfull.cpu().numpy()
+    assert np.abs(got - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+    plan.set_active(None)
+    lv, _ = plan.factor(sym.A2x)
+    assert np.array_equal(lv, got)  # sharding does not change a single bit
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's full sizes: size-independent properties
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["nd24k", "parabolic_fem"])
+def test_full_size_round_trip(api, oracle, name):
+    """b := L 1 on the stored structure, then L x = b must give x = 1 (the reference's own
+    check, common/Util.h:277-306), for 1 and for many right-hand sides; and the factor agrees
+    with the CPU port.  nd24k = configs[1], parabolic_fem = configs[3] stand-ins."""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    plan = api.Plan(sym, 0)
+    lv, sec = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    b = oracle.rhs_init_blocked(sym, lv)
+    for nrhs in (1, 16):
+        B = np.repeat(b[:, None], nrhs, axis=1)
+        X, _ = plan.solve(lv, B)
+        assert np.abs(X - 1.0).max() <= 1e-9
+    assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(np.ascontiguousarray(X[:, 0]))) == 1
+    # linearity of the solve: L (2x + y) = 2 L x + L y
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(sym.n)
+    Xy, _ = plan.solve(lv, np.stack([y, 2 * b + y], axis=1))
+    assert np.abs(Xy[:, 1] - (2.0 + Xy[:, 0])).max() <= 1e-9 * max(1.0, np.abs(Xy).max())
+    blas = oracle.bind_system_blas()
+    try:
+        ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym), threads=8)
+    finally:
+        oracle.unbind_blas()
+    assert ok and np.abs(lv - lo).max() <= 1e-10 * np.abs(lo).max()

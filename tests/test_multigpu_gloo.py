@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: two gloo ranks shard the etree subtrees (multigpu.cut_subtrees),
+factor their shares, run the ONE exchange step (multigpu.gather_to_root over
+torch.distributed) and rank 0 finishes the root part.  The numeric work is done by the CPU
+oracle here (no GPU in this tier); partitioning, masks, slices and the exchange are the
+product's code and are what is under test.  Result: bitwise the single-process factor.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _rank_main(rank, world, port, name, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from parsy_bench_amd import inspector as I, matrices as M, multigpu as MG
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, perm = M.workload(name)
+    sym = I.analyze(A, perm)
+    cut = MG.cut_subtrees(sym, world)
+
+    def factor_subset(mask, lvalues):
+        """Oracle run restricted to the masked supernodes, level by level (no root phase)."""
+        lev_lists = []
+        for l in range(sym.nlevels):
+            members = [int(s) for s in sym.levelSet[sym.levelPtr[l]: sym.levelPtr[l + 1]] if mask[s]]
+            lev_lists.append(members)
+        partition = np.array([s for lst in lev_lists for s in lst], dtype=np.int32)
+        parPtr = np.arange(len(partition) + 1, dtype=np.int32)
+        levelPtr = np.concatenate([[0], np.cumsum([len(l) for l in lev_lists]), [len(partition)]]).astype(np.int32)
+        nl = sym.nlevels + 1  # an empty last l-level: nothing runs in the sequential root phase
+        timing = np.zeros(16)
+        a = dict(c=sym.A2p, r=sym.A2i, v=np.ascontiguousarray(sym.A2x), lC=sym.p, lR=sym.s, Li=sym.i_ptr,
+                 bs=sym.super, aT=sym.sParent, cT=sym.A1p, rT=sym.A1i, c2s=sym.col2Sup)
+        a = {k: np.ascontiguousarray(v) for k, v in a.items()}
+        ok = O.lib().oracle_cholesky_left_par_05(
+            sym.n, O.P(a["c"]), O.P(a["r"]), O.P(a["v"]), O.P(a["lC"]), O.P(a["lR"]), O.P(a["Li"]),
+            O.P(lvalues), O.P(a["bs"]), sym.nsuper, O.P(timing), O.P(a["aT"]), O.P(a["cT"]), O.P(a["rT"]),
+            O.P(a["c2s"]), nl, O.P(levelPtr), None, 0, O.P(parPtr), O.P(partition), 1, 1,
+            sym.maxSupWid + 1, sym.maxCol + 1, None)
+        assert ok
+
+    lv = torch.zeros(int(sym.xsize), dtype=torch.float64)
+    factor_subset(cut.mask(rank), lv.numpy())
+    moved = MG.gather_to_root(lv, cut, sym, rank, dist)
+    if rank == 0:
+        factor_subset(cut.root_mask(), lv.numpy())
+        np.save(Path(out_dir) / "sharded.npy", lv.numpy())
+        np.save(Path(out_dir) / "moved.npy", np.array([moved, len(cut.subtrees), len(cut.root_nodes)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["small3d", "mid3d"])
+def test_two_rank_subtree_factorization_matches_single_process(tmp_path, oracle, name):
+    import torch.multiprocessing as mp
+    from conftest import problem
+    from parsy_bench_amd import inspector as I
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    A, perm, sym = problem(name)
+    ok, ref, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    got = np.load(tmp_path / "sharded.npy")
+    moved, nsub, nroot = np.load(tmp_path / "moved.npy")
+    assert ok and np.array_equal(got, ref)
+    assert nsub >= 2 and nroot >= 1 and moved > 0

@@ -1,0 +1,183 @@
+"""Pins the CPU oracle (oracle/parsy_oracle.c):
+  * its BLAS.h-shaped solve kernels bit-for-bit against vectors from the reference's own
+    triangularSolve/BLAS.h, and live against oracle/_ref where that was built;
+  * its ereach_sn / getLevelSet against the reference's (live) and the prune-set goldens;
+  * its dense POTRF/TRSM against the reference's cholesky/MyBLAS.h vectors and LAPACK (numpy);
+  * the assembled executors through the uniqueness of the Cholesky factor
+    (numpy.linalg.cholesky = LAPACK dpotrf) and L L' = P A P'.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import problem
+from parsy_bench_amd import inspector as I
+
+GOLD = Path(__file__).resolve().parent / "golden"
+NCOLS = (1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 23)
+
+
+@pytest.mark.parametrize("ncol", NCOLS)
+def test_blas_h_kernels_bitwise_vs_reference_vectors(oracle, ncol):
+    g = np.load(GOLD / "dense_kernels.npz")
+    L = oracle.lib()
+    ldm = ncol + 5
+    Mx = g[f"dlsolve_{ncol}_M"].copy()
+    x = g[f"dlsolve_{ncol}_rhs"].copy()
+    L.oracle_dlsolve_blas_nonUnit(ldm, ncol, oracle.P(Mx), oracle.P(x))
+    assert np.array_equal(x, g[f"dlsolve_{ncol}_x"])
+    y = g[f"dmatvec_{ncol}_y0"].copy()
+    Mv = np.ascontiguousarray(Mx[ncol:])
+    vec = g[f"dmatvec_{ncol}_vec"].copy()
+    L.oracle_dmatvec_blas(ldm, 5, ncol, oracle.P(Mv), oracle.P(vec), oracle.P(y))
+    assert np.array_equal(y, g[f"dmatvec_{ncol}_y"])
+
+
+@pytest.mark.parametrize("dim,n", [(1, 1), (3, 5), (8, 8), (13, 20), (32, 40)])
+def test_dense_potrf_trsm_vs_reference_myblas_and_lapack(oracle, dim, n):
+    g = np.load(GOLD / "dense_kernels.npz")
+    a = g[f"cholcol_{dim}_{n}_in"].copy()
+    ref = g[f"cholcol_{dim}_{n}_out"]
+    L = oracle.lib()
+    assert L.oracle_dpotrf_l(dim, oracle.P(a), n) == 0
+    A_in = g[f"cholcol_{dim}_{n}_in"].reshape(n, n).T  # column-major -> [row, col]
+    ours = a.reshape(n, n).T
+    refm = ref.reshape(n, n).T
+    tri = np.tril_indices(dim)
+    # the reference's Cholesky_col (MyBLAS.h:10) on the leading dim x dim block
+    assert np.allclose(ours[:dim, :dim][tri], refm[:dim, :dim][tri], rtol=1e-13, atol=1e-14)
+    assert np.allclose(np.tril(ours[:dim, :dim]), np.linalg.cholesky(A_in[:dim, :dim]), rtol=1e-13, atol=1e-14)
+    if n > dim:  # rows below: X L' = B
+        b = np.ascontiguousarray(g[f"cholcol_{dim}_{n}_in"]).copy()
+        L.oracle_dpotrf_l(dim, oracle.P(b), n)
+        bm = b.reshape(n, n).T
+        tail = np.ascontiguousarray(b[dim:])  # pointer to row `dim` of column 0, ld n
+        L.oracle_dtrsm_rltn(n - dim, dim, oracle.P(b), n, oracle.P(tail), n)
+        X = tail[: (dim - 1) * n + (n - dim)]
+        Xm = np.stack([tail[c * n: c * n + (n - dim)] for c in range(dim)], axis=1)
+        assert np.allclose(Xm @ np.tril(bm[:dim, :dim]).T, A_in[dim:, :dim], rtol=1e-12, atol=1e-12)
+
+
+def test_dense_syrk_gemm_vs_numpy(oracle):
+    rng = np.random.default_rng(2)
+    L = oracle.lib()
+    for (n, k, lda) in ((1, 1, 1), (5, 3, 9), (17, 8, 17), (40, 33, 64)):
+        A = np.asfortranarray(rng.standard_normal((lda, k)))
+        flat = np.ascontiguousarray(A.T.reshape(-1))
+        C = np.zeros(n * n)
+        L.oracle_dsyrk_ln(n, k, oracle.P(flat), lda, oracle.P(C), n)
+        Cm = C.reshape(n, n).T
+        ref = A[:n] @ A[:n].T
+        assert np.allclose(np.tril(Cm), np.tril(ref), rtol=1e-13, atol=1e-13)
+        m = max(1, n // 2)
+        B = np.asfortranarray(rng.standard_normal((lda, k)))
+        fb = np.ascontiguousarray(B.T.reshape(-1))
+        C2 = np.zeros(m * n)
+        L.oracle_dgemm_nt(m, n, k, oracle.P(flat), lda, oracle.P(fb), lda, oracle.P(C2), m)
+        assert np.allclose(C2.reshape(n, m).T, A[:m] @ B[:n].T, rtol=1e-13, atol=1e-13)
+
+
+def test_not_positive_definite_is_reported(oracle):
+    a = np.array([4.0, 2.0, 2.0, 0.5])  # [[4,2],[2,.5]] -> second pivot 0.5 - 1 < 0
+    assert oracle.lib().oracle_dpotrf_l(2, oracle.P(a), 2) == 2
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "mid3d"])
+def test_ereach_and_levelsets_vs_reference(oracle, name):
+    A, perm, sym = problem(name)
+    L = oracle.lib()
+    ns = sym.nsuper
+    xi = np.zeros(2 * ns, np.int32)
+    a1p, a1i = np.ascontiguousarray(sym.A1p), np.ascontiguousarray(sym.A1i)
+    c2s, par = np.ascontiguousarray(sym.col2Sup), np.ascontiguousarray(sym.sParent)
+    R = oracle.ref() if oracle.have_ref() else None
+    for t in range(ns):
+        top = L.oracle_ereach_sn(ns, oracle.P(a1p), oracle.P(a1i), int(sym.super[t]), int(sym.super[t + 1]),
+                                 oracle.P(c2s), oracle.P(par), oracle.P(xi), oracle.P(xi[ns:]))
+        mine = xi[top:ns].copy()
+        # the product's hoisted update lists are the same lists
+        assert np.array_equal(mine, sym.updSn[sym.updPtr[t]: sym.updPtr[t + 1]])
+        assert not xi[ns:].any()  # workspace restored
+        if R is not None:
+            xr = np.zeros(2 * ns, np.int32)
+            topr = R.ref_ereach_sn(ns, oracle.P(a1p), oracle.P(a1i), int(sym.super[t]), int(sym.super[t + 1]),
+                                   oracle.P(c2s), oracle.P(par), oracle.P(xr), oracle.P(xr[ns:]))
+            assert topr == top and np.array_equal(xr[topr:ns], mine)
+    lp, ls = np.zeros(ns + 1, np.int32), np.zeros(ns, np.int32)
+    nl = L.oracle_getLevelSet(ns, oracle.P(par), oracle.P(lp), oracle.P(ls))
+    assert nl == sym.nlevels and np.array_equal(lp[: nl + 1], sym.levelPtr) and np.array_equal(ls, sym.levelSet)
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d"])
+def test_factor_is_the_cholesky_factor(oracle, name):
+    A, perm, sym = problem(name)
+    ok, lv, timing = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok
+    Ld = I.bcsc_to_dense(sym, lv)
+    Ad = A.to_dense()[np.ix_(sym.Perm, sym.Perm)]
+    assert np.abs(Ld @ Ld.T - Ad).max() / np.abs(Ad).max() < 1e-14 * sym.n
+    assert np.abs(Ld - np.linalg.cholesky(Ad)).max() < 1e-13 * np.abs(Ld).max() * np.sqrt(sym.n)
+    assert not np.triu(Ld, 1).any()
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "mid3d", "ex15"])
+def test_schedule_independence_and_threads(oracle, name):
+    """_05 (H-level), wavefront, 1 thread or 4: bitwise the same factor."""
+    A, perm, sym = problem(name)
+    hl = I.trivial_hlevel(sym)
+    ok, base, _ = oracle.cholesky_05(sym, sym.A2x, hl, threads=1)
+    assert ok
+    for th in (1, 4):
+        ok2, lv2, _ = oracle.cholesky_wavefront(sym, sym.A2x, threads=th)
+        ok3, lv3, _ = oracle.cholesky_05(sym, sym.A2x, hl, threads=th)
+        assert ok2 and ok3 and np.array_equal(lv2, base) and np.array_equal(lv3, base)
+    # a coarser, still valid, H-level schedule: whole subtree chains in one w-partition
+    nl = 2
+    order = np.arange(sym.nsuper, dtype=np.int32)
+    roots = np.nonzero(sym.sParent < 0)[0]
+    top = set(roots.tolist())
+    below = np.array([s for s in order if s not in top], dtype=np.int32)
+    levelPtr = np.array([0, 1, 2], np.int32)
+    parPtr = np.array([0, len(below), sym.nsuper], np.int32)
+    partition = np.concatenate([below, np.array(sorted(top), np.int32)])
+    ok4, lv4, _ = oracle.cholesky_05(sym, sym.A2x, (nl, levelPtr, parPtr, partition), threads=2)
+    assert ok4 and np.array_equal(lv4, base)
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "mid3d"])
+def test_solve_variants(oracle, name):
+    A, perm, sym = problem(name)
+    hl = I.trivial_hlevel(sym)
+    ok, lv, _ = oracle.cholesky_05(sym, sym.A2x, hl)
+    b = oracle.rhs_init_blocked(sym, lv)
+    xs = oracle.blocked_lsolve(sym, lv, b, "serial")
+    assert np.abs(xs - 1).max() < 1e-12
+    assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(xs)) == 1
+    for variant in ("H1", "H2", "H2peeled"):
+        x = oracle.blocked_lsolve(sym, lv, b, variant, hl, threads=3)
+        assert np.abs(x - xs).max() < 1e-12
+    # dense check of the solve itself
+    if sym.n <= 1500:
+        Ld = I.bcsc_to_dense(sym, lv)
+        rng = np.random.default_rng(0)
+        rhs = rng.standard_normal(sym.n)
+        x = oracle.blocked_lsolve(sym, lv, rhs, "serial")
+        assert np.abs(Ld @ x - rhs).max() < 1e-11
+
+
+def test_bcsc2csc_drops_only_padding(oracle):
+    A, perm, sym = problem("tiny2d")
+    ok, lv, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    Cp = np.zeros(sym.n + 1, np.int64)
+    Ci = np.zeros(int(sym.nnzL), np.int32)
+    Cx = np.zeros(int(sym.nnzL))
+    a = [np.ascontiguousarray(sym.p), np.ascontiguousarray(sym.s), np.ascontiguousarray(sym.i_ptr),
+         np.ascontiguousarray(sym.super)]
+    oracle.lib().oracle_bcsc2csc(sym.n, sym.nsuper, oracle.P(a[0]), oracle.P(a[1]), oracle.P(a[2]), oracle.P(a[3]),
+                                 oracle.P(lv), oracle.P(Cp), oracle.P(Ci), oracle.P(Cx))
+    assert Cp[-1] == sym.nnzL
+    Ld = I.bcsc_to_dense(sym, lv)
+    for j in range(sym.n):
+        rows = Ci[Cp[j]: Cp[j + 1]]
+        assert rows[0] == j and np.array_equal(Ld[rows, j], Cx[Cp[j]: Cp[j + 1]])

@@ -1,0 +1,90 @@
+"""Host-side schedule of the device executor (built with device = -1: no HIP call)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import problem
+from parsy_bench_amd import _native as N, inspector as I, multigpu as MG
+
+
+def host_plan(sym):
+    h = N.lib().parsy_plan_from_symbolic(sym._handle, -1)
+    assert h, N.last_error()
+    pi = N.PlanInfo()
+    N.lib().parsy_plan_get_info(h, C.byref(pi))
+    return h, pi.as_dict()
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "mid3d", "ex15"])
+def test_plan_counts_match_the_pattern(name):
+    A, perm, sym = problem(name)
+    h, info = host_plan(sym)
+    try:
+        assert (info["n"], info["nsuper"], info["nlevels"]) == (sym.n, sym.nsuper, sym.nlevels)
+        assert (info["xsize"], info["ssize"], info["nnzL"], info["nnzA"]) == (sym.xsize, sym.ssize, sym.nnzL, sym.nnzA)
+        assert info["n_updates"] == len(sym.updSn)
+        assert info["n_small"] + info["n_big"] == sym.nsuper
+        assert info["flops_stored"] == pytest.approx(sym.flops_stored, rel=1e-12)
+        # update flops from the reference's formulas
+        w = np.diff(sym.super).astype(np.float64)
+        r = np.diff(sym.i_ptr[sym.super].astype(np.int64)).astype(np.float64)
+        m = r[sym.updSn] - sym.updLb
+        n1 = (sym.updUb - sym.updLb + 1).astype(np.float64)
+        K = w[sym.updSn]
+        assert info["update_flops"] == pytest.approx(float((K * n1 * (n1 + 1) + 2 * K * (m - n1) * n1).sum()), rel=1e-12)
+        assert info["relpos_len"] == int(m.sum())
+        assert info["reread_bytes"] == pytest.approx(float(8 * (K * m).sum()), rel=1e-12)
+        assert info["chol_launches"] >= sym.nlevels and info["solve_launches"] >= sym.nlevels
+    finally:
+        N.lib().parsy_plan_destroy(h)
+
+
+def test_device_calls_on_a_host_plan_fail_loudly():
+    A, perm, sym = problem("tiny2d")
+    h, _ = host_plan(sym)
+    try:
+        lv = np.zeros(int(sym.xsize))
+        rc = N.lib().parsy_factor_host(h, N.ptr(np.ascontiguousarray(sym.A2x)), N.ptr(lv), None)
+        assert rc != 0 and "no device" in N.last_error()
+    finally:
+        N.lib().parsy_plan_destroy(h)
+
+
+def test_malformed_pattern_is_rejected():
+    A, perm, sym = problem("tiny2d")
+    bad = sym.s.copy()
+    bad[0] += 1  # first row of supernode 0 is no longer its own first column
+    a = [np.ascontiguousarray(x) for x in (sym.super, sym.p, sym.i_ptr, bad, sym.sParent, sym.col2Sup, sym.A1p,
+                                           sym.A1i, sym.A2p, sym.A2i)]
+    h = N.lib().parsy_plan_create(sym.n, sym.nsuper, *[N.ptr(v) for v in a], -1)
+    assert not h and "supernode rows" in N.last_error()
+
+
+@pytest.mark.parametrize("name,nranks", [("small3d", 2), ("mid3d", 4), ("ex15", 8)])
+def test_subtree_cut_is_a_partition_into_independent_subtrees(name, nranks):
+    A, perm, sym = problem(name)
+    cut = MG.cut_subtrees(sym, nranks)
+    assert len(cut.owner) == sym.nsuper
+    # every supernode is in exactly one subtree or in the root part
+    covered = np.zeros(sym.nsuper, int)
+    for first, last, rank, cost in cut.subtrees:
+        covered[first:last + 1] += 1
+        assert (cut.owner[first:last + 1] == rank).all()
+        # closed under "descendant of": parents stay inside except the subtree root's
+        par = sym.sParent[first:last + 1]
+        assert ((par[:-1] >= first) & (par[:-1] <= last)).all()
+        assert par[-1] < 0 or cut.owner[par[-1]] < 0
+    covered[cut.root_nodes] += 1
+    assert (covered == 1).all()
+    # the root part is upward closed
+    for s in cut.root_nodes:
+        assert sym.sParent[s] < 0 or cut.owner[sym.sParent[s]] < 0
+    # no update crosses between two different ranks' subtrees
+    tgt = np.repeat(np.arange(sym.nsuper), np.diff(sym.updPtr))
+    o_t, o_d = cut.owner[tgt], cut.owner[sym.updSn]
+    assert ((o_t < 0) | (o_t == o_d)).all()
+    # slices are disjoint, ordered ranges of lValues
+    sl = sorted((a, b) for _, a, b in cut.slices(sym))
+    assert all(sl[i][1] <= sl[i + 1][0] for i in range(len(sl) - 1))
+    assert cut.rank_cost.max() <= cut.cost.sum()
