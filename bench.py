@@ -293,7 +293,9 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         try:
-            cb, lo = cpu_baseline(sym, os.cpu_count() or 1)
+            # the GPU box gives one GPU a 16-CPU share (os.cpu_count() reports the whole host)
+            share = min(len(os.sched_getaffinity(0)), 16)
+            cb, lo = cpu_baseline(sym, share)
             out["cpu_baseline"] = cb
             plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
             torch.cuda.synchronize()

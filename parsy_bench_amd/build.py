@@ -86,7 +86,28 @@ def _build(hipcc, force, verbose, extra_flags) -> Path:
     objs = sorted(str(p) for p in OBJ.glob("*.o"))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *objs])
+    if LIB.name == "libparsy_amd.so":
+        build_drivers(hipcc, run, force)
     return LIB
+
+
+DRIVERS = PKG / "drivers"
+
+
+def build_drivers(hipcc=None, run=None, force: bool = False):
+    """choleskyTest / triangularTest: the reference's example drivers over the C ABI."""
+    hipcc = hipcc or _hipcc()
+    if run is None:
+        def run(cmd):
+            subprocess.run(cmd, check=True)
+    outs = []
+    for name in ("choleskyTest", "triangularTest"):
+        src, out = DRIVERS / f"{name}.cpp", DRIVERS / f"{name}.bin"
+        if force or _stale(out, [src, DRIVERS / "mtx_io.hpp", LIB, PKG.parent / "include" / "parsy_amd.h"]):
+            run([hipcc, "-x", "c++", "-O2", "-std=c++17", str(src), "-x", "none", "-o", str(out), str(LIB),
+                 f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/.."])
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":

@@ -10,13 +10,14 @@
 //           the LDS budget: assemble, apply every update, POTRF+TRSM, store.
 //   TILES   every other supernode is cut into 64x64 tiles of its panel (lower
 //           trapezoid only); one workgroup per tile applies the external updates
-//           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).
+//           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).  The
+//           workgroup of the diagonal tile of block column 0 then factors that
+//           block (POTRF 64x64) and parks it in a scratch slot.
 //   then per 64-wide block column jb of those supernodes:
-//   PANEL   POTRF of the 64x64 diagonal block (redundantly per workgroup, result
-//           parked in a scratch slab) + TRSM of 128-row chunks below it
+//   PANEL   TRSM of 128-row chunks below diagonal block jb (read from its slot)
 //   INNER   right-looking in-supernode update: every tile right of block column jb
-//           gets -= L(I,jb) L(J,jb)' (dense SYRK/GEMM, K = 64, same MFMA kernel,
-//           identity row map)
+//           gets -= L(I,jb) L(J,jb)' (same MFMA kernel, K = 64, identity row map);
+//           the workgroup of diagonal tile jb+1 factors and parks it.
 //   FIXUP   once per level: parked diagonal blocks are copied into the panels.
 // The solve mirrors it (SOLVE_SMALL: width <= 64; SOLVE_PANEL per block column;
 // one SOLVE_FIXUP at the end).

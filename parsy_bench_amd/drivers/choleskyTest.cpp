@@ -1,0 +1,93 @@
+// choleskyTest -- same command line and CSV as the reference's driver
+// (examples/choleskyTest01.cpp:43-277), running on the MI355X executor:
+//
+//   choleskyTest <lower.mtx> numThread chunk costParam levelParam blasThreads finalSeqNode [orderFile]
+//
+// read -> inspect -> 5 x { zero valL; cholesky_left_par_05(...) } -> one CSV line:
+//   file,numThread,chunk,costParam,levelParam,blasThreads,finalSeqNode,total_s,parallel_s,root_s,symbolic_s,ordering_s,
+// (iteration #3 of 5 is reported, unsorted, as the reference does: :266-277).
+// The inspector is this library's (parsy_analyze).  METIS is not available here, so
+// without an order file the natural ordering is used and a note goes to stderr.
+// The H-level arrays handed to the executor are the etree level sets with one
+// supernode per w-partition; numThread / chunk / costParam / levelParam / blasThreads /
+// finalSeqNode are accepted and echoed (the GPU executor schedules by etree level).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/parsy_amd.h"
+#include "mtx_io.hpp"
+
+int main(int argc, char* argv[]) {
+    if (argc < 8) {
+        std::printf("input args are missing\n"
+                    "usage: %s <lower.mtx> numThread chunk costParam levelParam blasThreads finalSeqNode [orderFile]\n",
+                    argv[0]);
+        return -1;
+    }
+    const std::string f1 = argv[1];
+    const int numThread = std::atoi(argv[2]), chunk = std::atoi(argv[3]), costParam = std::atoi(argv[4]);
+    const int levelParam = std::atoi(argv[5]), blasThreads = std::atoi(argv[6]), finalSeqNode = std::atoi(argv[7]);
+    int n = 0;
+    std::vector<int> Ap, Ai, perm;
+    std::vector<double> Ax;
+    if (!parsy_io::read_lower_mtx(f1, n, Ap, Ai, Ax)) return -1;
+    auto t0 = std::chrono::system_clock::now();
+    if (argc > 8) {
+        if (!parsy_io::read_ordering(argv[8], n, perm)) return -1;
+    } else {
+        std::cerr << "[choleskyTest] no order file and no METIS in this build: natural ordering\n";
+    }
+    const double orderingTime = std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
+
+    const int nrelax[3] = {4, 16, 48};           // examples/choleskyTest01.cpp:111
+    const double zrelax[3] = {0.8, 0.1, 0.05};   // :112
+    t0 = std::chrono::system_clock::now();
+    parsy_symbolic* sym = parsy_analyze(n, Ap.data(), Ai.data(), Ax.data(), perm.empty() ? nullptr : perm.data(),
+                                        nrelax, zrelax);
+    if (!sym) {
+        std::cerr << "analysis failed: " << parsy_last_error() << "\n";
+        return -1;
+    }
+    parsy_symbolic_view v;
+    parsy_symbolic_get(sym, &v);
+    const double durationSym = std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
+
+    // H-level arrays: etree levels, one supernode per w-partition
+    std::vector<int> levelPtr(v.levelPtr, v.levelPtr + v.nlevels + 1), parPtr(v.nsuper + 1), partition(v.nsuper);
+    for (int k = 0; k <= v.nsuper; ++k) parPtr[k] = k;
+    for (int k = 0; k < v.nsuper; ++k) partition[k] = v.levelSet[k];
+
+    std::vector<double> valL((size_t)v.xsize);
+    std::vector<double> timingChol(4 + (numThread > 0 ? numThread : 1));
+    struct CholTime { double alltogether, parallel, rootNodes; };
+    std::vector<CholTime> timeArray;
+    const int iterNo = 5;
+    for (int k = 0; k < iterNo; ++k) {
+        std::fill(valL.begin(), valL.end(), 0.0);
+        std::fill(timingChol.begin(), timingChol.end(), 0.0);
+        auto s = std::chrono::system_clock::now();
+        const bool ok = cholesky_left_par_05(
+            n, (int*)v.A2p, (int*)v.A2i, (double*)v.A2x, (size_t*)v.p, (int*)v.s, (size_t*)v.i_ptr, valL.data(),
+            (int*)v.super, v.nsuper, timingChol.data(), (int*)v.sParent, (int*)v.A1p, (int*)v.A1i, (int*)v.col2Sup,
+            v.nlevels, levelPtr.data(), nullptr, 0, parPtr.data(), partition.data(), chunk, numThread,
+            v.maxSupWid + 1, v.maxCol + 1, nullptr);
+        const double dt = std::chrono::duration<double>(std::chrono::system_clock::now() - s).count();
+        if (!ok) return -1;
+        timeArray.push_back({dt, timingChol[0], timingChol[1]});
+    }
+    const int mid = iterNo == 1 ? 0 : iterNo / 2;
+    std::cout << f1 << "," << numThread << "," << chunk << "," << costParam << "," << levelParam << ","
+              << blasThreads << "," << finalSeqNode << ",";
+    std::cout << timeArray[mid].alltogether << "," << timeArray[mid].parallel << "," << timeArray[mid].rootNodes << ",";
+    std::cout << durationSym << "," << orderingTime << ",";
+    std::cout << "\n";
+    std::cerr << "[choleskyTest] n=" << n << " nsuper=" << v.nsuper << " nnz(L)=" << v.nnzL << " F=" << v.flops_colcount
+              << " device_s(iter3)=" << timingChol[2] << "\n";
+    parsy_dropin_reset();
+    parsy_symbolic_free(sym);
+    return 0;
+}
