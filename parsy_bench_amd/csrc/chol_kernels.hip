@@ -224,10 +224,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             const TileDesc* __restrict__ tiles, int jb,
                                                             double* __restrict__ L,
                                                             double* __restrict__ dscratch,
-                                                            int* __restrict__ info) {
+                                                            int* __restrict__ info,
+                                                            int* __restrict__ flags, int epoch,
+                                                            int fused) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[2][kTile];
-    __shared__ double As[2][kTile * kLdK], Bs[2][kTile * kLdK];
+    __shared__ double stage[4][kTile * kLdK];  // A stages 0,1 and B stages 2,3 (reused by the TRSM)
+    __shared__ int32_t s_ok;
+    double (*As)[kTile * kLdK] = stage;
+    double (*Bs)[kTile * kLdK] = stage + 2;
     __shared__ int32_t relA[4][kTile], relB[4][kTile];
     __shared__ int64_t e_src[kPass];
     __shared__ int64_t e_rel[kPass];
@@ -325,36 +330,44 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         }
         if (cnt == 0) continue;
 
-        // ---- loader: chunk (e, k0) -> 8 doubles (+ one relative index) per thread
+        // ---- loader: chunk (e, k0) -> 8 doubles (+ one relative index) per thread.  The
+        // per-descendant quantities live in registers and are refreshed only when the stream
+        // moves on to the next descendant.
         struct Chunk {
             double v[8];
             int32_t rel;
             int32_t e, k0;  // e < 0: nothing to store
         };
         int le = 0, lk = 0;  // next chunk of the stream to load
+        const double* l_src = nullptr;
+        int l_K = 0, l_ld = 0, l_relv = -1;
+        bool l_rv = false;
+        auto loader_enter = [&](int e) {
+            const int base_row = ld_which ? e_j0[e] : e_i0[e];
+            const int nrow = (ld_which ? e_j2[e] : e_i2[e]) - base_row;
+            l_K = e_K[e];
+            l_ld = e_ld[e];
+            l_rv = ld_row < nrow;
+            l_src = L + e_src[e] + base_row + ld_row + (int64_t)(ld_kh * 8) * l_ld;
+            l_relv = -1;
+            if (ld_kh == 0 && l_rv) l_relv = INNER ? (base_row + ld_row) : relpos[e_rel[e] + base_row + ld_row];
+        };
+        loader_enter(0);
         auto issue = [&](Chunk& c) {
             c.e = -1;
             if (le >= cnt) return;
-            const int e = le, k0 = lk;
-            c.e = e;
-            c.k0 = k0;
-            const int base_row = ld_which ? e_j0[e] : e_i0[e];
-            const int nrow = (ld_which ? e_j2[e] : e_i2[e]) - base_row;
-            const int K = e_K[e], ld = e_ld[e];
-            const double* __restrict__ src = L + e_src[e] + base_row + ld_row;
-            const bool rv = ld_row < nrow;
+            c.e = le;
+            c.k0 = lk;
+            c.rel = l_relv;
+            const int kb = lk + ld_kh * 8;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = k0 + ld_kh * 8 + q;
-                c.v[q] = (rv && k < K) ? src[(int64_t)k * ld] : 0.0;
-            }
-            c.rel = -1;
-            if (k0 == 0 && ld_kh == 0 && rv)
-                c.rel = INNER ? (base_row + ld_row) : relpos[e_rel[e] + base_row + ld_row];
+            for (int q = 0; q < 8; ++q) c.v[q] = (l_rv && kb + q < l_K) ? l_src[(int64_t)q * l_ld] : 0.0;
             lk += kKC;
-            if (lk >= K) {
+            l_src += (int64_t)kKC * l_ld;
+            if (lk >= l_K) {
                 lk = 0;
                 ++le;
+                if (le < cnt) loader_enter(le);
             }
         };
         auto store = [&](const Chunk& c, int stage) {
@@ -365,70 +378,80 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             if (c.k0 == 0 && ld_kh == 0) (ld_which ? relB : relA)[c.e & 3][ld_row] = c.rel;
         };
 
-        // ---- consumer state of this wave
+        // ---- consumer state of this wave (per-descendant quantities cached in registers)
         int ce_ = 0, ck = 0;  // chunk of the stream being multiplied
+        int c_K = 0, c_mi = 0, c_nj = 0, c_offA = 0, c_offB = 0;
+        int c_a0 = 0, c_a1 = 0, c_b0 = 0, c_b1 = 0;  // element offsets of this lane's fragment rows
+        bool c_on = false;
+        auto consumer_enter = [&](int e) {
+            c_K = e_K[e];
+            const int i0 = e_i0[e], j0 = e_j0[e];
+            const int ia = wa ? e_i1[e] : i0, ib = wa ? e_i2[e] : e_i1[e];
+            const int ja = wb ? e_j1[e] : j0, jbnd = wb ? e_j2[e] : e_j1[e];
+            c_mi = ib - ia;
+            c_nj = jbnd - ja;
+            c_offA = ia - i0;
+            c_offB = ja - j0;
+            c_on = wave_on && c_mi > 0 && c_nj > 0;
+            c_a0 = min(c_offA + l15, kTile - 1) * kLdK + kq;
+            c_a1 = min(c_offA + 16 + l15, kTile - 1) * kLdK + kq;
+            c_b0 = min(c_offB + l15, kTile - 1) * kLdK + kq;
+            c_b1 = min(c_offB + 16 + l15, kTile - 1) * kLdK + kq;
+        };
+        consumer_enter(0);
         double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
         auto consume = [&](int stage) {
             const int e = ce_;
-            const int K = e_K[e];
-            if (wave_on) {
-                const int i0 = e_i0[e], j0 = e_j0[e];
-                const int ia = wa ? e_i1[e] : i0, ib = wa ? e_i2[e] : e_i1[e];
-                const int ja = wb ? e_j1[e] : j0, jbnd = wb ? e_j2[e] : e_j1[e];
-                const int mi = ib - ia, nj = jbnd - ja;
-                if (mi > 0 && nj > 0) {
-                    const bool two_r = mi > 16, two_c = nj > 16;
-                    const int offA = ia - i0, offB = ja - j0;
-                    const double* __restrict__ pa0 = As[stage] + min(offA + l15, kTile - 1) * kLdK + kq;
-                    const double* __restrict__ pa1 = As[stage] + min(offA + 16 + l15, kTile - 1) * kLdK + kq;
-                    const double* __restrict__ pb0 = Bs[stage] + min(offB + l15, kTile - 1) * kLdK + kq;
-                    const double* __restrict__ pb1 = Bs[stage] + min(offB + 16 + l15, kTile - 1) * kLdK + kq;
-                    const int kend = min(kKC, K - ck);
+            if (c_on) {
+                const bool two_r = c_mi > 16, two_c = c_nj > 16;
+                const double* __restrict__ SA = As[stage];
+                const double* __restrict__ SB = Bs[stage];
+                const int kend = min(kKC, c_K - ck);
 #pragma unroll
-                    for (int u = 0; u < kKC / 4; ++u) {
-                        if (4 * u >= kend) break;
-                        const double a0 = pa0[4 * u], b0 = pb0[4 * u];
-                        const double a1 = pa1[4 * u], b1 = pb1[4 * u];
-                        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
-                        if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
-                        if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
-                        if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+                for (int u = 0; u < kKC / 4; ++u) {
+                    if (4 * u >= kend) break;
+                    const double a0 = SA[c_a0 + 4 * u], b0 = SB[c_b0 + 4 * u];
+                    const double a1 = SA[c_a1 + 4 * u], b1 = SB[c_b1 + 4 * u];
+                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+                    if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+                    if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+                    if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+                }
+                if (ck + kKC >= c_K) {
+                    // last chunk of this descendant: scatter-subtract through the relative
+                    // indices (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
+                    // row = (lane >> 4) + 4 * reg).  ds_add_f64 without return: the wave owns
+                    // Tw and its LDS operations execute in order, so the sum order is fixed.
+                    const int32_t* __restrict__ ra = relA[e & 3] + c_offA;
+                    const int32_t* __restrict__ rb = relB[e & 3] + c_offB;
+                    int rC[2];
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc) {
+                        const int jl = tc * 16 + l15;
+                        rC[tc] = (jl < c_nj) ? rb[jl] - subcol0 : -1;
                     }
-                    if (ck + kKC >= K) {
-                        // last chunk of this descendant: scatter-subtract through the relative
-                        // indices (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
-                        // row = (lane >> 4) + 4 * reg).  ds_add_f64 without return: the wave owns
-                        // Tw and its LDS operations execute in order, so the sum order is fixed.
-                        const int32_t* __restrict__ ra = relA[e & 3] + offA;
-                        const int32_t* __restrict__ rb = relB[e & 3] + offB;
-                        int rC[2];
 #pragma unroll
-                        for (int tc = 0; tc < 2; ++tc) {
-                            const int jl = tc * 16 + l15;
-                            rC[tc] = (jl < nj) ? rb[jl] - subcol0 : -1;
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int il0 = kq + 4 * v, il1 = 16 + kq + 4 * v;
-                            const int R0 = (il0 < mi) ? ra[il0] - subrow0 : -1;
-                            const int R1 = (il1 < mi) ? ra[il1] - subrow0 : -1;
-                            const int C0 = rC[0], C1 = rC[1];
-                            if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) lds_sub(&Tw[C0 * kLdSub + R0], c00[v]);
-                            if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) lds_sub(&Tw[C1 * kLdSub + R0], c01[v]);
-                            if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) lds_sub(&Tw[C0 * kLdSub + R1], c10[v]);
-                            if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) lds_sub(&Tw[C1 * kLdSub + R1], c11[v]);
-                        }
-                        c00 = {0, 0, 0, 0};
-                        c01 = {0, 0, 0, 0};
-                        c10 = {0, 0, 0, 0};
-                        c11 = {0, 0, 0, 0};
+                    for (int v = 0; v < 4; ++v) {
+                        const int il0 = kq + 4 * v, il1 = 16 + kq + 4 * v;
+                        const int R0 = (il0 < c_mi) ? ra[il0] - subrow0 : -1;
+                        const int R1 = (il1 < c_mi) ? ra[il1] - subrow0 : -1;
+                        const int C0 = rC[0], C1 = rC[1];
+                        if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) lds_sub(&Tw[C0 * kLdSub + R0], c00[v]);
+                        if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) lds_sub(&Tw[C1 * kLdSub + R0], c01[v]);
+                        if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) lds_sub(&Tw[C0 * kLdSub + R1], c10[v]);
+                        if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) lds_sub(&Tw[C1 * kLdSub + R1], c11[v]);
                     }
+                    c00 = {0, 0, 0, 0};
+                    c01 = {0, 0, 0, 0};
+                    c10 = {0, 0, 0, 0};
+                    c11 = {0, 0, 0, 0};
                 }
             }
             ck += kKC;
-            if (ck >= K) {
+            if (ck >= c_K) {
                 ck = 0;
                 ++ce_;
+                if (ce_ < cnt) consumer_enter(ce_);
             }
         };
 
@@ -466,24 +489,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     }
 
     if (stamp_wg) STAMP(9);
-    if (wave_on) {
-        for (int e = lane; e < kSub * kSub; e += 64) {
-            const int cc = e >> 5, rr = e & 31;
-            if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc))
-                G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] = Tw[cc * kLdSub + rr];
+    // The block column that has just received its last update is finished here: its diagonal
+    // tile is factored on the spot and parked in a scratch slot (FIXUP copies it into the
+    // panel); in a fused launch the tiles below it wait for that block and do their TRSM
+    // straight out of LDS, otherwise PANEL does it in the next launch.
+    const bool col_final = INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0;
+    const bool diag_tile = td.row0 == td.col0;
+    const bool trsm_here = fused && col_final && !diag_tile;
+    auto write_back = [&](int min_row) {  // min_row: first row of the TILE that is written
+        if (wave_on) {
+            for (int e = lane; e < kSub * kSub; e += 64) {
+                const int cc = e >> 5, rr = e & 31;
+                if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc) && kSub * wa + rr >= min_row)
+                    G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] = Tw[cc * kLdSub + rr];
+            }
         }
-    }
+    };
+    if (!trsm_here) write_back(0);
+    if (!col_final) return;
+    const int nb = min(kTile, w - td.col0);
+    int trsm_min_row = 0;
+    const int slot_id = D.dslot + td.col0 / kTile;
+    double* __restrict__ slot = dscratch + (int64_t)slot_id * (kTile * kTile);
 
-    // A diagonal tile that has just received its last update is factored on the spot and
-    // parked in its scratch slot (PANEL's TRSM reads it there, FIXUP copies it into the
-    // panel): block column 0 after the external updates, block column jb+1 after the
-    // right-looking update by block column jb.
-    const bool final_diag = td.row0 == td.col0 && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
-    if (final_diag) {
+    if (diag_tile) {
         __syncthreads();
         STAMP(10);
         const int ti = tid & 15, tj = tid >> 4;
-        const int nb = min(kTile, w - td.col0);
         double a[4][4];
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
@@ -499,7 +531,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         potrf64_regs(a, colbuf, ti, tj, nb, bad);
         STAMP(12);
         if (tid == 0 && bad) atomicMin(info, D.c0 + td.col0 + bad);
-        double* __restrict__ slot = dscratch + (int64_t)(D.dslot + td.col0 / kTile) * (kTile * kTile);
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -507,8 +538,125 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                 const int i = 4 * ti + ri, c = 4 * tj + ci;
                 slot[c * kTile + i] = (c < nb && i < nb && i >= c) ? a[ri][ci] : 0.0;
             }
+        if (fused) {
+            // publish (agent-scope release, cdna_hip_programming.md Guideline 16): every storing
+            // wave drains its stores, the workgroup meets, one lane releases and raises the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&flags[slot_id], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         STAMP(13);
+        // a block column narrower than the tile leaves rows of the panel below the diagonal
+        // block inside this very tile: solve them here (PANEL does it when not fused)
+        if (!(fused && nb < kTile && td.row0 + nb < r)) return;
+        trsm_min_row = nb;
+        __syncthreads();  // the parked block (global) is visible to the whole workgroup
+    } else if (!trsm_here) {
+        return;
+    } else if (tid == 0) {
+        if (td.row0 == td.col0 + kTile) STAMP(24);
+        // ---- wait for the parked diagonal block (bounded)
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(&flags[slot_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ok = ok;
     }
+    if (!diag_tile) {
+        __syncthreads();
+        if (!s_ok) {
+            if (tid == 0) atomicMin(info, -1);  // status < 0: a fused wait timed out
+            write_back(0);
+            return;
+        }
+    }
+    if (td.row0 == td.col0 + kTile) STAMP(25);
+    // ---- X := B inv(Ljj') on the rows of the LDS tile
+    double* __restrict__ Dg = &stage[0][0];  // 64 x 65 doubles, the update stream is finished
+    double* __restrict__ invd = colbuf[0];
+    {
+        double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+        for (int q = 0; q < kTile * kTile / kThreads; ++q) dtmp[q] = slot[q * kThreads + tid];
+#pragma unroll
+        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+            const int e = q * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
+        }
+        if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / slot[tid * kTile + tid] : 1.0;
+    }
+    __syncthreads();
+    if (td.row0 == td.col0 + kTile) STAMP(26);
+    // inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
+    // transposed into the (unused) strict upper triangle of the same sub-block:
+    // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  The TRSM below is then all products
+    // (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.
+    if (tid < kTile) {
+        const int b16 = (tid >> 4) * 16, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // all reads of the sub-block precede the in-place writes
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+    }
+    __syncthreads();
+    {
+        // each wave owns 16 rows of the tile for the whole solve: no barrier between blocks
+        const int rbase = 16 * wave;
+        auto TT = [&](int i, int c) -> double& {
+            return T[(i >> 5) * 2 + (c >> 5)][(c & 31) * kLdSub + (i & 31)];
+        };
+        for (int b16 = 0; b16 < nb; b16 += 16) {
+            double4_t acc = {0, 0, 0, 0};
+            for (int p16 = 0; p16 < b16; p16 += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = p16 + kq + 4 * u;
+                    const double av = TT(rbase + l15, k);                  // X[row][k]
+                    const double bv = Dg[k * kLdDiag + b16 + l15];         // L[b16 + j][k]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) TT(rbase + kq + 4 * v, b16 + l15) -= acc[v];
+            double4_t acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kq + 4 * u, j = l15;
+                const double av = TT(rbase + l15, b16 + k);                // R[row][k]
+                double wv = 0.0;                                            // inv(L_bb)'[k][j] = inv(L_bb)[j][k]
+                if (j > k) wv = Dg[(b16 + j) * kLdDiag + b16 + k];
+                else if (j == k) wv = invd[b16 + k];
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, wv, acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) TT(rbase + kq + 4 * v, b16 + l15) = acc2[v];
+        }
+    }
+    __syncthreads();
+    if (td.row0 == td.col0 + kTile) STAMP(27);
+    write_back(trsm_min_row);
+    if (td.row0 == td.col0 + kTile) STAMP(28);
 }
 
 #ifdef PARSY_STAMPS
@@ -517,15 +665,17 @@ extern "C" void parsy_debug_stamps(unsigned long long* out) {
 }
 #endif
 
-void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, double* L,
-                       hipStream_t stream) {
+void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
+                       int epoch, double* L, hipStream_t stream) {
     if (count <= 0) return;
     if (inner)
         hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info);
+                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
+                           fused);
     else
         hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info);
+                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
+                           fused);
 }
 
 // ---------------------------------------------------------------------------

@@ -67,6 +67,11 @@ static int plan_upload(parsy_plan* pl) {
         pl->owned.push_back(d);
         pl->dp.info = (int*)d;
         PARSY_HIP(hipMemset(d, 0x7f, sizeof(int)));
+        const size_t fbytes = std::max<int64_t>(S.n_dslots, 1) * sizeof(int);
+        PARSY_HIP(hipMalloc(&d, fbytes));
+        pl->owned.push_back(d);
+        pl->dp.flags = (int*)d;
+        PARSY_HIP(hipMemset(d, 0, fbytes));
     }
     PARSY_HIP(hipEventCreate(&pl->ev_f0));
     PARSY_HIP(hipEventCreate(&pl->ev_f1));
@@ -132,8 +137,12 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, L, stream); break;
-            case kLaunchTiles: launch_chol_tiles(pl->dp, l.first, l.count, false, 0, L, stream); break;
-            case kLaunchInner: launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, L, stream); break;
+            case kLaunchTiles:
+                launch_chol_tiles(pl->dp, l.first, l.count, false, 0, l.fused, pl->epoch, L, stream);
+                break;
+            case kLaunchInner:
+                launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, l.fused, pl->epoch, L, stream);
+                break;
             case kLaunchPanel: launch_chol_panel(pl->dp, l.first, l.count, L, stream); break;
             case kLaunchFixup: launch_chol_fixup(pl->dp, l.first, l.count, L, stream); break;
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
@@ -175,6 +184,7 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
         return -1;
     }
     const Schedule& S = pl->S;
+    pl->epoch = (pl->epoch == INT_MAX) ? 1 : pl->epoch + 1;  // flags of earlier factorizations go stale
     PARSY_HIP(hipEventRecord(pl->ev_f0, stream));
     if (init) PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
     // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)

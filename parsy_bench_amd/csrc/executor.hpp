@@ -19,6 +19,7 @@ struct parsy_plan {
     std::vector<void*> launch_owned; // the launch-array blocks
     parsy::DevicePattern dp;
     int64_t device_bytes = 0;
+    int epoch = 0;            // factorization counter (value the fused launches publish / wait for)
 
     double* xscratch = nullptr;
     int64_t xscratch_len = 0;

@@ -24,7 +24,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
     double* dscratch = nullptr;  // parked 64x64 diagonal blocks
-    int* info = nullptr;         // first failed pivot column + 1 (INT_MAX = none)
+    int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
+    int* flags = nullptr;        // per parked diagonal block: epoch of the factorization that parked it
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -32,8 +33,8 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
                       hipStream_t stream);
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
                        hipStream_t stream);
-void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, double* L,
-                       hipStream_t stream);
+void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
+                       int epoch, double* L, hipStream_t stream);
 void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 

@@ -2,6 +2,8 @@
 #include "schedule.hpp"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <stdexcept>
 #include <string>
 
@@ -95,6 +97,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
 
     // --- tiled supernodes: scratch slots and per-block-column update lists ----------
     S.sn_cb0.assign(ns, -1);
+    S.sn_tw0.assign(ns, -1);
     std::vector<std::vector<ColBlkEntry>> bucket;
     for (int t = 0; t < ns; ++t) {
         SnDesc& T = S.sn[t];
@@ -125,6 +128,23 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                 if (e.jhi > e.jlo) bucket[J].push_back(e);
             }
         }
+        // weight of every tile = number of 16-wide k chunks of the updates that reach it
+        const int nbr_t = ceil_div(T.r, kTile);
+        S.sn_tw0[t] = (int64_t)S.tile_w.size();
+        S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr_t, 0);
+        int32_t* tw = &S.tile_w[S.sn_tw0[t]];
+        for (int J = 0; J < nbc; ++J)
+            for (const ColBlkEntry& e : bucket[J]) {
+                const UpdDesc& U = S.upd[e.upd];
+                const int32_t* rel = &S.relpos[U.rel];
+                const int chunks = ceil_div(U.K, 16);
+                int last = -1;
+                for (int k = 0; k < U.m; ++k) {
+                    const int I = rel[k] / kTile;
+                    if (I != last && I >= J) tw[(size_t)J * nbr_t + I] += chunks;
+                    last = I;
+                }
+            }
         S.sn_cb0[t] = (int64_t)S.cb_ptr.size();
         for (int J = 0; J < nbc; ++J) {
             S.cb_ptr.push_back((int64_t)S.colblk.size());
@@ -160,7 +180,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
         sbigs.clear();
         // ---- Cholesky -------------------------------------------------------------
         if (!S.solve_only) {
-            Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0};
+            Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t]) continue;
@@ -176,53 +196,82 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (L.count > 0) S.chol.push_back(L);
         }
         if (!S.solve_only && !bigs.empty()) {
-            Launch L{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0};
-            int maxnb = 0;
+            // ---- TILES: external updates; block column 0 becomes final here -----------------
+            Launch L{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0, 0};
+            int maxnb = 0, waiting = 0;
+            for (int t : bigs) waiting += ceil_div(S.sn[t].r, kTile) - 1;
+            L.fused = waiting <= kMaxWaitingTiles;
+            std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
             for (int t : bigs) {
                 const SnDesc& T = S.sn[t];
                 const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                 maxnb = std::max(maxnb, nbc);
+                const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
                 for (int J = 0; J < nbc; ++J) {
                     const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + J], c1 = S.cb_ptr[S.sn_cb0[t] + J + 1];
-                    // the diagonal tile of block column 0 is always scheduled: it factors
-                    // the block once its (possibly empty) update list is applied
-                    if (c1 == c0 && J > 0) continue;
-                    for (int I = J; I < (c1 == c0 ? J + 1 : nbr); ++I)
-                        S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, (int32_t)c0, (int32_t)c1, 0});
+                    for (int I = J; I < nbr; ++I) {
+                        const int32_t wgt = tw[(size_t)J * nbr + I];
+                        // tiles nothing reaches are skipped, except those of block column 0 that
+                        // must factor (diagonal) or solve (fused launch) their block
+                        const bool needed = wgt > 0 || (J == 0 && (I == 0 || L.fused));
+                        if (!needed) continue;
+                        const int32_t prio = (J == 0 && I == 0) ? INT32_MAX : wgt;  // diagonal first
+                        wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, (int32_t)c0,
+                                                     (int32_t)(wgt > 0 ? c1 : c0), 0}});
+                    }
                 }
             }
+            // longest update streams first (the launch ends with its longest tile)
+            std::stable_sort(wt.begin(), wt.end(),
+                             [](const auto& a, const auto& b) { return a.first > b.first; });
+            for (auto& x : wt) S.tiles.push_back(x.second);
             L.count = (int32_t)S.tiles.size() - L.first;
             if (L.count > 0) S.chol.push_back(L);
+            bool prev_fused = L.fused && L.count > 0;
             for (int jb = 0; jb < maxnb; ++jb) {
-                Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0};
+                // ---- PANEL(jb): only when the launch that finalised column jb was not fused ----
+                if (!prev_fused) {
+                    Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0, 0};
+                    for (int t : bigs) {
+                        const SnDesc& T = S.sn[t];
+                        if (ceil_div(T.w, kTile) <= jb) continue;
+                        const int wb = std::min(kTile, T.w - jb * kTile);
+                        for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
+                            S.panels.push_back(PanelDesc{t, jb, row0, 0});
+                    }
+                    Lp.count = (int32_t)S.panels.size() - Lp.first;
+                    if (Lp.count > 0) S.chol.push_back(Lp);
+                }
+                // ---- INNER(jb): right-looking update of everything right of block column jb;
+                // block column jb+1 becomes final
+                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0, 0};
+                int wait_i = 0;
                 for (int t : bigs) {
                     const SnDesc& T = S.sn[t];
-                    if (ceil_div(T.w, kTile) <= jb) continue;
-                    const int wb = std::min(kTile, T.w - jb * kTile);
-                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
-                        S.panels.push_back(PanelDesc{t, jb, row0, 0});
+                    if (ceil_div(T.w, kTile) > jb + 1) wait_i += ceil_div(T.r, kTile) - (jb + 1) - 1;
                 }
-                Lp.count = (int32_t)S.panels.size() - Lp.first;
-                if (Lp.count > 0) S.chol.push_back(Lp);
-                // right-looking update of everything to the right of block column jb
-                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0};
-                for (int t : bigs) {
-                    const SnDesc& T = S.sn[t];
-                    const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
-                    for (int J = jb + 1; J < nbc; ++J)
-                        for (int I = J; I < nbr; ++I)
-                            S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, 0, 0});
-                }
+                Li.fused = wait_i <= kMaxWaitingTiles;
+                for (int pass = 0; pass < 3; ++pass)  // diagonal tiles, then column jb+1, then the rest
+                    for (int t : bigs) {
+                        const SnDesc& T = S.sn[t];
+                        const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+                        for (int J = jb + 1; J < nbc; ++J)
+                            for (int I = J; I < nbr; ++I) {
+                                const int cls = (J == jb + 1) ? (I == J ? 0 : 1) : 2;
+                                if (cls == pass) S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, 0, 0});
+                            }
+                    }
                 Li.count = (int32_t)S.tiles.size() - Li.first;
                 if (Li.count > 0) S.chol.push_back(Li);
+                prev_fused = Li.fused && Li.count > 0;
             }
-            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0};
+            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0, 0};
             S.fix_list.insert(S.fix_list.end(), bigs.begin(), bigs.end());
             S.chol.push_back(Lf);
         }
         // ---- forward solve ----------------------------------------------------------
         {
-            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0};
+            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t]) continue;
@@ -236,7 +285,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             int maxnb = 0;
             for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
             for (int jb = 0; jb < maxnb; ++jb) {
-                Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0};
+                Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0, 0};
                 for (int t : sbigs) {
                     const SnDesc& T = S.sn[t];
                     if (ceil_div(T.w, kTile) <= jb) continue;
@@ -252,7 +301,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
         }
     }
     if (!S.solve_fix_list.empty())
-        S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0});
+        S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0});
 }
 
 }  // namespace parsy

@@ -89,7 +89,14 @@ struct Launch {
     int32_t level;
     int32_t jb;            // block column (INNER / PANEL / SOLVE_PANEL)
     int32_t lds_bytes;     // dynamic LDS (SMALL)
+    int32_t fused;         // TILES / INNER: the workgroups of the block column that becomes final
+                           // wait for its diagonal block and do the TRSM themselves (no PANEL launch)
 };
+
+// Upper bound on workgroups that may wait inside one fused launch.  They occupy residency
+// slots while they wait; keeping them well below the 2 x 256 slots of the tile kernel
+// guarantees that the workgroup they wait for is always dispatched.
+constexpr int kMaxWaitingTiles = 320;
 
 struct Schedule {
     int n = 0, nsuper = 0, nlevels = 0;
@@ -125,6 +132,8 @@ struct Schedule {
     std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow
     std::vector<int64_t> sn_cb0;       // per supernode: first index into cb_ptr (-1: SMALL)
     std::vector<int64_t> cb_ptr;       // ColBlkEntry ranges per (tiled supernode, block column)
+    std::vector<int64_t> sn_tw0;       // per supernode: first index into tile_w (-1: SMALL)
+    std::vector<int32_t> tile_w;       // per (tiled supernode, J, I): 16-wide k chunks its update stream holds
 };
 
 // Build descriptors + launch lists. `active` (nsuper bytes or null = all) restricts

@@ -22,3 +22,5 @@ print("diag tile: update %.2f  writeback+sync %.2f  gather %.2f  potrf %.2f  par
     t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[13] - t[12]))
 print("root tile(0,0) thread0: entries %d chunks %d | store %.1f issue %.1f consume %.1f barrier %.1f | loop %.1f us" % (
     st[22], st[21], st[16] / 100.0, st[17] / 100.0, st[18] / 100.0, st[19] / 100.0, st[20] / 100.0))
+print("tile below diag: wait %.2f  load Dg %.2f  trsm %.2f  store %.2f us;  diag publish->(wait end) %.2f" % (
+    t[25] - t[24], t[26] - t[25], t[27] - t[26], t[28] - t[27], t[25] - t[13]))
