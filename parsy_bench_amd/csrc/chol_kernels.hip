@@ -361,7 +361,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             c.rel = l_relv;
             const int kb = lk + ld_kh * 8;
 #pragma unroll
+#ifdef PARSY_ABL_NOLOAD
+            for (int q = 0; q < 8; ++q) c.v[q] = (double)(kb + q);
+#else
             for (int q = 0; q < 8; ++q) c.v[q] = (l_rv && kb + q < l_K) ? l_src[(int64_t)q * l_ld] : 0.0;
+#endif
             lk += kKC;
             l_src += (int64_t)kKC * l_ld;
             if (lk >= l_K) {
@@ -412,12 +416,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                     if (4 * u >= kend) break;
                     const double a0 = SA[c_a0 + 4 * u], b0 = SB[c_b0 + 4 * u];
                     const double a1 = SA[c_a1 + 4 * u], b1 = SB[c_b1 + 4 * u];
+#ifdef PARSY_ABL_NOMFMA
+                    c00[0] += a0 * b0; c01[0] += a0 * b1; c10[0] += a1 * b0; c11[0] += a1 * b1;
+                    continue;
+#endif
                     c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
                     if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
                     if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
                     if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
                 }
+#ifdef PARSY_ABL_NOSCATTER
+                if (false) {
+#else
                 if (ck + kKC >= c_K) {
+#endif
+                    const bool two_r = c_mi > 16, two_c = c_nj > 16;
                     // last chunk of this descendant: scatter-subtract through the relative
                     // indices (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
                     // row = (lane >> 4) + 4 * reg).  ds_add_f64 without return: the wave owns
@@ -436,10 +449,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                         const int R0 = (il0 < c_mi) ? ra[il0] - subrow0 : -1;
                         const int R1 = (il1 < c_mi) ? ra[il1] - subrow0 : -1;
                         const int C0 = rC[0], C1 = rC[1];
-                        if (R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0)) lds_sub(&Tw[C0 * kLdSub + R0], c00[v]);
-                        if (R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1)) lds_sub(&Tw[C1 * kLdSub + R0], c01[v]);
-                        if (R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0)) lds_sub(&Tw[C0 * kLdSub + R1], c10[v]);
-                        if (R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1)) lds_sub(&Tw[C1 * kLdSub + R1], c11[v]);
+                        // Cells outside the update (padding of the 16x16 fragments, the strict upper
+                        // triangle of a diagonal sub-tile) subtract 0.0 from a padding element of the
+                        // sub-tile (row 32 of column lane & 31): branch-free, and the dummies are
+                        // spread so they do not pile onto one address.
+                        const int dummy = (lane & 31) * kLdSub + kSub;
+                        const bool ok00 = R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0);
+                        lds_sub(&Tw[ok00 ? C0 * kLdSub + R0 : dummy], ok00 ? c00[v] : 0.0);
+                        if (two_c) {
+                            const bool ok01 = R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1);
+                            lds_sub(&Tw[ok01 ? C1 * kLdSub + R0 : dummy], ok01 ? c01[v] : 0.0);
+                        }
+                        if (two_r) {
+                            const bool ok10 = R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0);
+                            lds_sub(&Tw[ok10 ? C0 * kLdSub + R1 : dummy], ok10 ? c10[v] : 0.0);
+                        }
+                        if (two_r && two_c) {
+                            const bool ok11 = R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1);
+                            lds_sub(&Tw[ok11 ? C1 * kLdSub + R1 : dummy], ok11 ? c11[v] : 0.0);
+                        }
                     }
                     c00 = {0, 0, 0, 0};
                     c01 = {0, 0, 0, 0};
