@@ -16,18 +16,70 @@ static constexpr int kThreads = 256;
 static constexpr int kLdDiag = kTile + 1;
 static constexpr int kRhs = 8;  // right-hand sides carried per pass over a panel
 
-// Forward substitution of the staged block: xs[c][q], c < w, q < nq, with the
-// lower-triangular block Dg (column-major, ld kLdDiag). All threads of the
-// workgroup participate; ends synchronised.
-__device__ __forceinline__ void block_forward_solve(const double* Dg, double (*xs)[kRhs], int w,
-                                                    int nq, int tid) {
-    for (int c = 0; c < w; ++c) {
-        if (tid < nq) xs[c][tid] = xs[c][tid] / Dg[c * kLdDiag + c];
+// Forward solve of the staged block xs[c][q] (c < w <= 64, q < nq) with the lower-triangular
+// block Dg (column-major, ld kLdDiag; entries outside w x w must be an identity).  Blocked by
+// 16: the four 16x16 diagonal sub-blocks are inverted once (one column per thread, written
+// transposed into the unused strict upper triangle of the sub-block), then per sub-block
+//   y_b = inv(L_bb) x_b   and   x_rest -= L(rest, b) y_b
+// -- 2 barriers per 16 columns instead of 2 per column.  All threads participate; ends
+// synchronised.  (triangularSolve/BLAS.h:8 divides by the diagonal; so does the inversion.)
+__device__ __forceinline__ void block_solve_apply16(const double* Dg, const double* invd,
+                                                    double (*xs)[kRhs], int w, int nq, int tid);
+
+__device__ __forceinline__ void block_solve_inv16(double* Dg, double* invd, double (*xs)[kRhs], int w,
+                                                  int nq, int tid) {
+    if (tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
+    __syncthreads();
+    if (tid < kTile && (tid & ~15) < w) {
+        const int b16 = tid & ~15, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // every read of the sub-block precedes the in-place writes
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+    }
+    __syncthreads();
+    block_solve_apply16(Dg, invd, xs, w, nq, tid);
+}
+
+// The substitution itself, given the inverted sub-blocks (re-used for every pass of
+// right-hand sides over the same diagonal block).
+__device__ __forceinline__ void block_solve_apply16(const double* Dg, const double* invd,
+                                                    double (*xs)[kRhs], int w, int nq, int tid) {
+    for (int b16 = 0; b16 < w; b16 += 16) {
+        // y = inv(L_bb) x_b : thread (i, q), i < 16
+        double yv = 0.0;
+        const int i = tid & 15, q = tid >> 4;
+        const bool act = q < nq;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double lv = 0.0;
+                if (k < i) lv = Dg[(b16 + i) * kLdDiag + b16 + k];  // inv(L_bb)[i][k], stored transposed
+                else if (k == i) lv = invd[b16 + i];
+                yv = fma(lv, xs[b16 + k][q], yv);
+            }
+        }
         __syncthreads();
-        const int rem = w - c - 1;
+        if (act) xs[b16 + i][q] = yv;
+        __syncthreads();
+        // rows below the sub-block: x[r][q] -= sum_k L[r][b16+k] y[k][q]
+        const int rem = w - b16 - 16;
         for (int e = tid; e < rem * nq; e += kThreads) {
-            const int q = e / rem, i = c + 1 + (e - q * rem);
-            xs[i][q] = fma(-Dg[c * kLdDiag + i], xs[c][q], xs[i][q]);
+            const int qq = e / rem, rr = b16 + 16 + (e - qq * rem);
+            double acc = xs[rr][qq];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = fma(-Dg[(b16 + k) * kLdDiag + rr], xs[b16 + k][qq], acc);
+            xs[rr][qq] = acc;
         }
         __syncthreads();
     }
@@ -40,6 +92,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
                                                           const double* __restrict__ L,
                                                           double* __restrict__ x, int nrhs, int ldx) {
     __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
     __shared__ double xs[kTile][kRhs];
     const int tid = threadIdx.x;
     const SnDesc D = sn[list[blockIdx.x]];
@@ -47,19 +100,23 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
     const double* __restrict__ G = L + D.px;
     const int32_t* __restrict__ ri = rows + D.pi;
 
-    for (int e = tid; e < w * w; e += kThreads) {
-        const int c = e / w, i = e - c * w;
-        if (i >= c) Dg[c * kLdDiag + i] = G[(int64_t)c * r + i];
+    const int wpad = (w + 15) & ~15;
+    for (int e = tid; e < wpad * wpad; e += kThreads) {
+        const int c = e / wpad, i = e - c * wpad;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (i >= c && i < w && c < w) v = G[(int64_t)c * r + i];
+        Dg[c * kLdDiag + i] = v;
     }
     for (int q0 = 0; q0 < nrhs; q0 += kRhs) {
         const int nq = min(kRhs, nrhs - q0);
         __syncthreads();
-        for (int e = tid; e < w * nq; e += kThreads) {
-            const int q = e / w, c = e - q * w;
-            xs[c][q] = x[(int64_t)(q0 + q) * ldx + D.c0 + c];
+        for (int e = tid; e < wpad * nq; e += kThreads) {
+            const int q = e / wpad, c = e - q * wpad;
+            xs[c][q] = (c < w) ? x[(int64_t)(q0 + q) * ldx + D.c0 + c] : 0.0;
         }
         __syncthreads();
-        block_forward_solve(Dg, xs, w, nq, tid);
+        if (q0 == 0) block_solve_inv16(Dg, invd, xs, w, nq, tid);
+        else block_solve_apply16(Dg, invd, xs, w, nq, tid);
         for (int e = tid; e < w * nq; e += kThreads) {
             const int q = e / w, c = e - q * w;
             x[(int64_t)(q0 + q) * ldx + D.c0 + c] = xs[c][q];
@@ -100,6 +157,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_panel(const SnDesc* __restri
                                                           double* __restrict__ xscratch, int nrhs,
                                                           int ldx) {
     __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
     __shared__ double xs[kTile][kRhs];
     const int tid = threadIdx.x;
     const PanelDesc pd = pds[blockIdx.x];
@@ -108,19 +166,32 @@ __global__ __launch_bounds__(kThreads) void k_solve_panel(const SnDesc* __restri
     const double* __restrict__ G = L + D.px;
     const int32_t* __restrict__ ri = rows + D.pi;
 
-    for (int e = tid; e < kTile * kTile; e += kThreads) {
-        const int c = e >> 6, i = e & 63;
-        if (c < wbk && i < wbk && i >= c) Dg[c * kLdDiag + i] = G[(int64_t)(cb + c) * r + cb + i];
+    {
+        double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            const int c = e >> 6, i = e & 63;
+            double v = (i == c) ? 1.0 : 0.0;
+            if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+            dtmp[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+        }
     }
     for (int q0 = 0; q0 < nrhs; q0 += kRhs) {
         const int nq = min(kRhs, nrhs - q0);
         __syncthreads();
-        for (int e = tid; e < wbk * nq; e += kThreads) {
-            const int q = e / wbk, c = e - q * wbk;
-            xs[c][q] = x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c];
+        for (int e = tid; e < kTile * nq; e += kThreads) {
+            const int q = e >> 6, c = e & 63;
+            xs[c][q] = (c < wbk) ? x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] : 0.0;
         }
         __syncthreads();
-        block_forward_solve(Dg, xs, wbk, nq, tid);
+        if (q0 == 0) block_solve_inv16(Dg, invd, xs, wbk, nq, tid);
+        else block_solve_apply16(Dg, invd, xs, wbk, nq, tid);
         if (pd.row0 < 0) {
             for (int e = tid; e < wbk * nq; e += kThreads) {
                 const int q = e / wbk, c = e - q * wbk;
@@ -133,10 +204,14 @@ __global__ __launch_bounds__(kThreads) void k_solve_panel(const SnDesc* __restri
             double acc[kRhs];
 #pragma unroll
             for (int q = 0; q < kRhs; ++q) acc[q] = 0.0;
-            for (int c = 0; c < wbk; ++c) {
-                const double lv = G[(int64_t)(cb + c) * r + k];
+            for (int c0 = 0; c0 < wbk; c0 += 16) {  // 16 loads in flight, then their FMAs
+                double lv[16];
 #pragma unroll
-                for (int q = 0; q < kRhs; ++q) acc[q] = fma(lv, xs[c][q], acc[q]);
+                for (int c = 0; c < 16; ++c) lv[c] = (c0 + c < wbk) ? G[(int64_t)(cb + c0 + c) * r + k] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+#pragma unroll
+                    for (int q = 0; q < kRhs; ++q) acc[q] = fma(lv[c], xs[c0 + c][q], acc[q]);
             }
             const int row = ri[k];  // rows inside the supernode map to its own columns
 #pragma unroll
