@@ -151,56 +151,93 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
 }
 
 // ---------------------------------------------------------------------------
-// POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked:
-// thread (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers; per column
-// j one LDS broadcast of the pivot column (double-buffered: one barrier per column)
-// and a rank-1 update in registers.  Entries outside the block (nb < 64) must be an
-// identity so that the loop is uniform.  Strictly-upper entries pick up garbage
-// that is never stored.  `colbuf` is 2 x 64 doubles of LDS.  On return a[][] holds the
-// factor; `bad` receives (1-based) the first column whose pivot was not positive.
+// POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked: thread
+// (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers.  Four columns per step:
+//   (1) the owner of the 4x4 diagonal micro-block broadcasts it through LDS,
+//   (2) every thread of that block column factors the micro-block itself (4 pivots in
+//       registers) and solves its own 4x4 block against it, then publishes the 4 new columns,
+//   (3) everybody applies the rank-4 update to its block.
+// Two barriers per 4 columns.  Entries outside the block (nb < 64) must be an identity so the
+// loop is uniform; strictly-upper entries pick up garbage that is never stored.  `scr` is
+// 16 + 64*5 doubles of LDS.  On return a[][] holds the factor; `bad` receives (1-based) the
+// first column whose pivot was not positive.  Pivots use rsqrt (1/sqrt(d) directly: the
+// divide-after-sqrt chain is the critical path of every block step).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double (*colbuf)[kTile], int ti,
-                                             int tj, int nb, int& bad) {
+static constexpr int kPotrfScratch = 16 + kTile * 5;
+__device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restrict__ scr, int ti, int tj,
+                                             int nb, int& bad) {
+    double* __restrict__ bufD = scr;        // 4x4 micro-block, row-major
+    double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
     const bool lower = ti >= tj;
     bad = 0;
     for (int tjj = 0; tjj < kTile / 4; ++tjj) {
+        if (ti == tjj && tj == tjj) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * tjj + jj;
-            double* __restrict__ buf = colbuf[j & 1];
-            if (tj == tjj && lower) {
+            for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                for (int ri = 0; ri < 4; ++ri) buf[4 * ti + ri] = a[ri][jj];
-            }
-            __syncthreads();
-            const double d = buf[j];
-            if (j < nb && !(d > 0.0) && bad == 0) bad = j + 1;
-            if (lower && tj >= tjj) {
-                // 1/sqrt(d) directly (one rsq + refinement instead of sqrt then divide: this
-                // chain is the critical path of every block step); l_jj = d * rsqrt(d)
-                const double inv = rsqrt(d);
-                const double sq = d * inv;
-                double li[4], lc[4];
+                for (int ci = 0; ci < 4; ++ci) bufD[ri * 4 + ci] = a[ri][ci];
+        }
+        __syncthreads();
+        if (tj == tjj && lower) {
+            double m[4][4], l[4][4], inv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    li[q] = buf[4 * ti + q] * inv;
-                    lc[q] = buf[4 * tj + q] * inv;
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) m[ri][ci] = bufD[ri * 4 + ci];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                double d = m[jj][jj];
+#pragma unroll
+                for (int k = 0; k < jj; ++k) d = fma(-l[jj][k], l[jj][k], d);
+                if (!(d > 0.0) && bad == 0 && 4 * tjj + jj < nb) bad = 4 * tjj + jj + 1;
+                inv[jj] = rsqrt(d);
+                l[jj][jj] = d * inv[jj];
+#pragma unroll
+                for (int ii = jj + 1; ii < 4; ++ii) {
+                    double v = m[ii][jj];
+#pragma unroll
+                    for (int k = 0; k < jj; ++k) v = fma(-l[ii][k], l[jj][k], v);
+                    l[ii][jj] = v * inv[jj];
                 }
-                if (tj > tjj) {
+            }
+            if (ti == tjj) {
 #pragma unroll
-                    for (int ri = 0; ri < 4; ++ri)
+                for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                        for (int ci = 0; ci < 4; ++ci) a[ri][ci] = fma(-li[ri], lc[ci], a[ri][ci]);
-                } else {
+                    for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
+            } else {
+                // X l' = A  (4x4, row by row)
 #pragma unroll
-                    for (int ri = 0; ri < 4; ++ri) {
+                for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                        for (int ci = jj + 1; ci < 4; ++ci) a[ri][ci] = fma(-li[ri], lc[ci], a[ri][ci]);
-                        const int row = 4 * ti + ri;
-                        a[ri][jj] = (row == j) ? sq : li[ri];
+                    for (int jj = 0; jj < 4; ++jj) {
+                        double v = a[ri][jj];
+#pragma unroll
+                        for (int k = 0; k < jj; ++k) v = fma(-a[ri][k], l[jj][k], v);
+                        a[ri][jj] = v * inv[jj];
                     }
-                }
             }
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) bufP[(4 * ti + ri) * 5 + ci] = a[ri][ci];
+        }
+        __syncthreads();
+        if (lower && tj > tjj) {
+            double li[4][4], lc[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    li[q][k] = bufP[(4 * ti + q) * 5 + k];
+                    lc[q][k] = bufP[(4 * tj + q) * 5 + k];
+                }
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[ri][ci] = fma(-li[ri][k], lc[ci][k], a[ri][ci]);
         }
     }
 }
@@ -208,6 +245,7 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double (*colbuf)
 static constexpr int kKC = 16;        // k extent of one staged operand chunk
 static constexpr int kLdK = kKC + 1;  // padded row length of a staged chunk (bank-conflict free)
 static constexpr int kPass = 128;     // update entries evaluated per pass
+static constexpr int kInFlight = 6;   // chunks of the stream in flight per thread (registers)
 
 // One workgroup per 64x64 tile of a panel.  The update stream of the tile -- every
 // (descendant, 16-wide k chunk) pair that touches it, in update order -- is pumped through
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             int* __restrict__ flags, int epoch,
                                                             int fused) {
     __shared__ double T[4][kSub * kLdSub];
-    __shared__ double colbuf[2][kTile];
+    __shared__ double colbuf[kPotrfScratch];
     __shared__ double stage[4][kTile * kLdK];  // A stages 0,1 and B stages 2,3 (reused by the TRSM)
     __shared__ int32_t s_ok;
     double (*As)[kTile * kLdK] = stage;
@@ -485,11 +523,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 
         // ---- pump: chunk p is multiplied from stage p & 1 while chunk p+1 is written to the
         // other stage and chunks p+2, p+3 are in flight in registers
-        Chunk q0, q1, q2;
-        issue(q0);
-        issue(q1);
-        issue(q2);
-        store(q0, 0);
+        Chunk q[kInFlight];
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i) issue(q[i]);
+        store(q[0], 0);
         __syncthreads();
         int p = 0;
 #ifdef PARSY_STAMPS
@@ -498,15 +535,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 #else
 #define PH(a, b, c, d) do { a; b; c; d; } while (0)
 #endif
-        while (ce_ < cnt) {
-            PH(store(q1, (p + 1) & 1), issue(q0), consume(p & 1), __syncthreads());
-            ++p;
-            if (ce_ >= cnt) break;
-            PH(store(q2, (p + 1) & 1), issue(q1), consume(p & 1), __syncthreads());
-            ++p;
-            if (ce_ >= cnt) break;
-            PH(store(q0, (p + 1) & 1), issue(q2), consume(p & 1), __syncthreads());
-            ++p;
+        // iteration p: chunk p+1 (registers -> other stage), a new chunk p+kInFlight is issued
+        // into the registers chunk p occupied, chunk p is multiplied
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int sidx = 0; sidx < kInFlight; ++sidx) {
+                if (!more) break;
+                PH(store(q[(sidx + 1) % kInFlight], (p + 1) & 1), issue(q[sidx]), consume(p & 1), __syncthreads());
+                ++p;
+                more = ce_ < cnt;
+            }
         }
 #ifdef PARSY_STAMPS
         if (!INNER && stamp_wg && tid == 0) {
@@ -558,7 +597,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         STAMP(11);
         potrf64_regs(a, colbuf, ti, tj, nb, bad);
         STAMP(12);
-        if (tid == 0 && bad) atomicMin(info, D.c0 + td.col0 + bad);
+        if (bad) atomicMin(info, D.c0 + td.col0 + bad);  // only threads that saw a bad pivot
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -612,7 +651,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     if (td.row0 == td.col0 + kTile) STAMP(25);
     // ---- X := B inv(Ljj') on the rows of the LDS tile
     double* __restrict__ Dg = &stage[0][0];  // 64 x 65 doubles, the update stream is finished
-    double* __restrict__ invd = colbuf[0];
+    double* __restrict__ invd = colbuf;
     {
         double dtmp[kTile * kTile / kThreads];
 #pragma unroll
