@@ -147,7 +147,11 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
             case kLaunchFixup: launch_chol_fixup(pl->dp, l.first, l.count, L, stream); break;
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
-                launch_solve_panel(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, stream);
+                if (l.fused)
+                    launch_solve_chain(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, pl->epoch,
+                                       stream);
+                else
+                    launch_solve_panel(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, stream);
                 break;
             case kLaunchSolveFixup:
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
@@ -208,7 +212,11 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         return -1;
     }
     const int64_t need = (int64_t)ldx * nrhs;
-    if (!pl->S.solve_fix_list.empty() && pl->xscratch_len < need) {
+    // one epoch per pass of right-hand sides (what the chain kernel publishes / waits for)
+    const int passes = (nrhs + 7) / 8;
+    if (pl->epoch > INT_MAX - 2 * passes - 2) pl->epoch = 0;
+    pl->epoch += 1;  // first pass uses this value; the kernel adds the pass index
+    if (pl->S.n_solve_wide > 0 && pl->xscratch_len < need) {
         // grows only when a larger right-hand-side block shows up (not per call)
         if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
         pl->xscratch = nullptr;
@@ -219,6 +227,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+    pl->epoch += passes;
     pl->have_s = true;
     return 0;
 }

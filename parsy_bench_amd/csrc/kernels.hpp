@@ -42,6 +42,8 @@ void launch_solve_small(const DevicePattern& P, int first, int count, const doub
                         int nrhs, int ldx, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
+void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, double* x,
+                        double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

@@ -173,6 +173,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve_panels.clear();
     S.solve_fix_list.clear();
     S.solve.clear();
+    S.n_solve_wide = 0;
 
     std::vector<int> bigs, sbigs;
     for (int lev = 0; lev < S.nlevels; ++lev) {
@@ -282,22 +283,35 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (L.count > 0) S.solve.push_back(L);
         }
         if (!sbigs.empty()) {
-            int maxnb = 0;
-            for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
-            for (int jb = 0; jb < maxnb; ++jb) {
-                Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0, 0};
-                for (int t : sbigs) {
-                    const SnDesc& T = S.sn[t];
-                    if (ceil_div(T.w, kTile) <= jb) continue;
-                    const int wb = std::min(kTile, T.w - jb * kTile);
-                    S.solve_panels.push_back(PanelDesc{t, jb, -1, 0});
-                    for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kSolveRows)
-                        S.solve_panels.push_back(PanelDesc{t, jb, row0, 0});
+            S.n_solve_wide += (int)sbigs.size();
+            int chain_wgs = 0;
+            for (int t : sbigs) chain_wgs += ceil_div(S.sn[t].r, kSolveRows);
+            if (chain_wgs <= kMaxChainWorkgroups) {
+                // one launch: every 256-row chunk of every wide supernode of the level
+                Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, 0, 0, 1};
+                for (int t : sbigs)
+                    for (int c = 0; c * kSolveRows < S.sn[t].r; ++c)
+                        S.solve_panels.push_back(PanelDesc{t, c, c * kSolveRows, 0});
+                Lc.count = (int32_t)S.solve_panels.size() - Lc.first;
+                S.solve.push_back(Lc);
+            } else {
+                int maxnb = 0;
+                for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
+                for (int jb = 0; jb < maxnb; ++jb) {
+                    Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0, 0};
+                    for (int t : sbigs) {
+                        const SnDesc& T = S.sn[t];
+                        if (ceil_div(T.w, kTile) <= jb) continue;
+                        const int wb = std::min(kTile, T.w - jb * kTile);
+                        S.solve_panels.push_back(PanelDesc{t, jb, -1, 0});
+                        for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kSolveRows)
+                            S.solve_panels.push_back(PanelDesc{t, jb, row0, 0});
+                    }
+                    Lp.count = (int32_t)S.solve_panels.size() - Lp.first;
+                    S.solve.push_back(Lp);
                 }
-                Lp.count = (int32_t)S.solve_panels.size() - Lp.first;
-                S.solve.push_back(Lp);
+                S.solve_fix_list.insert(S.solve_fix_list.end(), sbigs.begin(), sbigs.end());
             }
-            S.solve_fix_list.insert(S.solve_fix_list.end(), sbigs.begin(), sbigs.end());
         }
     }
     if (!S.solve_fix_list.empty())

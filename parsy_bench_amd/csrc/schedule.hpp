@@ -97,12 +97,14 @@ struct Launch {
 // slots while they wait; keeping them well below the 2 x 256 slots of the tile kernel
 // guarantees that the workgroup they wait for is always dispatched.
 constexpr int kMaxWaitingTiles = 320;
+constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
     int n = 0, nsuper = 0, nlevels = 0;
     bool solve_only = false;       // built without A / update lists: only the solve launches exist
     int64_t nnzA = 0, ssize = 0, xsize = 0, nnzL = 0;
     int max_width = 0, max_rows = 0, n_small = 0, n_big = 0;
+    int n_solve_wide = 0;          // supernodes wider than a tile (solve: block-column chain)
     int64_t n_dslots = 0;          // parked diagonal blocks (64*64 doubles each)
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;
     double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)

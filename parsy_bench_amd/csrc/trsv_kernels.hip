@@ -228,6 +228,146 @@ void launch_solve_panel(const DevicePattern& P, int first, int count, const doub
                        P.solve_panels + first, P.rows, L, x, xscratch, nrhs, ldx);
 }
 
+// SOLVE_CHAIN: the whole block-column chain of a wide supernode in ONE launch.  Workgroup c
+// owns rows [256c, 256c+256) of the panel and keeps the running update of its rows in
+// registers (pull form: no atomics inside the supernode).  For block column jb the owner of
+// rows [64jb, 64jb+64) solves the diagonal block on its up-to-date rows and publishes x_jb
+// (agent-scope release + flag, cdna_hip_programming.md Guideline 16); workgroups with rows
+// below wait for the flag (bounded), read x_jb and update their rows.  Rows below the
+// supernode's own columns are scattered once, at the end, with atomics (other supernodes of
+// the level update the same ancestor rows).  All workgroups of a launch are resident at
+// once (the host caps their number), so the waits cannot starve the workgroup they wait for.
+__global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restrict__ sn,
+                                                          const PanelDesc* __restrict__ pds,
+                                                          const int32_t* __restrict__ rows,
+                                                          const double* __restrict__ L,
+                                                          double* __restrict__ x,
+                                                          double* __restrict__ xscratch, int nrhs,
+                                                          int ldx, int* __restrict__ flags, int epoch0,
+                                                          int* __restrict__ info) {
+    __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
+    __shared__ double xs[kTile][kRhs];
+    __shared__ int32_t s_ok;
+    const int tid = threadIdx.x;
+    const PanelDesc pd = pds[blockIdx.x];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w, chunk = pd.jb, row0 = pd.row0;
+    const int nbc = (w + kTile - 1) / kTile;
+    const double* __restrict__ G = L + D.px;
+    const int k = row0 + tid;          // this thread's panel row
+    const bool kv = k < r;
+    const bool kdiag = kv && k < w;    // row inside the supernode's own columns
+    int pass = 0;
+    for (int q0 = 0; q0 < nrhs; q0 += kRhs, ++pass) {
+        const int nq = min(kRhs, nrhs - q0);
+        const int epoch = epoch0 + pass;
+        double xv[kRhs], acc[kRhs];
+#pragma unroll
+        for (int q = 0; q < kRhs; ++q) {
+            acc[q] = 0.0;
+            xv[q] = (kdiag && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + k] : 0.0;
+        }
+        for (int jb = 0; jb < nbc; ++jb) {
+            const int cb = jb * kTile, wbk = min(kTile, w - cb);
+            const int owner = cb / kSolveRows;
+            if (chunk < owner) break;  // no rows at or below this block column
+            __syncthreads();           // xs / Dg of the previous block column are free
+            if (chunk == owner) {
+                // diagonal block (identity padded) -> LDS, up-to-date rows of the block -> xs
+                {
+                    double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+                    for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+                        const int e = t * kThreads + tid;
+                        const int c = e >> 6, i = e & 63;
+                        double v = (i == c) ? 1.0 : 0.0;
+                        if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+                        dtmp[t] = v;
+                    }
+#pragma unroll
+                    for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+                        const int e = t * kThreads + tid;
+                        Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+                    }
+                }
+                const int lr = k - cb;  // row inside the block (0..63) for the 64 threads that hold it
+                if (lr >= 0 && lr < kTile) {
+#pragma unroll
+                    for (int q = 0; q < kRhs; ++q) xs[lr][q] = (lr < wbk) ? xv[q] - acc[q] : 0.0;
+                }
+                __syncthreads();
+                block_solve_inv16(Dg, invd, xs, wbk, nq, tid);
+                // publish x_jb.  The hand-off payload is small, so it travels as 8-byte agent-scope
+                // atomics on both sides (a valid form of Guideline 16 that needs neither the L2
+                // write-back of a release fence nor the L1 invalidate of an acquire); x itself gets
+                // the final value with plain stores (nobody reads it inside this launch).
+                for (int e = tid; e < wbk * nq; e += kThreads) {
+                    const int q = e / wbk, c = e - q * wbk;
+                    const double v = xs[c][q];
+                    __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], v, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = v;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(&flags[D.dslot + jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    int ok = 1;
+                    // epochs only grow: a later pass of this solve may already have raised the flag
+                    while (__hip_atomic_load(&flags[D.dslot + jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
+                        if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
+                            ok = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    s_ok = ok;
+                }
+                __syncthreads();
+                if (!s_ok) {
+                    if (tid == 0) atomicMin(info, -1);
+                    return;
+                }
+                for (int e = tid; e < kTile * nq; e += kThreads) {
+                    const int q = e >> 6, c = e & 63;
+                    xs[c][q] = (c < wbk) ? __hip_atomic_load(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c],
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0.0;
+                }
+                __syncthreads();
+            }
+            // rows strictly below the diagonal block: acc += L[k, cb..cb+wbk) x_jb
+            // (all 64 loads of the row in flight at once: one memory latency per block column)
+            if (kv && k >= cb + wbk) {
+                double lv[kTile];
+#pragma unroll
+                for (int c = 0; c < kTile; ++c) lv[c] = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+#pragma unroll
+                for (int c = 0; c < kTile; ++c)
+#pragma unroll
+                    for (int q = 0; q < kRhs; ++q) acc[q] = fma(lv[c], xs[c][q], acc[q]);
+            }
+        }
+        if (kv && !kdiag) {
+            const int row = rows[D.pi + k];
+#pragma unroll
+            for (int q = 0; q < kRhs; ++q)
+                if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + row], -acc[q]);
+        }
+    }
+}
+
+void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, double* x,
+                        double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_solve_chain, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
+                       P.rows, L, x, xscratch, nrhs, ldx, P.flags, epoch0, P.info);
+}
+
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.
 __global__ __launch_bounds__(kThreads) void k_solve_fixup(const SnDesc* __restrict__ sn,
                                                           const int32_t* __restrict__ list,
