@@ -44,6 +44,7 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
+    if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
     return 0;
 }
 
@@ -107,6 +108,7 @@ void plan_free(parsy_plan* pl) {
         for (void* d : pl->owned) (void)hipFree(d);
         for (void* d : pl->launch_owned) (void)hipFree(d);
         if (pl->xscratch) (void)hipFree(pl->xscratch);
+        if (pl->dinv) (void)hipFree(pl->dinv);
         if (pl->h_values_dev) (void)hipFree(pl->h_values_dev);
         if (pl->h_L_dev) (void)hipFree(pl->h_L_dev);
         if (pl->h_x_dev) (void)hipFree(pl->h_x_dev);
@@ -148,8 +150,8 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused)
-                    launch_solve_chain(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, pl->epoch,
-                                       stream);
+                    launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
+                                       pl->epoch, stream);
                 else
                     launch_solve_panel(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, stream);
                 break;
@@ -223,7 +225,14 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
         pl->xscratch_len = need;
     }
+    if (!pl->S.solve_wide_list.empty() && !pl->dinv) {
+        const size_t bytes = (size_t)std::max<int64_t>(pl->S.n_dslots, 1) * kTile * kTile * sizeof(double);
+        PARSY_HIP(hipMalloc((void**)&pl->dinv, bytes));
+        pl->device_bytes += (int64_t)bytes;
+    }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+    launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size(), pl->S.solve_wide_max_blocks, d_L, pl->dinv,
+                        stream);
     run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -21,6 +21,7 @@ struct parsy_plan {
     int64_t device_bytes = 0;
     int epoch = 0;            // factorization counter (value the fused launches publish / wait for)
 
+    double* dinv = nullptr;       // inverse 64x64 diagonal blocks of the wide supernodes (solve)
     double* xscratch = nullptr;
     int64_t xscratch_len = 0;
 

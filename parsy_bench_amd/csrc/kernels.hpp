@@ -23,6 +23,7 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
+    const int32_t* solve_wide_list = nullptr;  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
     double* dscratch = nullptr;  // parked 64x64 diagonal blocks
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // per parked diagonal block: epoch of the factorization that parked it
@@ -42,8 +43,10 @@ void launch_solve_small(const DevicePattern& P, int first, int count, const doub
                         int nrhs, int ldx, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
-void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, double* x,
-                        double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
+void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
+void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
+                         hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

@@ -172,6 +172,8 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve_small_list.clear();
     S.solve_panels.clear();
     S.solve_fix_list.clear();
+    S.solve_wide_list.clear();
+    S.solve_wide_max_blocks = 0;
     S.solve.clear();
     S.n_solve_wide = 0;
 
@@ -294,6 +296,10 @@ void build_launches(Schedule& S, const uint8_t* active) {
                         S.solve_panels.push_back(PanelDesc{t, c, c * kSolveRows, 0});
                 Lc.count = (int32_t)S.solve_panels.size() - Lc.first;
                 S.solve.push_back(Lc);
+                for (int t : sbigs) {
+                    S.solve_wide_list.push_back(t);
+                    S.solve_wide_max_blocks = std::max(S.solve_wide_max_blocks, ceil_div(S.sn[t].w, kTile));
+                }
             } else {
                 int maxnb = 0;
                 for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));

@@ -127,7 +127,9 @@ struct Schedule {
     // solve launch data
     std::vector<int32_t> solve_small_list;
     std::vector<PanelDesc> solve_panels;
-    std::vector<int32_t> solve_fix_list;  // all big-for-solve supernodes
+    std::vector<int32_t> solve_fix_list;  // wide supernodes solved by per-block-column launches
+    std::vector<int32_t> solve_wide_list; // wide supernodes solved by SOLVE_CHAIN
+    int solve_wide_max_blocks = 0;
     std::vector<Launch> solve;
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches

@@ -228,26 +228,74 @@ void launch_solve_panel(const DevicePattern& P, int first, int count, const doub
                        P.solve_panels + first, P.rows, L, x, xscratch, nrhs, ldx);
 }
 
+// DIAG_INVERSE: explicit inverses of the 64x64 diagonal blocks of the wide supernodes, one
+// 64-thread workgroup per block, one column per thread (forward substitution of L y = e_c).
+// Run once at the start of a solve; SOLVE_CHAIN then replaces the sequential 64-step
+// substitution on its critical path by a 64x64 matrix-vector product.  dinv holds one
+// column-major 64x64 lower-triangular block per scratch slot (identity padded).
+__global__ __launch_bounds__(64) void k_diag_inverse(const SnDesc* __restrict__ sn,
+                                                     const int32_t* __restrict__ list,
+                                                     const double* __restrict__ L,
+                                                     double* __restrict__ dinv) {
+    __shared__ double Dg[kTile * kLdDiag];
+    const SnDesc D = sn[list[blockIdx.x]];
+    const int jb = blockIdx.y, c = threadIdx.x;
+    const int r = D.r, cb = jb * kTile, wbk = min(kTile, D.w - cb);
+    if (cb >= D.w) return;
+    const double* __restrict__ G = L + D.px;
+    for (int e = c; e < kTile * kTile; e += 64) {
+        const int cc = e >> 6, i = e & 63;
+        double v = (i == cc) ? 1.0 : 0.0;
+        if (cc < wbk && i < wbk && i >= cc) v = G[(int64_t)(cb + cc) * r + cb + i];
+        Dg[cc * kLdDiag + i] = v;
+    }
+    __syncthreads();
+    // column c of the inverse: y[c] = 1/l_cc, y[i] = -(sum_{k=c}^{i-1} L[i][k] y[k]) / l_ii
+    double y[kTile];
+#pragma unroll
+    for (int i = 0; i < kTile; ++i) y[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < kTile; ++i) {
+        double sacc = (i == c) ? -1.0 : 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < i; ++k2) sacc = fma(Dg[k2 * kLdDiag + i], y[k2], sacc);
+        y[i] = (i >= c) ? -sacc / Dg[i * kLdDiag + i] : 0.0;
+    }
+    double* __restrict__ out = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile) + (int64_t)c * kTile;
+#pragma unroll
+    for (int i = 0; i < kTile; ++i) out[i] = y[i];
+}
+
+void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
+                         hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_diag_inverse, dim3(count, max_blocks), dim3(64), 0, stream, P.sn, P.solve_wide_list, L,
+                       dinv);
+}
+
 // SOLVE_CHAIN: the whole block-column chain of a wide supernode in ONE launch.  Workgroup c
 // owns rows [256c, 256c+256) of the panel and keeps the running update of its rows in
 // registers (pull form: no atomics inside the supernode).  For block column jb the owner of
-// rows [64jb, 64jb+64) solves the diagonal block on its up-to-date rows and publishes x_jb
-// (agent-scope release + flag, cdna_hip_programming.md Guideline 16); workgroups with rows
+// rows [64jb, 64jb+64) multiplies its up-to-date rows by the inverse diagonal block
+// (DIAG_INVERSE) and publishes x_jb as 8-byte agent-scope atomics + a flag
+// (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides"); workgroups with rows
 // below wait for the flag (bounded), read x_jb and update their rows.  Rows below the
 // supernode's own columns are scattered once, at the end, with atomics (other supernodes of
 // the level update the same ancestor rows).  All workgroups of a launch are resident at
 // once (the host caps their number), so the waits cannot starve the workgroup they wait for.
+template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restrict__ sn,
                                                           const PanelDesc* __restrict__ pds,
                                                           const int32_t* __restrict__ rows,
                                                           const double* __restrict__ L,
+                                                          const double* __restrict__ dinv,
                                                           double* __restrict__ x,
                                                           double* __restrict__ xscratch, int nrhs,
                                                           int ldx, int* __restrict__ flags, int epoch0,
                                                           int* __restrict__ info) {
-    __shared__ double Dg[kTile * kLdDiag];
-    __shared__ double invd[kTile];
-    __shared__ double xs[kTile][kRhs];
+    __shared__ double Di[2][kTile * kLdDiag];  // inverse diagonal blocks, double buffered
+    __shared__ double xs[kTile][NQ];
+    __shared__ double ts[kTile][NQ];
     __shared__ int32_t s_ok;
     const int tid = threadIdx.x;
     const PanelDesc pd = pds[blockIdx.x];
@@ -258,50 +306,60 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
     const int k = row0 + tid;          // this thread's panel row
     const bool kv = k < r;
     const bool kdiag = kv && k < w;    // row inside the supernode's own columns
-    int pass = 0;
-    for (int q0 = 0; q0 < nrhs; q0 += kRhs, ++pass) {
-        const int nq = min(kRhs, nrhs - q0);
-        const int epoch = epoch0 + pass;
-        double xv[kRhs], acc[kRhs];
+    // block columns whose diagonal block this workgroup owns: [jb_first, jb_last)
+    const int jb_first = row0 / kTile, jb_last = min(nbc, (row0 + kSolveRows) / kTile);
+    auto load_inv = [&](int jb, double (&regs)[kTile * kTile / kThreads]) {
+        const double* __restrict__ src = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile);
 #pragma unroll
-        for (int q = 0; q < kRhs; ++q) {
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) regs[t] = src[t * kThreads + tid];
+    };
+    auto store_inv = [&](int buf, const double (&regs)[kTile * kTile / kThreads]) {
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            Di[buf][(e >> 6) * kLdDiag + (e & 63)] = regs[t];
+        }
+    };
+    int pass = 0;
+    for (int q0 = 0; q0 < nrhs; q0 += NQ, ++pass) {
+        const int nq = min(NQ, nrhs - q0);
+        const int epoch = epoch0 + pass;
+        double xv[NQ], acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
             acc[q] = 0.0;
             xv[q] = (kdiag && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + k] : 0.0;
+        }
+        double inv_regs[kTile * kTile / kThreads];
+        if (jb_first < jb_last) {
+            load_inv(jb_first, inv_regs);
+            store_inv(jb_first & 1, inv_regs);
         }
         for (int jb = 0; jb < nbc; ++jb) {
             const int cb = jb * kTile, wbk = min(kTile, w - cb);
             const int owner = cb / kSolveRows;
             if (chunk < owner) break;  // no rows at or below this block column
-            __syncthreads();           // xs / Dg of the previous block column are free
+            __syncthreads();           // xs / ts of the previous block column are free
             if (chunk == owner) {
-                // diagonal block (identity padded) -> LDS, up-to-date rows of the block -> xs
-                {
-                    double dtmp[kTile * kTile / kThreads];
-#pragma unroll
-                    for (int t = 0; t < kTile * kTile / kThreads; ++t) {
-                        const int e = t * kThreads + tid;
-                        const int c = e >> 6, i = e & 63;
-                        double v = (i == c) ? 1.0 : 0.0;
-                        if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
-                        dtmp[t] = v;
-                    }
-#pragma unroll
-                    for (int t = 0; t < kTile * kTile / kThreads; ++t) {
-                        const int e = t * kThreads + tid;
-                        Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
-                    }
-                }
-                const int lr = k - cb;  // row inside the block (0..63) for the 64 threads that hold it
+                const int lr = k - cb;  // row inside the block for the 64 threads that hold it
                 if (lr >= 0 && lr < kTile) {
 #pragma unroll
-                    for (int q = 0; q < kRhs; ++q) xs[lr][q] = (lr < wbk) ? xv[q] - acc[q] : 0.0;
+                    for (int q = 0; q < NQ; ++q) ts[lr][q] = (lr < wbk) ? xv[q] - acc[q] : 0.0;
                 }
                 __syncthreads();
-                block_solve_inv16(Dg, invd, xs, wbk, nq, tid);
-                // publish x_jb.  The hand-off payload is small, so it travels as 8-byte agent-scope
-                // atomics on both sides (a valid form of Guideline 16 that needs neither the L2
-                // write-back of a release fence nor the L1 invalidate of an acquire); x itself gets
-                // the final value with plain stores (nobody reads it inside this launch).
+                // x_jb = inv(Ljj) t : thread (i, q-slice); the next owned inverse is fetched meanwhile
+                const bool next_owned = jb + 1 < jb_last;
+                if (next_owned) load_inv(jb + 1, inv_regs);
+                {
+                    const double* __restrict__ Dv = Di[jb & 1];
+                    for (int e = tid; e < kTile * nq; e += kThreads) {
+                        const int i = e & 63, q = e >> 6;
+                        double sacc = 0.0;
+                        for (int k2 = 0; k2 <= i; ++k2) sacc = fma(Dv[k2 * kLdDiag + i], ts[k2][q], sacc);
+                        xs[i][q] = sacc;
+                    }
+                }
+                __syncthreads();
                 for (int e = tid; e < wbk * nq; e += kThreads) {
                     const int q = e / wbk, c = e - q * wbk;
                     const double v = xs[c][q];
@@ -313,6 +371,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
                 __syncthreads();
                 if (tid == 0)
                     __hip_atomic_store(&flags[D.dslot + jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (next_owned) store_inv((jb + 1) & 1, inv_regs);
             } else {
                 if (tid == 0) {
                     const unsigned long long t0 = wall_clock64();
@@ -349,23 +408,28 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
 #pragma unroll
                 for (int c = 0; c < kTile; ++c)
 #pragma unroll
-                    for (int q = 0; q < kRhs; ++q) acc[q] = fma(lv[c], xs[c][q], acc[q]);
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv[c], xs[c][q], acc[q]);
             }
         }
         if (kv && !kdiag) {
             const int row = rows[D.pi + k];
 #pragma unroll
-            for (int q = 0; q < kRhs; ++q)
+            for (int q = 0; q < NQ; ++q)
                 if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + row], -acc[q]);
         }
     }
 }
 
-void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, double* x,
-                        double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream) {
+void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_solve_chain, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
-                       P.rows, L, x, xscratch, nrhs, ldx, P.flags, epoch0, P.info);
+    if (nrhs == 1)
+        hipLaunchKernelGGL(k_solve_chain<1>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
+                           P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.info);
+    else
+        hipLaunchKernelGGL(k_solve_chain<kRhs>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+                           P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0,
+                           P.info);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.
