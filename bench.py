@@ -99,11 +99,19 @@ def main():
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the executor has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; a rehearsal with more ranks than GPUs (PARSY_DIST_BACKEND=gloo) shares devices
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("PARSY_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    local_rank = dev_index
 
     from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
 
@@ -138,7 +146,7 @@ def main():
     def factor_step():
         plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
         if world > 1:
-            MG.gather_to_root(L, cut, sym, rank, dist)
+            MG.gather_to_root(L, cut, sym, rank, dist, stage_on_host=(backend != "nccl"))
             if rank == 0:
                 plan_root.factor_device(values.data_ptr(), L.data_ptr(), stream, init=False)
 
@@ -157,7 +165,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt

@@ -98,20 +98,26 @@ def cut_subtrees(sym, nranks: int, oversub: int = 4) -> SubtreeCut:
                       cost=cost, rank_cost=rank_cost)
 
 
-def gather_to_root(lvalues, cut: SubtreeCut, sym, rank: int, dist, root: int = 0):
+def gather_to_root(lvalues, cut: SubtreeCut, sym, rank: int, dist, root: int = 0, stage_on_host: bool = False):
     """The one exchange step: every subtree slice of lValues travels from its owner to `root`
     (point-to-point, all owners concurrently -- with RCCL each pair uses its own xGMI link).
-    `lvalues` is a 1-D torch tensor (device for nccl, CPU for gloo) of xsize doubles."""
-    ops = []
+    `lvalues` is a 1-D torch tensor of xsize doubles (device memory with nccl; with
+    `stage_on_host` -- gloo rehearsals -- device slices are bounced through host copies)."""
+    ops, landing = [], []
     for owner, start, stop in cut.slices(sym):
         if owner == root or stop <= start:
             continue
         view = lvalues[start:stop]
         if rank == root:
-            ops.append(dist.P2POp(dist.irecv, view, owner))
+            buf = view.cpu() if stage_on_host else view
+            if stage_on_host:
+                landing.append((view, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, owner))
         elif rank == owner:
-            ops.append(dist.P2POp(dist.isend, view, root))
+            ops.append(dist.P2POp(dist.isend, view.cpu() if stage_on_host else view, root))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    for view, buf in landing:
+        view.copy_(buf)
     return sum(stop - start for owner, start, stop in cut.slices(sym) if owner != root)
