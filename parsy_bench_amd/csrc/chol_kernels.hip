@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             double* __restrict__ dscratch,
                                                             int* __restrict__ info,
                                                             int* __restrict__ flags, int epoch,
-                                                            int fused) {
+                                                            int fused, int finalize) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[kPotrfScratch];
     __shared__ double stage[4][kTile * kLdK];  // A stages 0,1 and B stages 2,3 (reused by the TRSM)
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     // tile is factored on the spot and parked in a scratch slot (FIXUP copies it into the
     // panel); in a fused launch the tiles below it wait for that block and do their TRSM
     // straight out of LDS, otherwise PANEL does it in the next launch.
-    const bool col_final = INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0;
+    const bool col_final = finalize && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
     const bool diag_tile = td.row0 == td.col0;
     const bool trsm_here = fused && col_final && !diag_tile;
     auto write_back = [&](int min_row) {  // min_row: first row of the TILE that is written
@@ -733,16 +733,16 @@ extern "C" void parsy_debug_stamps(unsigned long long* out) {
 #endif
 
 void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
-                       int epoch, double* L, hipStream_t stream) {
+                       int finalize, int epoch, double* L, hipStream_t stream) {
     if (count <= 0) return;
     if (inner)
         hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
                            P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
-                           fused);
+                           fused, finalize);
     else
         hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
                            P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
-                           fused);
+                           fused, finalize);
 }
 
 // ---------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #include "executor.hpp"
 
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -74,6 +75,16 @@ static int plan_upload(parsy_plan* pl) {
         pl->dp.flags = (int*)d;
         PARSY_HIP(hipMemset(d, 0, fbytes));
     }
+    PARSY_HIP(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
+    PARSY_HIP(hipEventCreateWithFlags(&pl->ev_init, hipEventDisableTiming));
+    pl->ev_level_done.resize(S.nlevels + 1);
+    pl->ev_early_done.resize(S.nlevels + 1);
+    for (auto& e : pl->ev_level_done) PARSY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : pl->ev_early_done) PARSY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {
+        const char* no = std::getenv("PARSY_NO_OVERLAP");
+        pl->overlap = !(no && no[0] == '1');
+    }
     PARSY_HIP(hipEventCreate(&pl->ev_f0));
     PARSY_HIP(hipEventCreate(&pl->ev_f1));
     PARSY_HIP(hipEventCreate(&pl->ev_s0));
@@ -115,6 +126,10 @@ void plan_free(parsy_plan* pl) {
         for (hipEvent_t e : {pl->ev_f0, pl->ev_f1, pl->ev_s0, pl->ev_s1})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : pl->pev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : pl->ev_level_done) (void)hipEventDestroy(e);
+        for (hipEvent_t e : pl->ev_early_done) (void)hipEventDestroy(e);
+        if (pl->ev_init) (void)hipEventDestroy(pl->ev_init);
+        if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
     }
     delete pl;
 }
@@ -135,15 +150,42 @@ static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& c
 static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double* L, const double* Lc,
                          double* x, int nrhs, int ldx, hipStream_t stream) {
     size_t cursor = 0;
+    // TILES_EARLY launches go to the side stream (unless profiling / disabled): they wait for the
+    // completion event of the level two below their targets and run beside the main stream's
+    // block-column chain; the matching TILES (late) launch waits for them.
+    const bool overlap = pl->overlap && !pl->profile && pl->side_stream != nullptr;
+    int next_level_event = 0;  // ev_level_done[k] recorded for all k < next_level_event
+    std::vector<char> early_seen(pl->ev_early_done.size(), 0);
+    auto record_levels_below = [&](int level) {
+        for (; next_level_event < level && next_level_event < (int)pl->ev_level_done.size(); ++next_level_event)
+            (void)hipEventRecord(pl->ev_level_done[next_level_event], stream);
+    };
     for (const Launch& l : seq) {
+        const bool on_side = overlap && l.side;
+        if (!on_side) {
+            // everything enqueued so far on the main stream belongs to levels < l.level
+            if (overlap && l.kind <= kLaunchFixup) record_levels_below(l.level);
+            if (overlap && l.kind == kLaunchTiles && !l.early && early_seen[l.level])
+                (void)hipStreamWaitEvent(stream, pl->ev_early_done[l.level], 0);
+        }
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, L, stream); break;
             case kLaunchTiles:
-                launch_chol_tiles(pl->dp, l.first, l.count, false, 0, l.fused, pl->epoch, L, stream);
+                if (on_side) {
+                    record_levels_below(l.wait_level + 1);
+                    (void)hipStreamWaitEvent(pl->side_stream,
+                                             l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
+                    launch_chol_tiles(pl->dp, l.first, l.count, false, 0, 0, 0, pl->epoch, L, pl->side_stream);
+                    (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
+                    early_seen[l.level] = 1;
+                } else {
+                    launch_chol_tiles(pl->dp, l.first, l.count, false, 0, l.fused, l.early ? 0 : 1, pl->epoch, L,
+                                      stream);
+                }
                 break;
             case kLaunchInner:
-                launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, l.fused, pl->epoch, L, stream);
+                launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, l.fused, 1, pl->epoch, L, stream);
                 break;
             case kLaunchPanel: launch_chol_panel(pl->dp, l.first, l.count, L, stream); break;
             case kLaunchFixup: launch_chol_fixup(pl->dp, l.first, l.count, L, stream); break;
@@ -196,6 +238,7 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
     // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)
     PARSY_HIP(hipMemsetAsync(pl->dp.info, 0x7f, sizeof(int), stream));
     if (init) launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
+    PARSY_HIP(hipEventRecord(pl->ev_init, stream));
     run_launches(pl, S.chol, d_L, d_L, nullptr, 0, 0, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_f1, stream));

@@ -31,6 +31,12 @@ struct parsy_plan {
     double* h_x_dev = nullptr;
     int64_t h_x_len = 0;
 
+    // side stream of the TILES_EARLY launches + the events that order it against the main stream
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_init = nullptr;
+    std::vector<hipEvent_t> ev_level_done, ev_early_done;
+    bool overlap = true;      // PARSY_NO_OVERLAP=1 (or profiling) runs everything on the caller's stream
+
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     bool have_f = false, have_s = false;
 

@@ -35,7 +35,7 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
                        hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
-                       int epoch, double* L, hipStream_t stream);
+                       int finalize, int epoch, double* L, hipStream_t stream);
 void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 

@@ -95,10 +95,17 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         }
     }
 
+    std::vector<int> tree(P.sparent, P.sparent + ns);
+    level_sets(tree, S.levelPtr, S.levelSet);
+    S.nlevels = (int)S.levelPtr.size() - 1;
+    S.level_of.assign(ns, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) S.level_of[S.levelSet[q]] = l;
+
     // --- tiled supernodes: scratch slots and per-block-column update lists ----------
     S.sn_cb0.assign(ns, -1);
     S.sn_tw0.assign(ns, -1);
-    std::vector<std::vector<ColBlkEntry>> bucket;
+    std::vector<std::vector<ColBlkEntry>> bucket;  // [2*J + phase]
     for (int t = 0; t < ns; ++t) {
         SnDesc& T = S.sn[t];
         if (is_small(T)) {
@@ -113,9 +120,11 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const double K = (double)jb * kTile, wb = std::min(kTile, T.w - jb * kTile);
             S.inner_flops += K * wb * (wb + 1) + 2.0 * K * (double)(T.r - jb * kTile - wb) * wb;
         }
-        bucket.assign(nbc, {});
+        bucket.assign(2 * nbc, {});
         for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
             const UpdDesc& U = S.upd[u];
+            // early: the descendant is complete before the level below the target even starts
+            const int phase = (S.level_of[usn[u]] <= S.level_of[t] - 2) ? 0 : 1;
             S.tile_update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
             const int32_t* rel = &S.relpos[U.rel];
             const int jfirst = rel[0] / kTile, jlast = rel[U.n1 - 1] / kTile;
@@ -125,38 +134,38 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                 e.jlo = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile) - rel);
                 e.jmid = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile + kSub) - rel);
                 e.jhi = (int32_t)(std::lower_bound(rel, rel + U.n1, (J + 1) * kTile) - rel);
-                if (e.jhi > e.jlo) bucket[J].push_back(e);
+                if (e.jhi > e.jlo) bucket[2 * J + phase].push_back(e);
             }
         }
         // weight of every tile = number of 16-wide k chunks of the updates that reach it
         const int nbr_t = ceil_div(T.r, kTile);
         S.sn_tw0[t] = (int64_t)S.tile_w.size();
-        S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr_t, 0);
+        S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr_t * 2, 0);
         int32_t* tw = &S.tile_w[S.sn_tw0[t]];
         for (int J = 0; J < nbc; ++J)
-            for (const ColBlkEntry& e : bucket[J]) {
-                const UpdDesc& U = S.upd[e.upd];
-                const int32_t* rel = &S.relpos[U.rel];
-                const int chunks = ceil_div(U.K, 16);
-                int last = -1;
-                for (int k = 0; k < U.m; ++k) {
-                    const int I = rel[k] / kTile;
-                    if (I != last && I >= J) tw[(size_t)J * nbr_t + I] += chunks;
-                    last = I;
+            for (int phase = 0; phase < 2; ++phase)
+                for (const ColBlkEntry& e : bucket[2 * J + phase]) {
+                    const UpdDesc& U = S.upd[e.upd];
+                    const int32_t* rel = &S.relpos[U.rel];
+                    const int chunks = ceil_div(U.K, 16);
+                    int last = -1;
+                    for (int k = 0; k < U.m; ++k) {
+                        const int I = rel[k] / kTile;
+                        if (I != last && I >= J) tw[((size_t)J * nbr_t + I) * 2 + phase] += chunks;
+                        last = I;
+                    }
                 }
-            }
+        // cb_ptr holds, per block column, [early begin, late begin] and one closing entry
         S.sn_cb0[t] = (int64_t)S.cb_ptr.size();
-        for (int J = 0; J < nbc; ++J) {
-            S.cb_ptr.push_back((int64_t)S.colblk.size());
-            S.colblk.insert(S.colblk.end(), bucket[J].begin(), bucket[J].end());
-        }
+        for (int J = 0; J < nbc; ++J)
+            for (int phase = 0; phase < 2; ++phase) {
+                S.cb_ptr.push_back((int64_t)S.colblk.size());
+                S.colblk.insert(S.colblk.end(), bucket[2 * J + phase].begin(), bucket[2 * J + phase].end());
+            }
         S.cb_ptr.push_back((int64_t)S.colblk.size());
     }
     if (S.colblk.size() > 0x7fffffffULL) throw std::runtime_error("schedule: block-column lists exceed int32");
 
-    std::vector<int> tree(P.sparent, P.sparent + ns);
-    level_sets(tree, S.levelPtr, S.levelSet);
-    S.nlevels = (int)S.levelPtr.size() - 1;
     build_launches(S, active);
 }
 
@@ -177,13 +186,18 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve.clear();
     S.n_solve_wide = 0;
 
+    // TILES_EARLY(lev) is enqueued right before level lev-1's launches, so that it runs on the side
+    // stream while the main stream works through that level's block-column chain.
+    std::vector<Launch> early_launches;
+    std::vector<size_t> level_begin;  // index in S.chol where each level's launches start
     std::vector<int> bigs, sbigs;
     for (int lev = 0; lev < S.nlevels; ++lev) {
+        level_begin.push_back(S.chol.size());
         bigs.clear();
         sbigs.clear();
         // ---- Cholesky -------------------------------------------------------------
         if (!S.solve_only) {
-            Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0};
+            Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t]) continue;
@@ -199,42 +213,55 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (L.count > 0) S.chol.push_back(L);
         }
         if (!S.solve_only && !bigs.empty()) {
-            // ---- TILES: external updates; block column 0 becomes final here -----------------
-            Launch L{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0, 0};
+            // ---- TILES: external updates; block column 0 becomes final in the LATE launch ------
+            Launch L{kLaunchTiles, 0, 0, lev, 0, 0, 0, 0, -1, 0};
             int maxnb = 0, waiting = 0;
             for (int t : bigs) waiting += ceil_div(S.sn[t].r, kTile) - 1;
             L.fused = waiting <= kMaxWaitingTiles;
-            std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
-            for (int t : bigs) {
-                const SnDesc& T = S.sn[t];
-                const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
-                maxnb = std::max(maxnb, nbc);
-                const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
-                for (int J = 0; J < nbc; ++J) {
-                    const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + J], c1 = S.cb_ptr[S.sn_cb0[t] + J + 1];
-                    for (int I = J; I < nbr; ++I) {
-                        const int32_t wgt = tw[(size_t)J * nbr + I];
-                        // tiles nothing reaches are skipped, except those of block column 0 that
-                        // must factor (diagonal) or solve (fused launch) their block
-                        const bool needed = wgt > 0 || (J == 0 && (I == 0 || L.fused));
-                        if (!needed) continue;
-                        const int32_t prio = (J == 0 && I == 0) ? INT32_MAX : wgt;  // diagonal first
-                        wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, (int32_t)c0,
-                                                     (int32_t)(wgt > 0 ? c1 : c0), 0}});
+            for (int phase = 0; phase < 2; ++phase) {
+                std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
+                for (int t : bigs) {
+                    const SnDesc& T = S.sn[t];
+                    const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+                    maxnb = std::max(maxnb, nbc);
+                    const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
+                    for (int J = 0; J < nbc; ++J) {
+                        const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + 2 * J + phase];
+                        const int64_t c1 = S.cb_ptr[S.sn_cb0[t] + 2 * J + phase + 1];
+                        for (int I = J; I < nbr; ++I) {
+                            const int32_t wgt = tw[((size_t)J * nbr + I) * 2 + phase];
+                            // tiles nothing reaches are skipped, except (late launch) those of block
+                            // column 0 that must factor (diagonal) or solve (fused launch) their block
+                            const bool needed = wgt > 0 || (phase == 1 && J == 0 && (I == 0 || L.fused));
+                            if (!needed) continue;
+                            const int32_t prio = (phase == 1 && J == 0 && I == 0) ? INT32_MAX : wgt;
+                            wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, (int32_t)c0,
+                                                         (int32_t)(wgt > 0 ? c1 : c0), 0}});
+                        }
                     }
                 }
+                // longest update streams first (a launch ends with its longest tile)
+                std::stable_sort(wt.begin(), wt.end(),
+                                 [](const auto& a, const auto& b) { return a.first > b.first; });
+                Launch Lt = L;
+                Lt.first = (int32_t)S.tiles.size();
+                for (auto& x : wt) S.tiles.push_back(x.second);
+                Lt.count = (int32_t)S.tiles.size() - Lt.first;
+                Lt.early = phase == 0;
+                Lt.side = phase == 0;
+                Lt.wait_level = lev - 2;  // early updates need every level up to lev-2 complete
+                if (phase == 0) Lt.fused = 0;
+                if (Lt.count > 0) {
+                    if (phase == 0) early_launches.push_back(Lt);
+                    else S.chol.push_back(Lt);
+                }
+                if (phase == 1) L.count = Lt.count;
             }
-            // longest update streams first (the launch ends with its longest tile)
-            std::stable_sort(wt.begin(), wt.end(),
-                             [](const auto& a, const auto& b) { return a.first > b.first; });
-            for (auto& x : wt) S.tiles.push_back(x.second);
-            L.count = (int32_t)S.tiles.size() - L.first;
-            if (L.count > 0) S.chol.push_back(L);
             bool prev_fused = L.fused && L.count > 0;
             for (int jb = 0; jb < maxnb; ++jb) {
                 // ---- PANEL(jb): only when the launch that finalised column jb was not fused ----
                 if (!prev_fused) {
-                    Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0, 0};
+                    Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0, 0, 0, -1, 0};
                     for (int t : bigs) {
                         const SnDesc& T = S.sn[t];
                         if (ceil_div(T.w, kTile) <= jb) continue;
@@ -247,7 +274,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 }
                 // ---- INNER(jb): right-looking update of everything right of block column jb;
                 // block column jb+1 becomes final
-                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0, 0};
+                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0, 0, 0, -1, 0};
                 int wait_i = 0;
                 for (int t : bigs) {
                     const SnDesc& T = S.sn[t];
@@ -268,13 +295,13 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 if (Li.count > 0) S.chol.push_back(Li);
                 prev_fused = Li.fused && Li.count > 0;
             }
-            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0, 0};
+            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0, 0, 0, -1, 0};
             S.fix_list.insert(S.fix_list.end(), bigs.begin(), bigs.end());
             S.chol.push_back(Lf);
         }
         // ---- forward solve ----------------------------------------------------------
         {
-            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0};
+            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t]) continue;
@@ -290,7 +317,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             for (int t : sbigs) chain_wgs += ceil_div(S.sn[t].r, kSolveRows);
             if (chain_wgs <= kMaxChainWorkgroups) {
                 // one launch: every 256-row chunk of every wide supernode of the level
-                Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, 0, 0, 1};
+                Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, 0, 0, 1, 0, -1, 0};
                 for (int t : sbigs)
                     for (int c = 0; c * kSolveRows < S.sn[t].r; ++c)
                         S.solve_panels.push_back(PanelDesc{t, c, c * kSolveRows, 0});
@@ -304,7 +331,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 int maxnb = 0;
                 for (int t : sbigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
                 for (int jb = 0; jb < maxnb; ++jb) {
-                    Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0, 0};
+                    Launch Lp{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, jb, 0, 0, 0, -1, 0};
                     for (int t : sbigs) {
                         const SnDesc& T = S.sn[t];
                         if (ceil_div(T.w, kTile) <= jb) continue;
@@ -320,8 +347,21 @@ void build_launches(Schedule& S, const uint8_t* active) {
             }
         }
     }
+    // splice the early launches in front of the level before their target level
+    if (!early_launches.empty()) {
+        std::vector<Launch> merged;
+        size_t e = 0;
+        std::sort(early_launches.begin(), early_launches.end(),
+                  [](const Launch& a, const Launch& b) { return a.level < b.level; });
+        for (int lev = 0; lev < S.nlevels; ++lev) {
+            while (e < early_launches.size() && early_launches[e].level - 1 <= lev) merged.push_back(early_launches[e++]);
+            const size_t b0 = level_begin[lev], b1 = lev + 1 < S.nlevels ? level_begin[lev + 1] : S.chol.size();
+            merged.insert(merged.end(), S.chol.begin() + b0, S.chol.begin() + b1);
+        }
+        S.chol.swap(merged);
+    }
     if (!S.solve_fix_list.empty())
-        S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0});
+        S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0, 0, -1, 0});
 }
 
 }  // namespace parsy

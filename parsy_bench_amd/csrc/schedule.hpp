@@ -8,7 +8,10 @@
 // Cholesky, one etree level (wavefront) at a time:
 //   SMALL   one workgroup per supernode whose panel (rows x width doubles) fits
 //           the LDS budget: assemble, apply every update, POTRF+TRSM, store.
-//   TILES   every other supernode is cut into 64x64 tiles of its panel (lower
+//   TILES   (split in two launches: updates from descendants at least two levels below the
+//           target run EARLY on a side stream, concurrently with the previous level's block
+//           column chain; the rest runs LATE on the main stream and finalises)
+//           every other supernode is cut into 64x64 tiles of its panel (lower
 //           trapezoid only); one workgroup per tile applies the external updates
 //           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).  The
 //           workgroup of the diagonal tile of block column 0 then factors that
@@ -91,6 +94,9 @@ struct Launch {
     int32_t lds_bytes;     // dynamic LDS (SMALL)
     int32_t fused;         // TILES / INNER: the workgroups of the block column that becomes final
                            // wait for its diagonal block and do the TRSM themselves (no PANEL launch)
+    int32_t side;          // 1: runs on the plan's side stream (TILES_EARLY), 0: main stream
+    int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only)
+    int32_t early;         // TILES only: 1 = the "early" half of the update lists, no finalisation
 };
 
 // Upper bound on workgroups that may wait inside one fused launch.  They occupy residency
@@ -137,7 +143,9 @@ struct Schedule {
     std::vector<int64_t> sn_cb0;       // per supernode: first index into cb_ptr (-1: SMALL)
     std::vector<int64_t> cb_ptr;       // ColBlkEntry ranges per (tiled supernode, block column)
     std::vector<int64_t> sn_tw0;       // per supernode: first index into tile_w (-1: SMALL)
-    std::vector<int32_t> tile_w;       // per (tiled supernode, J, I): 16-wide k chunks its update stream holds
+    std::vector<int32_t> tile_w;       // per (tiled supernode, J, I, phase): 16-wide k chunks of its update stream
+                                       // (phase 0 = early: descendants two or more levels below; 1 = late)
+    std::vector<int32_t> level_of;     // etree level of every supernode
 };
 
 // Build descriptors + launch lists. `active` (nsuper bytes or null = all) restricts
