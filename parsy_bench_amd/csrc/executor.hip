@@ -75,7 +75,12 @@ static int plan_upload(parsy_plan* pl) {
         pl->dp.flags = (int*)d;
         PARSY_HIP(hipMemset(d, 0, fbytes));
     }
-    PARSY_HIP(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
+    {
+        // lowest priority: the side stream only fills what the main stream's chain leaves idle
+        int prio_least = 0, prio_greatest = 0;
+        PARSY_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        PARSY_HIP(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, prio_least));
+    }
     PARSY_HIP(hipEventCreateWithFlags(&pl->ev_init, hipEventDisableTiming));
     pl->ev_level_done.resize(S.nlevels + 1);
     pl->ev_early_done.resize(S.nlevels + 1);
