@@ -53,40 +53,190 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 }
 
 // ---------------------------------------------------------------------------
-// SMALL: one workgroup per supernode, whole panel resident in LDS.
+// SMALL: one workgroup per supernode, whole panel resident in LDS.  The updates are a
+// stream of (descendant, k-slice) blocks -- the rows of the descendant from `lb` down, at
+// most kSmallStage doubles -- pumped through a double-buffered LDS stage by all threads
+// (coalesced along rows, two blocks in flight in registers) while the pair products of the
+// staged block are subtracted from the panel; one barrier per block, fixed order.
 // ---------------------------------------------------------------------------
+static constexpr int kSmallStage = 2048;                       // doubles per staged block
+static constexpr int kSmallPerThread = kSmallStage / kThreads;  // 8
+static constexpr int kSmallRelCap = 256;                       // rows of a descendant block staged with indices
+
 __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restrict__ sn,
                                                          const UpdDesc* __restrict__ upd,
                                                          const int32_t* __restrict__ relpos,
                                                          const int32_t* __restrict__ list,
                                                          double* __restrict__ L,
-                                                         int* __restrict__ info) {
-    extern __shared__ __attribute__((aligned(16))) double P[];
+                                                         int* __restrict__ info, int stage_cap) {
+    // stage_cap (<= kSmallStage, host-chosen per launch): doubles per staged block
+    extern __shared__ __attribute__((aligned(16))) double P[];  // panel, then 2 stages, then 2 index rings
     const int tid = threadIdx.x;
     const SnDesc D = sn[list[blockIdx.x]];
     const int r = D.r, w = D.w, total = r * w;
     double* __restrict__ G = L + D.px;
+    const int total_pad = (total + 1) & ~1;
+    double* __restrict__ S0 = P + total_pad;
+    int32_t* __restrict__ R0 = reinterpret_cast<int32_t*>(S0 + 2 * stage_cap);
 
-    for (int e = tid; e < total; e += kThreads) P[e] = G[e];
-    __syncthreads();
+    // panel: all loads of a thread are issued before its LDS stores
+    for (int base = 0; base < total; base += 8 * kThreads) {
+        double tv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = base + q * kThreads + tid;
+            tv[q] = e < total ? G[e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = base + q * kThreads + tid;
+            if (e < total) P[e] = tv[q];
+        }
+    }
 
-    for (int u = 0; u < D.nupd; ++u) {
-        const UpdDesc U = upd[D.upd0 + u];
-        const double* __restrict__ src = L + U.src;
-        const int32_t* __restrict__ rel = relpos + U.rel;
-        const int m = U.m, n1 = U.n1, K = U.K, ld = U.ld;
+    // ---- stream state: block = (update u, k0, kc) with m * kc <= kSmallStage -----------------
+    struct Blk {
+        double v[kSmallPerThread];
+        int32_t rel;    // relative index of row `tid` of the block (first block of an update only)
+        int32_t m, kc, n1, first, u;  // m == 0: nothing; u: update number (index ring slot u & 3)
+    };
+    int lu = 0, lk = 0;  // loader position
+    UpdDesc LU;
+    int l_kstep = 1;
+    auto loader_enter = [&]() {
+        if (lu < D.nupd) {
+            LU = upd[D.upd0 + lu];
+            l_kstep = max(1, stage_cap / max(LU.m, 1));
+        }
+    };
+    loader_enter();
+    auto issue = [&](Blk& b) {
+        b.m = 0;
+        if (lu >= D.nupd) return;
+        const int m = LU.m;
+        // a descendant block taller than a stage is not staged: its update is applied straight
+        // from global memory by the consumer (one pseudo-block covering all of K)
+        const bool direct = m > stage_cap;
+        const int kc = direct ? LU.K : min(l_kstep, LU.K - lk);
+        b.m = direct ? -1 : m;
+        b.kc = kc;
+        b.n1 = LU.n1;
+        b.first = lk == 0;
+        b.u = lu;
+        if (direct) {
+            lk = 0;
+            ++lu;
+            loader_enter();
+            return;
+        }
+        const double* __restrict__ src = L + LU.src + (int64_t)lk * LU.ld;
+        const int cnt = m * kc;
+#pragma unroll
+        for (int q = 0; q < kSmallPerThread; ++q) {
+            const int e = q * kThreads + tid;
+            double v = 0.0;
+            if (e < cnt) {
+                const int kk = e / m, i = e - kk * m;
+                v = src[i + (int64_t)kk * LU.ld];
+            }
+            b.v[q] = v;
+        }
+        b.rel = (lk == 0 && tid < m && tid < kSmallRelCap) ? relpos[LU.rel + tid] : 0;
+        lk += kc;
+        if (lk >= LU.K) {
+            lk = 0;
+            ++lu;
+            loader_enter();
+        }
+    };
+    auto store = [&](const Blk& b, int stage) {
+        if (b.m <= 0) return;
+        double* __restrict__ S = S0 + stage * stage_cap;
+#pragma unroll
+        for (int q = 0; q < kSmallPerThread; ++q) {
+            const int e = q * kThreads + tid;
+            if (e < b.m * b.kc) S[e] = b.v[q];
+        }
+        if (b.first && tid < b.m && tid < kSmallRelCap) R0[(b.u & 3) * kSmallRelCap + tid] = b.rel;
+    };
+    // consumer: needs m, kc, n1 of the block in `stage` and the index ring of its update
+    int cu = 0, ck = 0;
+    UpdDesc CU;
+    int c_kstep = 1;
+    auto consumer_enter = [&]() {
+        if (cu < D.nupd) {
+            CU = upd[D.upd0 + cu];
+            c_kstep = max(1, stage_cap / max(CU.m, 1));
+        }
+    };
+    consumer_enter();
+    auto consume = [&](int stage) {
+        const int m = CU.m, n1 = CU.n1;
+        if (m > stage_cap) {  // not staged (see issue): straight from the descendant's panel
+            const double* __restrict__ src = L + CU.src;
+            const int32_t* __restrict__ relg = relpos + CU.rel;
+            for (int e = tid; e < m * n1; e += kThreads) {
+                const int j = e / m, i = e - j * m;
+                if (i >= j) {
+                    double acc = 0.0;
+                    for (int kk = 0; kk < CU.K; ++kk)
+                        acc = fma(src[i + (int64_t)kk * CU.ld], src[j + (int64_t)kk * CU.ld], acc);
+                    P[relg[j] * r + relg[i]] -= acc;
+                }
+            }
+            ck = 0;
+            ++cu;
+            consumer_enter();
+            return;
+        }
+        const int kc = min(c_kstep, CU.K - ck);
+        const double* __restrict__ S = S0 + stage * stage_cap;
+        const int32_t* __restrict__ rel = R0 + (cu & 3) * kSmallRelCap;  // came with the update's first block
+        const int32_t* __restrict__ relg = relpos + CU.rel;  // rows beyond the staged indices (rare)
         const int pairs = m * n1;
         for (int e = tid; e < pairs; e += kThreads) {
             const int j = e / m, i = e - j * m;
             if (i >= j) {
-                const double* a = src + i;
-                const double* b = src + j;
                 double acc = 0.0;
-                for (int k = 0; k < K; ++k) acc = fma(a[(int64_t)k * ld], b[(int64_t)k * ld], acc);
-                P[rel[j] * r + rel[i]] -= acc;
+                for (int kk = 0; kk < kc; ++kk) acc = fma(S[kk * m + i], S[kk * m + j], acc);
+                const int ri = i < kSmallRelCap ? rel[i] : relg[i];
+                const int rj = j < kSmallRelCap ? rel[j] : relg[j];
+                P[rj * r + ri] -= acc;
             }
         }
+        ck += kc;
+        if (ck >= CU.K) {
+            ck = 0;
+            ++cu;
+            consumer_enter();
+        }
+    };
+
+    Blk b0, b1, b2;
+    issue(b0);
+    issue(b1);
+    issue(b2);
+    store(b0, 0);
+    __syncthreads();
+    int p = 0;
+    while (cu < D.nupd) {
+        store(b1, (p + 1) & 1);
+        issue(b0);
+        consume(p & 1);
         __syncthreads();
+        ++p;
+        if (cu >= D.nupd) break;
+        store(b2, (p + 1) & 1);
+        issue(b1);
+        consume(p & 1);
+        __syncthreads();
+        ++p;
+        if (cu >= D.nupd) break;
+        store(b0, (p + 1) & 1);
+        issue(b2);
+        consume(p & 1);
+        __syncthreads();
+        ++p;
     }
 
     // right-looking POTRF on the w diagonal rows with the r-w rows below carried
@@ -111,11 +261,15 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
     for (int e = tid; e < total; e += kThreads) G[e] = P[e];
 }
 
-void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), (size_t)lds_bytes, stream, P.sn,
-                       P.upd, P.relpos, P.small_list + first, L, P.info);
+    // panel (padded to 16 B) + two staged blocks + four index-ring slots
+    stage_cap = min(max(stage_cap, 2), kSmallStage);
+    const size_t lds = (size_t)((lds_bytes + 15) & ~15) + 2 * (size_t)stage_cap * sizeof(double) +
+                       4 * kSmallRelCap * sizeof(int32_t);
+    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.sn,
+                       P.upd, P.relpos, P.small_list + first, L, P.info, stage_cap);
 }
 
 // ---------------------------------------------------------------------------

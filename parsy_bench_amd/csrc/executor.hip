@@ -175,7 +175,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         }
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {
-            case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, L, stream); break;
+            case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, L, stream); break;
             case kLaunchTiles:
                 if (on_side) {
                     record_levels_below(l.wait_level + 1);

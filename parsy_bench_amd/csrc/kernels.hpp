@@ -32,7 +32,7 @@ struct DevicePattern {           // device copies of Schedule arrays
 // lValues[a_dst[q]] = values[q]
 void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int64_t nnz,
                       hipStream_t stream);
-void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, double* L,
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
                        hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
                        int finalize, int epoch, double* L, hipStream_t stream);

@@ -205,6 +205,10 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 if (is_small(T)) {
                     S.small_list.push_back(t);
                     L.lds_bytes = std::max<int32_t>(L.lds_bytes, T.w * T.r * (int)sizeof(double));
+                    // jb carries the stage size of the SMALL launch: the largest descendant block,
+                    // capped (kernel: kSmallStage = 2048 doubles)
+                    for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
+                        L.jb = std::max<int32_t>(L.jb, std::min<int64_t>((int64_t)S.upd[u].m * S.upd[u].K, 2048));
                 } else {
                     bigs.push_back(t);
                 }
