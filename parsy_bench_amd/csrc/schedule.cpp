@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -171,6 +172,13 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
 
 void build_launches(Schedule& S, const uint8_t* active) {
     const int ns = S.nsuper;
+    // PARSY_FORCE_UNFUSED=1 schedules the fallback forms everywhere (separate PANEL launches,
+    // per-block-column solve launches): the paths taken when a launch would hold more waiting
+    // workgroups than may safely be resident.  Used by the tests to cover them on small inputs.
+    const char* fu = std::getenv("PARSY_FORCE_UNFUSED");
+    const bool force_unfused = fu && fu[0] == '1';
+    const int max_waiting = force_unfused ? -1 : kMaxWaitingTiles;
+    const int max_chain = force_unfused ? -1 : kMaxChainWorkgroups;
     S.active.assign(ns, 1);
     if (active) S.active.assign(active, active + ns);
     S.small_list.clear();
@@ -221,7 +229,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             Launch L{kLaunchTiles, 0, 0, lev, 0, 0, 0, 0, -1, 0};
             int maxnb = 0, waiting = 0;
             for (int t : bigs) waiting += ceil_div(S.sn[t].r, kTile) - 1;
-            L.fused = waiting <= kMaxWaitingTiles;
+            L.fused = waiting <= max_waiting;
             for (int phase = 0; phase < 2; ++phase) {
                 std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
                 for (int t : bigs) {
@@ -284,7 +292,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     const SnDesc& T = S.sn[t];
                     if (ceil_div(T.w, kTile) > jb + 1) wait_i += ceil_div(T.r, kTile) - (jb + 1) - 1;
                 }
-                Li.fused = wait_i <= kMaxWaitingTiles;
+                Li.fused = wait_i <= max_waiting;
                 for (int pass = 0; pass < 3; ++pass)  // diagonal tiles, then column jb+1, then the rest
                     for (int t : bigs) {
                         const SnDesc& T = S.sn[t];
@@ -319,7 +327,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             S.n_solve_wide += (int)sbigs.size();
             int chain_wgs = 0;
             for (int t : sbigs) chain_wgs += ceil_div(S.sn[t].r, kSolveRows);
-            if (chain_wgs <= kMaxChainWorkgroups) {
+            if (chain_wgs <= max_chain) {
                 // one launch: every 256-row chunk of every wide supernode of the level
                 Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, 0, 0, 1, 0, -1, 0};
                 for (int t : sbigs)

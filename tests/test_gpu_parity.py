@@ -310,3 +310,26 @@ def test_full_size_round_trip(api, oracle, name):
     finally:
         oracle.unbind_blas()
     assert ok and np.abs(lv - lo).max() <= 1e-10 * np.abs(lo).max()
+
+
+def test_unfused_fallback_paths(api, oracle, monkeypatch):
+    """The schedules used when a fused launch would hold too many waiting workgroups
+    (separate PANEL launches, per-block-column solve launches) give the same answers."""
+    from parsy_bench_amd import inspector as I
+    monkeypatch.setenv("PARSY_FORCE_UNFUSED", "1")
+    A, perm, sym = problem("lap30")
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+    b = oracle.rhs_init_blocked(sym, lo)
+    X, _ = plan.solve(lo, np.stack([b, 2 * b, b + 1.0], axis=1))
+    xo = oracle.blocked_lsolve(sym, lo, b + 1.0, "serial")
+    assert np.abs(X[:, 0] - 1.0).max() <= 1e-9 and np.abs(X[:, 2] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+    monkeypatch.delenv("PARSY_FORCE_UNFUSED")
+    plan2 = api.Plan(sym, 0)
+    assert plan2.info["chol_launches"] < info["chol_launches"]  # the fused schedule has fewer launches
+    lv2, _ = plan2.factor(sym.A2x)
+    assert np.abs(lv2 - lv).max() <= FACTOR_TOL * np.abs(lo).max()
