@@ -212,6 +212,19 @@ def main():
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
         solve_err = float((X.view(nrhs, sym.n) - ones).abs().max().item())
+        # backward solve L' x = y (extension): timed the same way, reported beside
+        def bsolve_step():
+            X.copy_(B)
+            solve_plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+
+        for _ in range(args.warmup):
+            bsolve_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            bsolve_step()
+        torch.cuda.synchronize()
+        dt_b = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
 
@@ -267,6 +280,7 @@ def main():
         "solve_nrhs": nrhs,
         "solve_ms": (dt_s / args.steps * 1e3) if dt_s else None,
         "solve_max_abs_err_vs_ones": solve_err,
+        "backward_solve_ms": dt_b / args.steps * 1e3,
     }
 
     if prof is not None:

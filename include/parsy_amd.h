@@ -159,6 +159,15 @@ int parsy_factor_status(parsy_plan* plan);
 int parsy_solve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs,
                        int ldx, void* stream);
 
+/* Backward solve L' X = Y in place (same layout as parsy_solve_device).  Not part of the
+ * reference (it only has the forward solve): forward + backward solve A x = b
+ * for the permuted system, x = P' L'^-1 L^-1 P b. Asynchronous on `stream`. */
+int parsy_backsolve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs, int ldx,
+                           void* stream);
+/* Host convenience: forward (if `forward` != 0) then backward solve on host buffers. */
+int parsy_solve2_host(parsy_plan* plan, const double* lValues, double* x, int nrhs, int ldx,
+                      int forward, double* seconds);
+
 /* Host-buffer conveniences (H2D + kernels + D2H, synchronous). `seconds`, if
  * non-NULL, receives the device time of the numeric kernels alone. */
 int parsy_factor_host(parsy_plan* plan, const double* values, double* lValues, double* seconds);
@@ -177,7 +186,7 @@ double parsy_last_solve_ms(parsy_plan* plan);
  *     elapsed time of every launch of the last factor/solve to its kernel kind.
  *   parsy_plan_profile_get: accumulated ms and launch counts per kind (8 entries:
  *     0 SMALL, 1 TILES, 2 INNER, 3 PANEL, 4 FIXUP, 5 SOLVE_SMALL, 6 SOLVE_PANEL,
- *     7 SOLVE_FIXUP) and the number of collected runs. */
+ *     7 SOLVE_FIXUP; the arrays passed must hold 8 entries) and the number of collected runs. */
 int parsy_plan_profile(parsy_plan* plan, int enable);
 int parsy_plan_profile_collect(parsy_plan* plan);
 int parsy_plan_profile_get(parsy_plan* plan, double* kind_ms, int* kind_launches, int* runs);

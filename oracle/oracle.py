@@ -57,6 +57,8 @@ def lib():
         L.oracle_H2LeveledBlockedLsolve.argtypes = base + [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
         L.oracle_H2LeveledBlockedLsolve_Peeled.argtypes = base + [C.c_int, vp, vp, C.c_int, vp, vp,
                                                                  C.c_int, C.c_int]
+        L.oracle_blockedLTsolve.restype = C.c_int
+        L.oracle_blockedLTsolve.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
         L.oracle_ereach_sn.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.oracle_getLevelSet.argtypes = [C.c_size_t, vp, vp, vp]
         L.oracle_dlsolve_blas_nonUnit.argtypes = [C.c_int, C.c_int, vp, vp]
@@ -174,6 +176,15 @@ def blocked_lsolve(sym, lValues, x, variant: str = "serial", hlevel=None, thread
             rc = L.oracle_H2LeveledBlockedLsolve_Peeled(*base, nl, P(lp), None, 0, P(pp), P(pt), 1, threads)
         else:
             raise ValueError(variant)
+    assert rc == 1
+    return x
+
+
+def blocked_ltsolve(sym, lValues, y):
+    """Backward solve L' x = y (checker of the product's backward solve; not a reference function)."""
+    x = np.ascontiguousarray(y, dtype=np.float64).copy()
+    a = [_sz(sym.p), _i32(sym.s), np.ascontiguousarray(lValues), _sz(sym.i_ptr), _i32(sym.super)]
+    rc = lib().oracle_blockedLTsolve(sym.n, P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(a[4]), sym.nsuper, P(x))
     assert rc == 1
     return x
 

@@ -15,6 +15,8 @@
  *   oracle_dlsolve_blas_nonUnit / oracle_dmatvec_blas  triangularSolve/BLAS.h:8-103 / :119-191
  *   oracle_getLevelSet                 common/TreeUtils.h:119-169
  *   oracle_rhsInitBlocked / oracle_testTriangular / oracle_bcsc2csc  common/Util.h:277-338
+ * plus oracle_blockedLTsolve, the checker of the product's backward solve (no reference
+ * counterpart: SURVEY.md 8f rank 1).
  *
  * Third-party arithmetic: the reference calls Intel MKL (version unpinned, taken
  * from $MKLROOT, reference CMakeLists.txt:3-5) for dsyrk / dgemm / dpotrf / dtrsm
@@ -29,7 +31,8 @@
  * (ereach_sn, getLevelSet, dlsolve_blas_nonUnit, dmatvec_blas, MyBLAS.h's
  * Cholesky_col / lSolve_dense_col and the inspector functions) are built into
  * oracle/_ref by oracle/Makefile and this file is checked against them
- * (tests/test_oracle_vs_ref.py; committed vectors in tests/golden/).  The
+ * (tests/test_oracle.py, tests/test_inspector_golden.py; committed vectors in
+ * tests/golden/).  The
  * assembled executors are pinned through those pieces plus the uniqueness of the
  * Cholesky factor (checked against LAPACK via numpy and against L L' = P A P').
  * There is no end-to-end run of the reference executors behind it: at executor
@@ -607,6 +610,28 @@ ORACLE_API int oracle_H2LeveledBlockedLsolve_Peeled(int n, size_t* Lp, int* Li, 
             }
         }
     free(tempVec);
+    return 1;
+}
+
+/* Backward solve L' x = y on the BCSC factor.  NOT a reference function (the reference has
+ * only the forward solves): the checker of the product's backward
+ * solve, written as the plain column-by-column dot-product form, last column first. */
+ORACLE_API int oracle_blockedLTsolve(int n, const size_t* Lp, const int* Li, const double* Lx,
+                                     const size_t* Li_ptr, const int* sup2col, int supNo, double* x) {
+    (void)n;
+    if (!Lp || !Li || !x) return 0;
+    for (int s = supNo - 1; s >= 0; --s) {
+        const int c0 = sup2col[s], c1 = sup2col[s + 1];
+        const int r = (int)(Li_ptr[c1] - Li_ptr[c0]);
+        const int* rows = Li + Li_ptr[c0];
+        for (int c = c1 - 1; c >= c0; --c) {
+            const double* col = Lx + Lp[c];
+            const int d = c - c0;
+            double acc = x[c];
+            for (int j = d + 1; j < r; ++j) acc -= col[j] * x[rows[j]];
+            x[c] = acc / col[d];
+        }
+    }
     return 1;
 }
 

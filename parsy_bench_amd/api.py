@@ -179,6 +179,33 @@ class Plan:
             raise RuntimeError("parsy_solve_host failed: " + N.last_error())
         return (X[:, 0].copy() if one else np.ascontiguousarray(X)), sec.value
 
+    def solve2(self, lValues, b, forward: bool = True):
+        """Backward solve L' x = y (forward=False) or the full L L' x = b (forward=True) of the
+        PERMUTED system; returns (x, device_seconds)."""
+        b = np.asarray(b, dtype=np.float64)
+        one = b.ndim == 1
+        X = np.asfortranarray(b.reshape(self.sym.n, -1)).copy(order="F")
+        lv = _f64(lValues)
+        sec = C.c_double(0)
+        rc = N.lib().parsy_solve2_host(self._h, N.ptr(lv), X.ctypes.data_as(C.c_void_p), X.shape[1],
+                                       self.sym.n, 1 if forward else 0, C.byref(sec))
+        if rc != 0:
+            raise RuntimeError("parsy_solve2_host failed: " + N.last_error())
+        return (X[:, 0].copy() if one else np.ascontiguousarray(X)), sec.value
+
+    def solve_spd(self, lValues, b):
+        """x with A x = b for the ORIGINAL matrix: x = P' L'^-1 L^-1 P b (Perm from the inspector)."""
+        b = np.asarray(b, dtype=np.float64)
+        pb = b[self.sym.Perm] if b.ndim == 1 else b[self.sym.Perm, :]
+        z, sec = self.solve2(lValues, pb, forward=True)
+        x = np.empty_like(z)
+        x[self.sym.Perm] = z
+        return x, sec
+
+    def backsolve_device(self, d_lValues: int, d_x: int, nrhs: int, ldx: int, stream: int = 0) -> None:
+        if N.lib().parsy_backsolve_device(self._h, d_lValues, d_x, nrhs, ldx, stream) != 0:
+            raise RuntimeError("parsy_backsolve_device failed: " + N.last_error())
+
     # device-pointer API ---------------------------------------------------------
     def factor_device(self, d_values: int, d_lValues: int, stream: int = 0, init: bool = True) -> None:
         if N.lib().parsy_factor_device_ex(self._h, d_values, d_lValues, stream, 0 if init else 1) != 0:

@@ -381,6 +381,51 @@ int parsy_solve_host(parsy_plan* pl, const double* lValues, double* x, int nrhs,
     return 0;
 }
 
+int parsy_backsolve_device(parsy_plan* pl, const double* d_lValues, double* d_x, int nrhs, int ldx,
+                           void* stream) {
+    if (!pl || !d_lValues || !d_x) {
+        set_last_error("parsy_backsolve_device: null argument");
+        return -1;
+    }
+    return parsy::plan_backsolve(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream);
+}
+
+int parsy_solve2_host(parsy_plan* pl, const double* lValues, double* x, int nrhs, int ldx, int forward,
+                      double* seconds) {
+    if (!pl || !lValues || !x) {
+        set_last_error("parsy_solve2_host: null argument");
+        return -1;
+    }
+    if (pl->device < 0) {
+        set_last_error("parsy_solve2_host: plan has no device");
+        return -1;
+    }
+    const parsy::Schedule& S = pl->S;
+    CAPI_HIP(hipSetDevice(pl->device), -1);
+    if (!pl->h_L_dev) CAPI_HIP(hipMalloc((void**)&pl->h_L_dev, std::max<int64_t>(S.xsize, 1) * 8), -1);
+    const int64_t need = (int64_t)ldx * nrhs;
+    if (pl->h_x_len < need) {
+        if (pl->h_x_dev) (void)hipFree(pl->h_x_dev);
+        pl->h_x_dev = nullptr;
+        CAPI_HIP(hipMalloc((void**)&pl->h_x_dev, (size_t)need * 8), -1);
+        pl->h_x_len = need;
+    }
+    CAPI_HIP(hipMemcpy(pl->h_L_dev, lValues, (size_t)S.xsize * 8, hipMemcpyHostToDevice), -1);
+    CAPI_HIP(hipMemcpy(pl->h_x_dev, x, (size_t)need * 8, hipMemcpyHostToDevice), -1);
+    double sec = 0;
+    if (forward) {
+        if (parsy::plan_solve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
+        CAPI_HIP(hipDeviceSynchronize(), -1);
+        sec += parsy_last_solve_ms(pl) * 1e-3;
+    }
+    if (parsy::plan_backsolve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
+    CAPI_HIP(hipDeviceSynchronize(), -1);
+    sec += parsy_last_solve_ms(pl) * 1e-3;
+    if (seconds) *seconds = sec;
+    CAPI_HIP(hipMemcpy(x, pl->h_x_dev, (size_t)need * 8, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
 void parsy_dropin_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_plans) parsy::plan_free(kv.second);

@@ -46,6 +46,7 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
     if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
+    if (upload(pl, S.bsolve_blocks, pl->dp.bsolve_blocks, true)) return -1;
     return 0;
 }
 
@@ -205,10 +206,28 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
             case kLaunchSolveFixup:
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
+            case kLaunchBackBlock: launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
         }
     }
     profile_mark(pl, -1, stream, cursor);
     if (pl->profile) pl->pev_kind.resize(cursor);
+}
+
+int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream) {
+    if (pl->device < 0) {
+        set_last_error("parsy_backsolve: plan was built without a device (device < 0)");
+        return -1;
+    }
+    if (nrhs < 1 || ldx < pl->S.n) {
+        set_last_error("parsy_backsolve: need nrhs >= 1 and ldx >= n");
+        return -1;
+    }
+    PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+    run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
+    PARSY_HIP(hipGetLastError());
+    PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+    pl->have_s = true;
+    return 0;
 }
 
 int plan_collect_profile(parsy_plan* pl) {
@@ -218,7 +237,7 @@ int plan_collect_profile(parsy_plan* pl) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pl->pev[i], pl->pev[i + 1]) != hipSuccess) return -1;
         const int k = pl->pev_kind[i];
-        if (k >= 0 && k < 8) {
+        if (k >= 0 && k < 10) {
             pl->kind_ms[k] += ms;
             pl->kind_launches[k] += 1;
         }

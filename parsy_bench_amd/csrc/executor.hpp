@@ -44,8 +44,8 @@ struct parsy_plan {
     bool profile = false;
     std::vector<hipEvent_t> pev;
     std::vector<int> pev_kind;
-    double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int kind_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double kind_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int kind_launches[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int profiled_runs = 0;
 };
 
@@ -60,6 +60,7 @@ int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream
                 bool init = true);
 int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
                hipStream_t stream);
+int plan_backsolve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream);
 int plan_collect_profile(parsy_plan* plan);
 
 }  // namespace parsy

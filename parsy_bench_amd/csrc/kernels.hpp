@@ -23,7 +23,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
-    const int32_t* solve_wide_list = nullptr;  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
+    const int32_t* solve_wide_list = nullptr;
+    const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
     double* dscratch = nullptr;  // parked 64x64 diagonal blocks
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // per parked diagonal block: epoch of the factorization that parked it
@@ -47,6 +48,8 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
                          hipStream_t stream);
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x, int nrhs,
+                         int ldx, hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

@@ -372,6 +372,24 @@ void build_launches(Schedule& S, const uint8_t* active) {
         }
         S.chol.swap(merged);
     }
+    // ---- backward solve: root level first; within a level the narrow supernodes and, for the
+    // wide ones, the block columns from the last one down (one launch per block-column index)
+    S.bsolve_blocks.clear();
+    S.bsolve.clear();
+    for (int lev = S.nlevels - 1; lev >= 0; --lev) {
+        int maxnb = 0;
+        for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q)
+            if (S.active[S.levelSet[q]]) maxnb = std::max(maxnb, ceil_div(S.sn[S.levelSet[q]].w, kTile));
+        for (int jb = maxnb - 1; jb >= 0; --jb) {
+            Launch Lb{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, jb, 0, 0, 0, -1, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (S.active[t] && ceil_div(S.sn[t].w, kTile) > jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
+            }
+            Lb.count = (int32_t)S.bsolve_blocks.size() - Lb.first;
+            if (Lb.count > 0) S.bsolve.push_back(Lb);
+        }
+    }
     if (!S.solve_fix_list.empty())
         S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0, 0, -1, 0});
 }

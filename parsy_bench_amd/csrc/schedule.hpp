@@ -83,7 +83,7 @@ struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
 
 enum LaunchKind : int32_t {
     kLaunchSmall = 0, kLaunchTiles = 1, kLaunchInner = 2, kLaunchPanel = 3, kLaunchFixup = 4,
-    kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7,
+    kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
 };
 
 struct Launch {
@@ -137,6 +137,10 @@ struct Schedule {
     std::vector<int32_t> solve_wide_list; // wide supernodes solved by SOLVE_CHAIN
     int solve_wide_max_blocks = 0;
     std::vector<Launch> solve;
+
+    // backward solve L' x = y: levels from the root down, wide supernodes block column by block column
+    std::vector<PanelDesc> bsolve_blocks;
+    std::vector<Launch> bsolve;
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches
     std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow

@@ -432,6 +432,152 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                            P.info);
 }
 
+// ---------------------------------------------------------------------------
+// Backward solve L' x = y (the reference only has the forward solve;
+// with this the library solves A x = b end to end).  Pull form, no atomics: a block of <= 64
+// columns [cb, cb+wbk) of a supernode is finished by one workgroup once every row below it
+// is final (ancestors' columns: earlier levels; later block columns of the same supernode:
+// earlier launches):   t = y_blk - L(below, blk)' x(below),   x_blk = inv(L_bb)' t.
+// The product runs one wave per column with lanes along the (contiguous) rows.
+// ---------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restrict__ sn,
+                                                           const PanelDesc* __restrict__ pds,
+                                                           const int32_t* __restrict__ rows,
+                                                           const double* __restrict__ L,
+                                                           double* __restrict__ x, int nrhs, int ldx) {
+    __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
+    __shared__ double ts[kTile][NQ];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const PanelDesc pd = pds[blockIdx.x];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    const int kbeg = cb + wbk;  // first panel row below the block
+
+    {   // diagonal block (identity padded) -> LDS
+        double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            const int c = e >> 6, i = e & 63;
+            double v = (i == c) ? 1.0 : 0.0;
+            if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+            dtmp[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+        }
+    }
+    __syncthreads();
+    // inverses of the 16x16 diagonal sub-blocks (stored transposed in the strict upper triangle)
+    if (tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
+    __syncthreads();
+    if (tid < kTile && (tid & ~15) < wbk) {
+        const int b16 = tid & ~15, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+    }
+
+    for (int q0 = 0; q0 < nrhs; q0 += NQ) {
+        const int nq = min(NQ, nrhs - q0);
+        __syncthreads();
+        for (int e = tid; e < kTile * NQ; e += kThreads) {
+            const int c = e & 63, q = e >> 6;
+            ts[c][q] = (c < wbk && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] : 0.0;
+        }
+        __syncthreads();
+        // t[c] -= sum_k L[k, cb+c] x[row(k)]: wave `wave` takes columns wave, wave+4, ...
+        {
+            double acc[kTile / 4][NQ];
+#pragma unroll
+            for (int ci = 0; ci < kTile / 4; ++ci)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[ci][q] = 0.0;
+            for (int k = kbeg + lane; k < r; k += 64) {
+                const int xr = (k < w) ? (D.c0 + k) : ri[k];
+                double xk[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) xk[q] = (q < nq) ? x[(int64_t)(q0 + q) * ldx + xr] : 0.0;
+#pragma unroll
+                for (int ci = 0; ci < kTile / 4; ++ci) {
+                    const int c = wave + 4 * ci;
+                    const double lv = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv, xk[q], acc[ci][q]);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < kTile / 4; ++ci)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    double v = acc[ci][q];
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    if (lane == 0) ts[wave + 4 * ci][q] -= v;  // each (column, q) has one writer
+                }
+        }
+        __syncthreads();
+        // x_blk = inv(L_bb)' t, 16 columns at a time from the last sub-block up
+        for (int b16 = ((wbk - 1) & ~15); b16 >= 0; b16 -= 16) {
+            const int i = tid & 15, q = tid >> 4;
+            const bool act = q < nq;
+            double zv = 0.0;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    double lv = 0.0;  // inv(L_bb)'[i][k] = inv(L_bb)[k][i]
+                    if (k > i) lv = Dg[(b16 + k) * kLdDiag + b16 + i];
+                    else if (k == i) lv = invd[b16 + i];
+                    zv = fma(lv, ts[b16 + k][q], zv);
+                }
+            }
+            __syncthreads();
+            if (act) ts[b16 + i][q] = zv;
+            __syncthreads();
+            // columns above the sub-block: t[a] -= sum_k L[b16+k][a] z[k]
+            for (int e = tid; e < b16 * nq; e += kThreads) {
+                const int qq = e / b16, a2 = e - qq * b16;
+                double accv = ts[a2][qq];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) accv = fma(-Dg[a2 * kLdDiag + b16 + k], ts[b16 + k][qq], accv);
+                ts[a2][qq] = accv;
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < wbk * nq; e += kThreads) {
+            const int q = e / wbk, c = e - q * wbk;
+            x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = ts[c][q];
+        }
+    }
+}
+
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x, int nrhs,
+                         int ldx, hipStream_t stream) {
+    if (count <= 0) return;
+    if (nrhs == 1)
+        hipLaunchKernelGGL(k_bsolve_block<1>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+                           P.bsolve_blocks + first, P.rows, L, x, nrhs, ldx);
+    else
+        hipLaunchKernelGGL(k_bsolve_block<4>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+                           P.bsolve_blocks + first, P.rows, L, x, nrhs, ldx);
+}
+
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.
 __global__ __launch_bounds__(kThreads) void k_solve_fixup(const SnDesc* __restrict__ sn,
                                                           const int32_t* __restrict__ list,

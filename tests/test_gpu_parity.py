@@ -333,3 +333,36 @@ def test_unfused_fallback_paths(api, oracle, monkeypatch):
     assert plan2.info["chol_launches"] < info["chol_launches"]  # the fused schedule has fewer launches
     lv2, _ = plan2.factor(sym.A2x)
     assert np.abs(lv2 - lv).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+# ---------------------------------------------------------------------------
+# backward solve and the end-to-end solve A x = b
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
+@pytest.mark.parametrize("nrhs", [1, 5])
+def test_backward_solve_matches_checker(api, oracle, name, nrhs):
+    A, sym, plan, lv, lo = _factor_both(api, oracle, name)
+    rng = np.random.default_rng(9)
+    Y = rng.standard_normal((sym.n, nrhs))
+    X, _ = plan.solve2(lo, Y, forward=False)
+    for q in range(nrhs):
+        xo = oracle.blocked_ltsolve(sym, lo, Y[:, q])
+        assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+
+
+@pytest.mark.parametrize("name", ["small3d", "ex15", "lap30", "nd24k"])
+def test_end_to_end_solve_residual(api, oracle, name):
+    """Factor on the GPU, then x = P' L'^-1 L^-1 P b: the residual of the ORIGINAL system is an
+    oracle-independent check of the whole path (north_star: 1e-10 relative residual)."""
+    A, perm, sym = problem(name)
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    As = A.to_scipy()
+    rng = np.random.default_rng(12)
+    B = rng.standard_normal((sym.n, 3))
+    X, _ = plan.solve_spd(lv, B)
+    R = As @ X - B
+    assert np.abs(R).max() <= RESID_TOL * (np.abs(As).max() * np.abs(X).max() + np.abs(B).max())
+    xs, _ = plan.solve_spd(lv, As @ np.ones(sym.n))
+    assert np.abs(xs - 1.0).max() <= 1e-9

@@ -181,3 +181,20 @@ def test_bcsc2csc_drops_only_padding(oracle):
     for j in range(sym.n):
         rows = Ci[Cp[j]: Cp[j + 1]]
         assert rows[0] == j and np.array_equal(Ld[rows, j], Cx[Cp[j]: Cp[j + 1]])
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d"])
+def test_backward_solve_checker_vs_dense(oracle, name):
+    """oracle_blockedLTsolve (checker of the product's backward solve; no reference counterpart)."""
+    A, perm, sym = problem(name)
+    ok, lv, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    Ld = I.bcsc_to_dense(sym, lv)
+    rng = np.random.default_rng(4)
+    y = rng.standard_normal(sym.n)
+    x = oracle.blocked_ltsolve(sym, lv, y)
+    assert np.abs(Ld.T @ x - y).max() < 1e-11
+    # forward + backward = solve with P A P'
+    b = rng.standard_normal(sym.n)
+    z = oracle.blocked_ltsolve(sym, lv, oracle.blocked_lsolve(sym, lv, b, "serial"))
+    Ad = A.to_dense()[np.ix_(sym.Perm, sym.Perm)]
+    assert np.abs(Ad @ z - b).max() < 1e-10 * max(1.0, np.abs(z).max())
