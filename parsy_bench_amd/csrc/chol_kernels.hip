@@ -396,23 +396,24 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
     }
 }
 
-static constexpr int kKC = 16;        // k extent of one staged operand chunk
-static constexpr int kLdK = kKC + 1;  // padded row length of a staged chunk (bank-conflict free)
-static constexpr int kPass = 128;     // update entries evaluated per pass
-static constexpr int kInFlight = 6;   // chunks of the stream in flight per thread (registers)
+static constexpr int kKC = 16;        // k extent of one chunk of an update stream
+static constexpr int kInFlight = 4;   // chunks in flight per wave (operands prefetched into registers)
 
-// One workgroup per 64x64 tile of a panel.  The update stream of the tile -- every
-// (descendant, 16-wide k chunk) pair that touches it, in update order -- is pumped through
-// a double-buffered LDS stage by all 256 threads with coalesced loads (rows of a panel
-// column are contiguous), three chunks deep (two in registers, one landing in LDS), while
-// each wave multiplies its 32x32 sub-tile's rows out of the stage with
-// v_mfma_f64_16x16x4_f64 and, at the end of a descendant, scatter-subtracts the product
-// into its private LDS sub-tile through the relative indices (ds_add_f64, in order).
+// One workgroup per 64x64 tile of a panel, one wave per 32x32 sub-tile, and the four waves run
+// their update streams independently (no workgroup barrier until the stream is finished).  A
+// wave's stream -- WaveEntry list built on the host: every descendant with rows in the
+// sub-tile's row AND column window, in update order -- is cut in 16-wide k chunks.  The MFMA
+// operands of a chunk go straight from the descendant's column-major panel into registers
+// (v_mfma_f64_16x16x4_f64: lane = (row & 15, k >> 2 group), 16 consecutive rows per k are one
+// 128-B segment), kInFlight chunks ahead of the multiply; at the end of a descendant the
+// product is scatter-subtracted into the wave's private LDS sub-tile through the relative
+// indices (ds_add_f64 without return; the LDS operations of one wave execute in order, so the
+// summation order is fixed).
 template <bool INNER>
 __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
-                                                            const UpdDesc* __restrict__ upd,
                                                             const int32_t* __restrict__ relpos,
-                                                            const ColBlkEntry* __restrict__ colblk,
+                                                            const WaveEntry* __restrict__ wents,
+                                                            const int64_t* __restrict__ wptr,
                                                             const TileDesc* __restrict__ tiles, int jb,
                                                             double* __restrict__ L,
                                                             double* __restrict__ dscratch,
@@ -421,19 +422,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             int fused, int finalize) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[kPotrfScratch];
-    __shared__ double stage[4][kTile * kLdK];  // A stages 0,1 and B stages 2,3 (reused by the TRSM)
+    __shared__ double dgbuf[kTile * kLdDiag];  // diagonal block + its 16x16 inverses (TRSM)
     __shared__ int32_t s_ok;
-    double (*As)[kTile * kLdK] = stage;
-    double (*Bs)[kTile * kLdK] = stage + 2;
-    __shared__ int32_t relA[4][kTile], relB[4][kTile];
-    __shared__ int64_t e_src[kPass];
-    __shared__ int64_t e_rel[kPass];
-    __shared__ int32_t e_ld[kPass], e_K[kPass];
-    __shared__ int32_t e_i0[kPass], e_i1[kPass], e_i2[kPass];
-    __shared__ int32_t e_j0[kPass], e_j1[kPass], e_j2[kPass];
-    __shared__ int32_t wcount[2];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileDesc td = tiles[blockIdx.x];
     const SnDesc D = sn[td.sn];
     const int r = D.r, w = D.w;
@@ -464,250 +457,177 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         }
     }
 
-    // loader role of this thread: operand (A rows / B rows), row of the stage, k half
-    const int ld_which = tid >> 7, ld_row = tid & 63, ld_kh = (tid >> 6) & 1;
-    const int l15 = lane & 15, kq = lane >> 4;
+    const int l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
     const bool diag_sub = subrow0 == subcol0;
 
-    const int n_entries = INNER ? 1 : (td.cb1 - td.cb0);
-    for (int base = 0; base < n_entries; base += kPass) {
-        const int cnt_raw = min(kPass, n_entries - base);
-        __syncthreads();  // previous pass fully consumed
-        // ---- evaluate the entries of this pass; keep (in order) those with rows in the tile
-        int cnt;
+    // ---- this wave's update stream
+    int64_t le = 0, e_end = 0;  // next entry the loader enters / end of the list
+    if (wave_on) {
         if (INNER) {
-            if (tid == 0) {
-                e_src[0] = D.px + (int64_t)jb * kTile * r;  // block column jb of the same panel
-                e_rel[0] = -1;
-                e_ld[0] = r;
-                e_K[0] = min(kTile, w - jb * kTile);
-                e_i0[0] = td.row0;
-                e_i1[0] = min(td.row0 + kSub, r);
-                e_i2[0] = min(td.row0 + kTile, r);
-                e_j0[0] = td.col0;
-                e_j1[0] = min(td.col0 + kSub, w);
-                e_j2[0] = min(td.col0 + kTile, w);
-            }
-            __syncthreads();
-            cnt = 1;
+            e_end = 1;
         } else {
-            bool keep = false;
-            ColBlkEntry ce;
-            UpdDesc U;
-            int i0 = 0, i1 = 0, i2 = 0;
-            if (tid < cnt_raw) {
-                ce = colblk[td.cb0 + base + tid];
-                U = upd[ce.upd];
-                lower_bound3(relpos + U.rel, U.m, td.row0, td.row0 + kSub, td.row0 + kTile, i0, i1, i2);
-                keep = i2 > i0;
-            }
-            const unsigned long long bal = __ballot(keep);
-            if (wave < 2 && lane == 0) wcount[wave] = __popcll(bal);
-            __syncthreads();
-            if (keep) {
-                const int pos = (wave ? wcount[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
-                e_src[pos] = U.src;
-                e_rel[pos] = U.rel;
-                e_ld[pos] = U.ld;
-                e_K[pos] = U.K;
-                e_i0[pos] = i0;
-                e_i1[pos] = i1;
-                e_i2[pos] = i2;
-                e_j0[pos] = ce.jlo;
-                e_j1[pos] = ce.jmid;
-                e_j2[pos] = ce.jhi;
-            }
-            cnt = wcount[0] + wcount[1];
-            __syncthreads();
+            le = wptr[td.wp + wave];
+            e_end = wptr[td.wp + wave + 1];
         }
-        if (cnt == 0) continue;
-
-        // ---- loader: chunk (e, k0) -> 8 doubles (+ one relative index) per thread.  The
-        // per-descendant quantities live in registers and are refreshed only when the stream
-        // moves on to the next descendant.
+    }
+    if (le < e_end) {
         struct Chunk {
-            double v[8];
-            int32_t rel;
-            int32_t e, k0;  // e < 0: nothing to store
+            double a0[4], a1[4], b0[4], b1[4];  // MFMA operands of the four k steps
+            int32_t rel;                         // last chunk of an entry: this lane's relative index
+            int32_t kend, last, mn;              // wave-uniform: valid k in the chunk (0: padding of the
+                                                 // stream), last chunk of its entry, window sizes
         };
-        int le = 0, lk = 0;  // next chunk of the stream to load
-        const double* l_src = nullptr;
-        int l_K = 0, l_ld = 0, l_relv = -1;
-        bool l_rv = false;
-        auto loader_enter = [&](int e) {
-            const int base_row = ld_which ? e_j0[e] : e_i0[e];
-            const int nrow = (ld_which ? e_j2[e] : e_i2[e]) - base_row;
-            l_K = e_K[e];
-            l_ld = e_ld[e];
-            l_rv = ld_row < nrow;
-            l_src = L + e_src[e] + base_row + ld_row + (int64_t)(ld_kh * 8) * l_ld;
-            l_relv = -1;
-            if (ld_kh == 0 && l_rv) l_relv = INNER ? (base_row + ld_row) : relpos[e_rel[e] + base_row + ld_row];
+        // loader state (wave-uniform except the lane offsets).  Every chunk issues the same 16
+        // operand loads (+ the relative index): fragments a narrow entry does not have re-read
+        // its last row, k steps past a ragged end re-read column K-1 (masked in the multiply),
+        // chunks behind the end of the stream re-read the last one.  A fixed number of loads
+        // per chunk keeps the s_waitcnt of the multiply exactly kInFlight-1 chunks behind.
+        const double* l_p = G;                   // descendant panel at row lb, column = chunk start
+        int l_K = 0, l_k = 0, l_ld = 0, l_mn = 0;
+        int l_oA0 = 0, l_oA1 = 0, l_oB0 = 0, l_oB1 = 0, l_orel = 0;
+        WaveEntry l_next = {};
+        if (!INNER) l_next = wents[le];
+        auto loader_enter = [&]() {
+            WaveEntry E;
+            if (INNER) {
+                E.src = D.px + (int64_t)jb * kTile * r;  // block column jb of the same panel, identity map
+                E.rel = 0;
+                E.ld = r;
+                E.K = min(kTile, w - jb * kTile);
+                E.ia = subrow0;
+                E.ja = subcol0;
+                E.mn = nrows | (ncols << 8);
+            } else {
+                E = l_next;  // fetched one entry ahead
+                if (le + 1 < e_end) l_next = wents[le + 1];
+            }
+            const int mi = E.mn & 255, nj = E.mn >> 8;
+            l_p = L + E.src;
+            l_K = E.K;
+            l_k = 0;
+            l_ld = E.ld;
+            l_mn = E.mn;
+            l_oA0 = E.ia + min(l15, mi - 1);
+            l_oA1 = E.ia + min(16 + l15, mi - 1);
+            l_oB0 = E.ja + min(l15, nj - 1);
+            l_oB1 = E.ja + min(16 + l15, nj - 1);
+            l_orel = E.rel + (lane < 32 ? E.ia + min(l31, mi - 1) : E.ja + min(l31, nj - 1));
+            ++le;
         };
-        loader_enter(0);
+        bool l_live = true;
+        loader_enter();
         auto issue = [&](Chunk& c) {
-            c.e = -1;
-            if (le >= cnt) return;
-            c.e = le;
-            c.k0 = lk;
-            c.rel = l_relv;
-            const int kb = lk + ld_kh * 8;
+            const int kend = l_live ? min(kKC, l_K - l_k) : 0;
+            c.kend = kend;
+            c.mn = l_mn;
+            c.last = l_live && (l_k + kKC >= l_K);
+            int ko[4];
+            if (kend == kKC) {
 #pragma unroll
+                for (int u = 0; u < 4; ++u) ko[u] = (4 * u + kq) * l_ld;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ko[u] = min(4 * u + kq, max(kend, 1) - 1) * l_ld;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
 #ifdef PARSY_ABL_NOLOAD
-            for (int q = 0; q < 8; ++q) c.v[q] = (double)(kb + q);
+                c.a0[u] = c.a1[u] = c.b0[u] = c.b1[u] = (double)(ko[u]);
 #else
-            for (int q = 0; q < 8; ++q) c.v[q] = (l_rv && kb + q < l_K) ? l_src[(int64_t)q * l_ld] : 0.0;
+                c.a0[u] = l_p[l_oA0 + ko[u]];
+                c.b0[u] = l_p[l_oB0 + ko[u]];
+                c.a1[u] = l_p[l_oA1 + ko[u]];
+                c.b1[u] = l_p[l_oB1 + ko[u]];
 #endif
-            lk += kKC;
-            l_src += (int64_t)kKC * l_ld;
-            if (lk >= l_K) {
-                lk = 0;
-                ++le;
-                if (le < cnt) loader_enter(le);
+            }
+            if (!INNER) c.rel = relpos[l_orel];
+            if (c.last) {
+                if (le < e_end) loader_enter();
+                else l_live = false;
+            } else if (l_live) {
+                l_k += kKC;
+                l_p += (int64_t)kKC * l_ld;
             }
         };
-        auto store = [&](const Chunk& c, int stage) {
-            if (c.e < 0) return;
-            double* __restrict__ S = (ld_which ? Bs[stage] : As[stage]) + ld_row * kLdK + ld_kh * 8;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) S[q] = c.v[q];
-            if (c.k0 == 0 && ld_kh == 0) (ld_which ? relB : relA)[c.e & 3][ld_row] = c.rel;
-        };
 
-        // ---- consumer state of this wave (per-descendant quantities cached in registers)
-        int ce_ = 0, ck = 0;  // chunk of the stream being multiplied
-        int c_K = 0, c_mi = 0, c_nj = 0, c_offA = 0, c_offB = 0;
-        int c_a0 = 0, c_a1 = 0, c_b0 = 0, c_b1 = 0;  // element offsets of this lane's fragment rows
-        bool c_on = false;
-        auto consumer_enter = [&](int e) {
-            c_K = e_K[e];
-            const int i0 = e_i0[e], j0 = e_j0[e];
-            const int ia = wa ? e_i1[e] : i0, ib = wa ? e_i2[e] : e_i1[e];
-            const int ja = wb ? e_j1[e] : j0, jbnd = wb ? e_j2[e] : e_j1[e];
-            c_mi = ib - ia;
-            c_nj = jbnd - ja;
-            c_offA = ia - i0;
-            c_offB = ja - j0;
-            c_on = wave_on && c_mi > 0 && c_nj > 0;
-            c_a0 = min(c_offA + l15, kTile - 1) * kLdK + kq;
-            c_a1 = min(c_offA + 16 + l15, kTile - 1) * kLdK + kq;
-            c_b0 = min(c_offB + l15, kTile - 1) * kLdK + kq;
-            c_b1 = min(c_offB + 16 + l15, kTile - 1) * kLdK + kq;
-        };
-        consumer_enter(0);
         double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-        auto consume = [&](int stage) {
-            const int e = ce_;
-            if (c_on) {
-                const bool two_r = c_mi > 16, two_c = c_nj > 16;
-                const double* __restrict__ SA = As[stage];
-                const double* __restrict__ SB = Bs[stage];
-                const int kend = min(kKC, c_K - ck);
+        auto consume = [&](const Chunk& c) {
+            const int mi = c.mn & 255, nj = c.mn >> 8;
+            const bool two_r = mi > 16, two_c = nj > 16;
+            const bool up = two_c && !diag_sub;  // rows 0..15 x columns 16..31: strictly upper in a diagonal sub-tile
+            // straight-line on purpose (no early exit on a ragged or padding chunk): k past the
+            // end contributes 0 through the A operand, B holds finite panel values
 #pragma unroll
-                for (int u = 0; u < kKC / 4; ++u) {
-                    if (4 * u >= kend) break;
-                    const double a0 = SA[c_a0 + 4 * u], b0 = SB[c_b0 + 4 * u];
-                    const double a1 = SA[c_a1 + 4 * u], b1 = SB[c_b1 + 4 * u];
+            for (int u = 0; u < 4; ++u) {
+                const bool kin = 4 * u + kq < c.kend;
+                const double a0 = kin ? c.a0[u] : 0.0, a1 = kin ? c.a1[u] : 0.0;
 #ifdef PARSY_ABL_NOMFMA
-                    c00[0] += a0 * b0; c01[0] += a0 * b1; c10[0] += a1 * b0; c11[0] += a1 * b1;
-                    continue;
+                c00[0] += a0 * c.b0[u] + a1 * c.b1[u];
+                continue;
 #endif
-                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
-                    if (two_c) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
-                    if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
-                    if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
-                }
+                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b0[u], c00, 0, 0, 0);
+                if (up) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b1[u], c01, 0, 0, 0);
+                if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b0[u], c10, 0, 0, 0);
+                if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b1[u], c11, 0, 0, 0);
+            }
 #ifdef PARSY_ABL_NOSCATTER
-                if (false) {
+            if (false) {
 #else
-                if (ck + kKC >= c_K) {
+            if (c.last) {
 #endif
-                    const bool two_r = c_mi > 16, two_c = c_nj > 16;
-                    // last chunk of this descendant: scatter-subtract through the relative
-                    // indices (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
-                    // row = (lane >> 4) + 4 * reg).  ds_add_f64 without return: the wave owns
-                    // Tw and its LDS operations execute in order, so the sum order is fixed.
-                    const int32_t* __restrict__ ra = relA[e & 3] + c_offA;
-                    const int32_t* __restrict__ rb = relB[e & 3] + c_offB;
-                    int rC[2];
+                // scatter-subtract through the relative indices (C/D layout of
+                // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg).  Lanes 0..31
+                // hold the sub-tile row of descendant row `lane` of the row window, lanes 32..63 the
+                // sub-tile column of descendant row `lane - 32` of the column window (-1: outside).
+                const int relv = (l31 < (lane < 32 ? mi : nj)) ? (INNER ? l31 : c.rel - (lane < 32 ? subrow0 : subcol0)) : -1;
+                const int C0 = __builtin_amdgcn_ds_bpermute((32 + l15) * 4, relv);
+                const int C1 = __builtin_amdgcn_ds_bpermute((48 + l15) * 4, relv);
+                // Cells outside the update (padding of the 16x16 fragments, the strict upper triangle
+                // of a diagonal sub-tile) subtract 0.0 from a padding element of the sub-tile (row 32
+                // of column lane & 31): branch-free, and the dummies do not pile onto one address.
+                const int dummy = l31 * kLdSub + kSub;
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc) {
-                        const int jl = tc * 16 + l15;
-                        rC[tc] = (jl < c_nj) ? rb[jl] - subcol0 : -1;
+                for (int v = 0; v < 4; ++v) {
+                    const int R0 = __builtin_amdgcn_ds_bpermute((kq + 4 * v) * 4, relv);
+                    const bool ok00 = R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0);
+                    lds_sub(&Tw[ok00 ? C0 * kLdSub + R0 : dummy], ok00 ? c00[v] : 0.0);
+                    if (up) {
+                        const bool ok01 = R0 >= 0 && C1 >= 0;
+                        lds_sub(&Tw[ok01 ? C1 * kLdSub + R0 : dummy], ok01 ? c01[v] : 0.0);
                     }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int il0 = kq + 4 * v, il1 = 16 + kq + 4 * v;
-                        const int R0 = (il0 < c_mi) ? ra[il0] - subrow0 : -1;
-                        const int R1 = (il1 < c_mi) ? ra[il1] - subrow0 : -1;
-                        const int C0 = rC[0], C1 = rC[1];
-                        // Cells outside the update (padding of the 16x16 fragments, the strict upper
-                        // triangle of a diagonal sub-tile) subtract 0.0 from a padding element of the
-                        // sub-tile (row 32 of column lane & 31): branch-free, and the dummies are
-                        // spread so they do not pile onto one address.
-                        const int dummy = (lane & 31) * kLdSub + kSub;
-                        const bool ok00 = R0 >= 0 && C0 >= 0 && (!diag_sub || R0 >= C0);
-                        lds_sub(&Tw[ok00 ? C0 * kLdSub + R0 : dummy], ok00 ? c00[v] : 0.0);
+                    if (two_r) {
+                        const int R1 = __builtin_amdgcn_ds_bpermute((16 + kq + 4 * v) * 4, relv);
+                        const bool ok10 = R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0);
+                        lds_sub(&Tw[ok10 ? C0 * kLdSub + R1 : dummy], ok10 ? c10[v] : 0.0);
                         if (two_c) {
-                            const bool ok01 = R0 >= 0 && C1 >= 0 && (!diag_sub || R0 >= C1);
-                            lds_sub(&Tw[ok01 ? C1 * kLdSub + R0 : dummy], ok01 ? c01[v] : 0.0);
-                        }
-                        if (two_r) {
-                            const bool ok10 = R1 >= 0 && C0 >= 0 && (!diag_sub || R1 >= C0);
-                            lds_sub(&Tw[ok10 ? C0 * kLdSub + R1 : dummy], ok10 ? c10[v] : 0.0);
-                        }
-                        if (two_r && two_c) {
                             const bool ok11 = R1 >= 0 && C1 >= 0 && (!diag_sub || R1 >= C1);
                             lds_sub(&Tw[ok11 ? C1 * kLdSub + R1 : dummy], ok11 ? c11[v] : 0.0);
                         }
                     }
-                    c00 = {0, 0, 0, 0};
-                    c01 = {0, 0, 0, 0};
-                    c10 = {0, 0, 0, 0};
-                    c11 = {0, 0, 0, 0};
                 }
-            }
-            ck += kKC;
-            if (ck >= c_K) {
-                ck = 0;
-                ++ce_;
-                if (ce_ < cnt) consumer_enter(ce_);
+                c00 = {0, 0, 0, 0};
+                c01 = {0, 0, 0, 0};
+                c10 = {0, 0, 0, 0};
+                c11 = {0, 0, 0, 0};
             }
         };
 
-        // ---- pump: chunk p is multiplied from stage p & 1 while chunk p+1 is written to the
-        // other stage and chunks p+2, p+3 are in flight in registers
+        // rounds of kInFlight chunks, one back edge: the stream is done when the last chunk of
+        // a round is padding (kend == 0; padding multiplies by zero and scatters nothing)
         Chunk q[kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) issue(q[i]);
-        store(q[0], 0);
-        __syncthreads();
-        int p = 0;
-#ifdef PARSY_STAMPS
-        unsigned long long ts = 0, ti = 0, tc = 0, tb = 0, t0, t1, t2, t3, t4, tl0 = wall_clock64();
-#define PH(a, b, c, d) do { t0 = wall_clock64(); a; t1 = wall_clock64(); b; t2 = wall_clock64(); c; t3 = wall_clock64(); d; t4 = wall_clock64(); ts += t1 - t0; ti += t2 - t1; tc += t3 - t2; tb += t4 - t3; } while (0)
-#else
-#define PH(a, b, c, d) do { a; b; c; d; } while (0)
-#endif
-        // iteration p: chunk p+1 (registers -> other stage), a new chunk p+kInFlight is issued
-        // into the registers chunk p occupied, chunk p is multiplied
         bool more = true;
         while (more) {
 #pragma unroll
             for (int sidx = 0; sidx < kInFlight; ++sidx) {
-                if (!more) break;
-                PH(store(q[(sidx + 1) % kInFlight], (p + 1) & 1), issue(q[sidx]), consume(p & 1), __syncthreads());
-                ++p;
-                more = ce_ < cnt;
+                consume(q[sidx]);
+                if (sidx == kInFlight - 1) more = q[sidx].kend != 0;
+                issue(q[sidx]);
             }
         }
-#ifdef PARSY_STAMPS
-        if (!INNER && stamp_wg && tid == 0) {
-            g_stamps[16] = ts; g_stamps[17] = ti; g_stamps[18] = tc; g_stamps[19] = tb;
-            g_stamps[20] = wall_clock64() - tl0; g_stamps[21] = p; g_stamps[22] = cnt;
-        }
-#endif
     }
+    __syncthreads();
 
     if (stamp_wg) STAMP(9);
     // The block column that has just received its last update is finished here: its diagonal
@@ -804,7 +724,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     }
     if (td.row0 == td.col0 + kTile) STAMP(25);
     // ---- X := B inv(Ljj') on the rows of the LDS tile
-    double* __restrict__ Dg = &stage[0][0];  // 64 x 65 doubles, the update stream is finished
+    double* __restrict__ Dg = dgbuf;
     double* __restrict__ invd = colbuf;
     {
         double dtmp[kTile * kTile / kThreads];
@@ -890,12 +810,12 @@ void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner,
                        int finalize, int epoch, double* L, hipStream_t stream) {
     if (count <= 0) return;
     if (inner)
-        hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
+        hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
+                           P.wave_entries, P.wave_ptr, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
                            fused, finalize);
     else
-        hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.upd,
-                           P.relpos, P.colblk, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
+        hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
+                           P.wave_entries, P.wave_ptr, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
                            fused, finalize);
 }
 

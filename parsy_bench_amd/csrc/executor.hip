@@ -58,7 +58,8 @@ static int plan_upload(parsy_plan* pl) {
     if (upload(pl, S.relpos, pl->dp.relpos, false)) return -1;
     if (upload(pl, S.a_dst, pl->dp.a_dst, false)) return -1;
     if (upload(pl, S.rows, pl->dp.rows, false)) return -1;
-    if (upload(pl, S.colblk, pl->dp.colblk, false)) return -1;
+    if (upload(pl, S.wave_entries, pl->dp.wave_entries, false)) return -1;
+    if (upload(pl, S.wave_ptr, pl->dp.wave_ptr, false)) return -1;
     {
         void* d = nullptr;
         const size_t bytes = std::max<int64_t>(S.n_dslots, 1) * kTile * kTile * sizeof(double);

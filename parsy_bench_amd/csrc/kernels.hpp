@@ -15,7 +15,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* relpos = nullptr;
     const int64_t* a_dst = nullptr;
     const int32_t* rows = nullptr;
-    const ColBlkEntry* colblk = nullptr;
+    const WaveEntry* wave_entries = nullptr;  // update streams of the tile kernel
+    const int64_t* wave_ptr = nullptr;
     const int32_t* small_list = nullptr;
     const TileDesc* tiles = nullptr;
     const PanelDesc* panels = nullptr;

@@ -96,6 +96,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         }
     }
 
+    if (S.relpos.size() > 0x7fffffffULL) throw std::runtime_error("schedule: relative index array exceeds int32");
     std::vector<int> tree(P.sparent, P.sparent + ns);
     level_sets(tree, S.levelPtr, S.levelSet);
     S.nlevels = (int)S.levelPtr.size() - 1;
@@ -103,10 +104,16 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     for (int l = 0; l < S.nlevels; ++l)
         for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) S.level_of[S.levelSet[q]] = l;
 
-    // --- tiled supernodes: scratch slots and per-block-column update lists ----------
-    S.sn_cb0.assign(ns, -1);
+    // --- tiled supernodes: scratch slots and the per-wave update streams ---------------
+    // Every (target, descendant) update is cut along the 32-row windows of the target's tiles:
+    // the descendant rows that fall into row window I32 times those (among its first n1 rows)
+    // that fall into column window J32 are one WaveEntry of sub-tile (I32, J32), I32 >= J32.
+    // Lists keep the reference's update order, so the sum order per entry of L is fixed.
+    S.sn_wp0.assign(ns, -1);
     S.sn_tw0.assign(ns, -1);
-    std::vector<std::vector<ColBlkEntry>> bucket;  // [2*J + phase]
+    struct Group { int32_t win, first, len; };
+    std::vector<Group> groups;
+    std::vector<int64_t> cursor;
     for (int t = 0; t < ns; ++t) {
         SnDesc& T = S.sn[t];
         if (is_small(T)) {
@@ -114,58 +121,69 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             continue;
         }
         S.n_big++;
-        const int nbc = ceil_div(T.w, kTile);
+        const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
         T.dslot = (int32_t)S.n_dslots;
         S.n_dslots += nbc;
         for (int jb = 1; jb < nbc; ++jb) {
             const double K = (double)jb * kTile, wb = std::min(kTile, T.w - jb * kTile);
             S.inner_flops += K * wb * (wb + 1) + 2.0 * K * (double)(T.r - jb * kTile - wb) * wb;
         }
-        bucket.assign(2 * nbc, {});
-        for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
-            const UpdDesc& U = S.upd[u];
-            // early: the descendant is complete before the level below the target even starts
-            const int phase = (S.level_of[usn[u]] <= S.level_of[t] - 2) ? 0 : 1;
-            S.tile_update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
-            const int32_t* rel = &S.relpos[U.rel];
-            const int jfirst = rel[0] / kTile, jlast = rel[U.n1 - 1] / kTile;
-            for (int J = jfirst; J <= jlast; ++J) {
-                ColBlkEntry e;
-                e.upd = (int32_t)u;
-                e.jlo = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile) - rel);
-                e.jmid = (int32_t)(std::lower_bound(rel, rel + U.n1, J * kTile + kSub) - rel);
-                e.jhi = (int32_t)(std::lower_bound(rel, rel + U.n1, (J + 1) * kTile) - rel);
-                if (e.jhi > e.jlo) bucket[2 * J + phase].push_back(e);
-            }
-        }
-        // weight of every tile = number of 16-wide k chunks of the updates that reach it
-        const int nbr_t = ceil_div(T.r, kTile);
-        S.sn_tw0[t] = (int64_t)S.tile_w.size();
-        S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr_t * 2, 0);
-        int32_t* tw = &S.tile_w[S.sn_tw0[t]];
-        for (int J = 0; J < nbc; ++J)
-            for (int phase = 0; phase < 2; ++phase)
-                for (const ColBlkEntry& e : bucket[2 * J + phase]) {
-                    const UpdDesc& U = S.upd[e.upd];
-                    const int32_t* rel = &S.relpos[U.rel];
-                    const int chunks = ceil_div(U.K, 16);
-                    int last = -1;
-                    for (int k = 0; k < U.m; ++k) {
-                        const int I = rel[k] / kTile;
-                        if (I != last && I >= J) tw[((size_t)J * nbr_t + I) * 2 + phase] += chunks;
-                        last = I;
+        // key of a list: ((J * nbr + I) * 2 + phase) * 4 + wave
+        const size_t nkeys = (size_t)nbc * nbr * 8;
+        auto for_each_entry = [&](auto&& fn) {
+            for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
+                const UpdDesc& U = S.upd[u];
+                // early: the descendant is complete before the level below the target even starts
+                const int phase = (S.level_of[usn[u]] <= S.level_of[t] - 2) ? 0 : 1;
+                const int32_t* rel = &S.relpos[U.rel];
+                groups.clear();
+                for (int k = 0; k < U.m;) {
+                    const int win = rel[k] / kSub;
+                    int k1 = k + 1;
+                    while (k1 < U.m && rel[k1] / kSub == win) ++k1;
+                    groups.push_back(Group{win, k, k1 - k});
+                    k = k1;
+                }
+                for (const Group& gc : groups) {
+                    if (gc.first >= U.n1) break;
+                    const int nj = std::min(gc.len, U.n1 - gc.first);
+                    for (const Group& gr : groups) {
+                        if (gr.win < gc.win) continue;
+                        const int I = gr.win / 2, J = gc.win / 2;
+                        const size_t key = (((size_t)J * nbr + I) * 2 + phase) * 4 + (gr.win & 1) * 2 + (gc.win & 1);
+                        fn(key, U, gr.first, gr.len, gc.first, nj);
                     }
                 }
-        // cb_ptr holds, per block column, [early begin, late begin] and one closing entry
-        S.sn_cb0[t] = (int64_t)S.cb_ptr.size();
-        for (int J = 0; J < nbc; ++J)
-            for (int phase = 0; phase < 2; ++phase) {
-                S.cb_ptr.push_back((int64_t)S.colblk.size());
-                S.colblk.insert(S.colblk.end(), bucket[2 * J + phase].begin(), bucket[2 * J + phase].end());
             }
-        S.cb_ptr.push_back((int64_t)S.colblk.size());
+        };
+        cursor.assign(nkeys + 1, 0);
+        for_each_entry([&](size_t key, const UpdDesc&, int, int, int, int) { cursor[key + 1]++; });
+        const int64_t base = (int64_t)S.wave_entries.size();
+        for (size_t k = 0; k < nkeys; ++k) cursor[k + 1] += cursor[k];
+        S.sn_wp0[t] = (int64_t)S.wave_ptr.size();
+        for (size_t k = 0; k <= nkeys; ++k) S.wave_ptr.push_back(base + cursor[k]);
+        S.wave_entries.resize((size_t)(base + cursor[nkeys]));
+        for_each_entry([&](size_t key, const UpdDesc& U, int ia, int mi, int ja, int nj) {
+            S.wave_entries[(size_t)(base + cursor[key]++)] =
+                WaveEntry{U.src, (int32_t)U.rel, U.ld, U.K, ia, ja, mi | (nj << 8)};
+        });
+        for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
+            const UpdDesc& U = S.upd[u];
+            S.tile_update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
+        }
+        // weight of every tile = 16-wide k chunks of its longest wave stream
+        S.sn_tw0[t] = (int64_t)S.tile_w.size();
+        S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr * 2, 0);
+        int32_t* tw = &S.tile_w[S.sn_tw0[t]];
+        const int64_t* wp = &S.wave_ptr[S.sn_wp0[t]];
+        for (size_t tp = 0; tp < (size_t)nbc * nbr * 2; ++tp)
+            for (int q = 0; q < 4; ++q) {
+                int64_t chunks = 0;
+                for (int64_t e = wp[tp * 4 + q]; e < wp[tp * 4 + q + 1]; ++e)
+                    chunks += ceil_div(S.wave_entries[(size_t)e].K, 16);
+                tw[tp] = std::max<int32_t>(tw[tp], (int32_t)std::min<int64_t>(chunks, INT32_MAX));
+            }
     }
-    if (S.colblk.size() > 0x7fffffffULL) throw std::runtime_error("schedule: block-column lists exceed int32");
 
     build_launches(S, active);
 }
@@ -238,8 +256,6 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     maxnb = std::max(maxnb, nbc);
                     const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
                     for (int J = 0; J < nbc; ++J) {
-                        const int64_t c0 = S.cb_ptr[S.sn_cb0[t] + 2 * J + phase];
-                        const int64_t c1 = S.cb_ptr[S.sn_cb0[t] + 2 * J + phase + 1];
                         for (int I = J; I < nbr; ++I) {
                             const int32_t wgt = tw[((size_t)J * nbr + I) * 2 + phase];
                             // tiles nothing reaches are skipped, except (late launch) those of block
@@ -247,8 +263,8 @@ void build_launches(Schedule& S, const uint8_t* active) {
                             const bool needed = wgt > 0 || (phase == 1 && J == 0 && (I == 0 || L.fused));
                             if (!needed) continue;
                             const int32_t prio = (phase == 1 && J == 0 && I == 0) ? INT32_MAX : wgt;
-                            wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, (int32_t)c0,
-                                                         (int32_t)(wgt > 0 ? c1 : c0), 0}});
+                            wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, 0,
+                                                         S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2 + phase) * 4}});
                         }
                     }
                 }
@@ -300,7 +316,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                         for (int J = jb + 1; J < nbc; ++J)
                             for (int I = J; I < nbr; ++I) {
                                 const int cls = (J == jb + 1) ? (I == J ? 0 : 1) : 2;
-                                if (cls == pass) S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, 0, 0});
+                                if (cls == pass) S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, -1});
                             }
                     }
                 Li.count = (int32_t)S.tiles.size() - Li.first;

@@ -61,16 +61,20 @@ struct UpdDesc {      // one per (target, descendant) pair, in the reference's u
     int32_t n1;       // ndrow1: of those, rows inside the target's columns
 };
 
-struct ColBlkEntry {  // update restricted to one 64-wide block column of a target
-    int32_t upd;      // index into UpdDesc
-    int32_t jlo, jmid, jhi;  // descendant rows [jlo,jmid) hit columns [col0,col0+32), [jmid,jhi) the next 32
+struct WaveEntry {    // one (descendant, 32x32 sub-tile) pair of the tile kernel's update stream
+    int64_t src;      // offset in lValues of row lb of the descendant's panel (UpdDesc::src)
+    int32_t rel;      // offset into relpos of row lb (UpdDesc::rel)
+    int32_t ld, K;    // rows and width of the descendant
+    int32_t ia, ja;   // first descendant row (counted from lb) inside the sub-tile's row / column window
+    int32_t mn;       // rows in the row window | rows in the column window << 8  (1..32 each)
 };
 
 struct TileDesc {     // one workgroup of the TILES / INNER kernels
     int32_t sn;
     int32_t row0, col0;   // tile origin inside the panel (multiples of 64, row0 >= col0)
-    int32_t cb0, cb1;     // ColBlkEntry range (TILES only)
     int32_t pad;
+    int64_t wp;           // TILES: wave_ptr[wp + q .. wp + q + 1] = WaveEntry range of wave q (sub-tile
+                          // rows 32*(q>>1).., columns 32*(q&1)..); INNER: unused
 };
 
 struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
@@ -121,7 +125,8 @@ struct Schedule {
     std::vector<int32_t> relpos;
     std::vector<int64_t> a_dst;     // destination in lValues of every A2 entry
     std::vector<int32_t> rows;      // lR
-    std::vector<ColBlkEntry> colblk;
+    std::vector<WaveEntry> wave_entries;  // update streams of the tile kernel, one list per (tile, phase, wave)
+    std::vector<int64_t> wave_ptr;        // ... in the order [supernode][J][I][phase][wave], one closing entry each
 
     // Cholesky launch data
     std::vector<int32_t> small_list;
@@ -144,11 +149,10 @@ struct Schedule {
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches
     std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow
-    std::vector<int64_t> sn_cb0;       // per supernode: first index into cb_ptr (-1: SMALL)
-    std::vector<int64_t> cb_ptr;       // ColBlkEntry ranges per (tiled supernode, block column)
+    std::vector<int64_t> sn_wp0;       // per supernode: first index into wave_ptr (-1: SMALL)
     std::vector<int64_t> sn_tw0;       // per supernode: first index into tile_w (-1: SMALL)
-    std::vector<int32_t> tile_w;       // per (tiled supernode, J, I, phase): 16-wide k chunks of its update stream
-                                       // (phase 0 = early: descendants two or more levels below; 1 = late)
+    std::vector<int32_t> tile_w;       // per (tiled supernode, J, I, phase): 16-wide k chunks of the longest of its
+                                       // four wave streams (phase 0 = early: descendants two or more levels below)
     std::vector<int32_t> level_of;     // etree level of every supernode
 };
 
