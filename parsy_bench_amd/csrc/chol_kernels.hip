@@ -23,12 +23,16 @@ static constexpr int kLdSub = kSub + 1;   // padded leading dimension of a wave'
 static constexpr int kLdDiag = kTile + 1; // padded leading dimension of a diagonal block in LDS
 
 #ifdef PARSY_STAMPS
-// diagnostic build only: phase stamps (100 MHz wall clock) of the last PANEL workgroup 0
-// and the last potrf-ing tile workgroup; read back with parsy_debug_stamps().
+// diagnostic build only: phase stamps (100 MHz wall clock) of the last workgroup that factored
+// the last diagonal tile of a supernode; read back with parsy_debug_stamps().
 __device__ unsigned long long g_stamps[32];
 #define STAMP(i) do { if (threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+// per block column J of the last supernode that ran: times of the diagonal tile (J,J) and the tile below it
+__device__ unsigned long long g_trace[16 * 512];
+#define TRACE(J, i) do { if (threadIdx.x == 0 && (J) < 512) g_trace[(J) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define TRACE(J, i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -281,6 +285,17 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
 // (rows of a 16-row fragment are contiguous: 128-B segments per k), then
 // scatter-subtracted through the relative indices.
 // ---------------------------------------------------------------------------
+// Hand-off accesses of the chain launch (tiles published inside a launch): 8-byte agent-scope
+// relaxed atomics = global_load/store_dwordx2 sc1 -- write-through stores, loads that bypass the
+// CU's L1 -- on both sides, so no release/acquire fence is needed
+// (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void lds_sub(double* p, double v) {
     __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -398,51 +413,75 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
 
 static constexpr int kKC = 16;        // k extent of one chunk of an update stream
 static constexpr int kInFlight = 4;   // chunks in flight per wave (operands prefetched into registers)
+static constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 // One workgroup per 64x64 tile of a panel, one wave per 32x32 sub-tile, and the four waves run
 // their update streams independently (no workgroup barrier until the stream is finished).  A
-// wave's stream -- WaveEntry list built on the host: every descendant with rows in the
-// sub-tile's row AND column window, in update order -- is cut in 16-wide k chunks.  The MFMA
-// operands of a chunk go straight from the descendant's column-major panel into registers
-// (v_mfma_f64_16x16x4_f64: lane = (row & 15, k >> 2 group), 16 consecutive rows per k are one
-// 128-B segment), kInFlight chunks ahead of the multiply; at the end of a descendant the
-// product is scatter-subtracted into the wave's private LDS sub-tile through the relative
-// indices (ds_add_f64 without return; the LDS operations of one wave execute in order, so the
-// summation order is fixed).
-template <bool INNER>
+// wave's stream is cut in 16-wide k chunks.  The MFMA operands of a chunk go straight from the
+// source panel (column-major: 16 consecutive rows per k are one 128-B segment) into registers
+// (v_mfma_f64_16x16x4_f64: lane = (row & 15, k >> 2 group)), kInFlight chunks ahead of the
+// multiply; at the end of an entry the product is scatter-subtracted into the wave's private
+// LDS sub-tile through the relative indices (ds_add_f64 without return; the LDS operations of
+// one wave execute in order, so the summation order is fixed).
+//
+// CHAIN = false (TILES launch): the stream is the early WaveEntry list of the tile (built on the
+//   host: every descendant with rows in the sub-tile's row AND column window, in update order);
+//   the tile is written back.
+// CHAIN = true: the workgroup takes its tile (I,J) from the launch's ticket counter.  Stream:
+//   the late WaveEntry list, then block columns k = 0..J-1 of the tile's own supernode
+//   (left-looking inside the supernode; identity row map), each as soon as tiles (I,k) and (J,k)
+//   are published.  Then the tile is finished -- POTRF (I == J), or TRSM against the published
+//   diagonal tile -- written to the panel write-through and published (flag = epoch; every read of
+//   a published tile is an sc1 load: cdna_hip_programming.md Guideline 16).  Tickets are handed out in
+//   start order and tiles are listed producers-first, so a workgroup only ever waits for
+//   workgroups that have started.  Every wait is bounded; a timeout (or any failure flag) makes
+//   all waiters give up and parsy_factor_status() report < 0.
+template <bool CHAIN>
 __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
                                                             const int32_t* __restrict__ relpos,
                                                             const WaveEntry* __restrict__ wents,
                                                             const int64_t* __restrict__ wptr,
-                                                            const TileDesc* __restrict__ tiles, int jb,
+                                                            const TileDesc* __restrict__ tiles,
                                                             double* __restrict__ L,
-                                                            double* __restrict__ dscratch,
                                                             int* __restrict__ info,
-                                                            int* __restrict__ flags, int epoch,
-                                                            int fused, int finalize) {
+                                                            int* __restrict__ tflags,
+                                                            int* __restrict__ ticket, int epoch) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[kPotrfScratch];
     __shared__ double dgbuf[kTile * kLdDiag];  // diagonal block + its 16x16 inverses (TRSM)
-    __shared__ int32_t s_ok;
+    __shared__ int32_t s_ok, s_task;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileDesc td = tiles[blockIdx.x];
+    int task = blockIdx.x;
+    if (CHAIN) {
+        if (tid == 0) s_task = atomicAdd(ticket, 1);
+        __syncthreads();
+        task = s_task;
+    }
+    const TileDesc td = tiles[task];
     const SnDesc D = sn[td.sn];
     const int r = D.r, w = D.w;
     double* __restrict__ G = L + D.px;
-    const bool stamp_wg = td.row0 == td.col0 && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
+    const int tI = td.row0 / kTile, tJ = td.col0 / kTile, nbc = (w + kTile - 1) / kTile;
+    const bool diag_tile = td.row0 == td.col0;
+    const bool stamp_wg = CHAIN && diag_tile && td.col0 + kTile >= w;  // last diagonal tile of a supernode
     if (stamp_wg) STAMP(8);
+    const bool sub_tile = td.row0 == td.col0 + kTile;
+    if (CHAIN && diag_tile) TRACE(tJ, 0);
+    if (CHAIN && sub_tile) TRACE(tJ, 7);
 
     const int wa = wave >> 1, wb = wave & 1;
     const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
     const bool wave_on = subrow0 < r && subcol0 < w && subrow0 >= subcol0;
     const int nrows = min(kSub, r - subrow0), ncols = min(kSub, w - subcol0);
     double* __restrict__ Tw = T[wave];
+    const int l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
+    const bool diag_sub = subrow0 == subcol0;
 
+    // the sub-tile's current values: loads first, LDS stores after the stream's first loads
+    double tv[kSub * kSub / 64];
     if (wave_on) {
-        // all 16 loads of the lane are issued before the first LDS store
-        double tv[kSub * kSub / 64];
 #pragma unroll
         for (int q = 0; q < kSub * kSub / 64; ++q) {
             const int e = q * 64 + lane;
@@ -450,58 +489,107 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
             tv[q] = in ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
         }
+    }
+    auto store_subtile = [&]() {
 #pragma unroll
         for (int q = 0; q < kSub * kSub / 64; ++q) {
             const int e = q * 64 + lane;
             Tw[(e >> 5) * kLdSub + (e & 31)] = tv[q];
         }
-    }
-
-    const int l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
-    const bool diag_sub = subrow0 == subcol0;
+    };
 
     // ---- this wave's update stream
-    int64_t le = 0, e_end = 0;  // next entry the loader enters / end of the list
+    int64_t le = 0, e_end = 0;       // next external entry / end of the list
+    int l_kint = 0, n_int = 0;       // next internal block column / their number (CHAIN)
     if (wave_on) {
-        if (INNER) {
-            e_end = 1;
-        } else {
-            le = wptr[td.wp + wave];
-            e_end = wptr[td.wp + wave + 1];
-        }
+        le = wptr[td.wp + wave];
+        e_end = wptr[td.wp + wave + 1];
+        if (CHAIN) n_int = tJ;
     }
-    if (le < e_end) {
+    bool gave_up = false;
+    if (le < e_end || n_int > 0) {
         struct Chunk {
             double a0[4], a1[4], b0[4], b1[4];  // MFMA operands of the four k steps
-            int32_t rel;                         // last chunk of an entry: this lane's relative index
+            int32_t rel;                         // this lane's relative index (used with the last chunk)
             int32_t kend, last, mn;              // wave-uniform: valid k in the chunk (0: padding of the
                                                  // stream), last chunk of its entry, window sizes
         };
+        // Internal entries wait for their operands.  kready = number of leading block columns
+        // whose tiles (I,k) and (J,k) are known to be published (acquired).
+        int kready = 0;
+        const int fI = D.tflag0 + tI * nbc, fJ = D.tflag0 + tJ * nbc;  // flags of tiles (I,0..), (J,0..)
+        auto extend_ready = [&]() {  // after a successful wait: take every further published column
+            while (kready < n_int) {
+                const int k = kready + lane;
+                bool ok = false;
+                if (k < n_int) {
+                    ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                    if (!diag_tile)
+                        ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                }
+                const unsigned long long miss = ~__ballot(ok);
+                const int adv = miss ? __builtin_ctzll(miss) : 64;
+                kready += adv;
+                if (adv < 64) break;
+            }
+            // every load of a published tile is an sc1 load: no cache to invalidate; this only keeps
+            // the compiler from moving those loads above the poll
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto ensure_ready = [&](int k) {  // block (bounded) until block column k can be read
+            const unsigned long long t0 = wall_clock64();
+            int spins = 0;
+            for (;;) {
+                // one address per wave and poll: the waiting waves must not flood the L2
+                bool ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                if (!diag_tile)
+                    ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                if (ok) break;
+                if (diag_tile && k == n_int - 1 && spins == 0) TRACE(tJ, 8);
+                if ((spins & 15) == 15 &&
+                    (wall_clock64() - t0 > kSpinTicks ||
+                     __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                    gave_up = true;
+                    return;
+                }
+                if (spins < 8) __builtin_amdgcn_s_sleep(8);
+                else __builtin_amdgcn_s_sleep(48);
+                ++spins;
+            }
+            if (diag_tile && k == n_int - 1) TRACE(tJ, 9);
+            extend_ready();
+            if (diag_tile && k == n_int - 1) TRACE(tJ, 10);
+        };
+
         // loader state (wave-uniform except the lane offsets).  Every chunk issues the same 16
         // operand loads (+ the relative index): fragments a narrow entry does not have re-read
         // its last row, k steps past a ragged end re-read column K-1 (masked in the multiply),
         // chunks behind the end of the stream re-read the last one.  A fixed number of loads
         // per chunk keeps the s_waitcnt of the multiply exactly kInFlight-1 chunks behind.
-        const double* l_p = G;                   // descendant panel at row lb, column = chunk start
+        const double* l_p = G;                   // source panel at row lb, column = chunk start
         int l_K = 0, l_k = 0, l_ld = 0, l_mn = 0;
-        int l_oA0 = 0, l_oA1 = 0, l_oB0 = 0, l_oB1 = 0, l_orel = 0;
+        unsigned l_oA0 = 0, l_oA1 = 0, l_oB0 = 0, l_oB1 = 0, l_orel = 0;  // row offsets of the lane's fragment rows
         WaveEntry l_next = {};
-        if (!INNER) l_next = wents[le];
+        if (le < e_end) l_next = wents[le];
+        bool l_live = true;
         auto loader_enter = [&]() {
             WaveEntry E;
-            if (INNER) {
-                E.src = D.px + (int64_t)jb * kTile * r;  // block column jb of the same panel, identity map
-                E.rel = 0;
-                E.ld = r;
-                E.K = min(kTile, w - jb * kTile);
-                E.ia = subrow0;
-                E.ja = subcol0;
-                E.mn = nrows | (ncols << 8);
-            } else {
+            if (le < e_end) {
                 E = l_next;  // fetched one entry ahead
                 if (le + 1 < e_end) l_next = wents[le + 1];
+                ++le;
+            } else {
+                // block column l_kint of the tile's own supernode, identity row map
+                E.src = D.px + (int64_t)l_kint * kTile * r;
+                E.rel = 0;
+                E.ld = r;
+                E.K = kTile;
+                E.ia = subrow0;
+                E.ja = subcol0;
+                E.mn = nrows | (ncols << 8) | (1 << 16);
+                ++l_kint;
             }
-            const int mi = E.mn & 255, nj = E.mn >> 8;
+            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
             l_p = L + E.src;
             l_K = E.K;
             l_k = 0;
@@ -512,16 +600,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             l_oB0 = E.ja + min(l15, nj - 1);
             l_oB1 = E.ja + min(16 + l15, nj - 1);
             l_orel = E.rel + (lane < 32 ? E.ia + min(l31, mi - 1) : E.ja + min(l31, nj - 1));
-            ++le;
         };
-        bool l_live = true;
-        loader_enter();
+        // The loader never enters a block column that is not known to be published: it stalls
+        // (the stream runs on padding) and the blocking wait happens at the top of a round.
+        bool l_stalled = false;
+        if (le >= e_end) ensure_ready(0);
+        if (gave_up) l_live = false;
+        else loader_enter();
         auto issue = [&](Chunk& c) {
             const int kend = l_live ? min(kKC, l_K - l_k) : 0;
             c.kend = kend;
             c.mn = l_mn;
             c.last = l_live && (l_k + kKC >= l_K);
-            int ko[4];
+#ifdef PARSY_ABL_NOLOAD
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c.a0[u] = c.a1[u] = c.b0[u] = c.b1[u] = (double)(kend + u);
+#else
+            // One block of loads for every kind of chunk.  In the chain launch they are all sc1 loads
+            // (block columns of the tile's own supernode are published during the launch; descendants'
+            // panels read the same way cost nothing extra: sc1 only bypasses the CU's L1).
+            unsigned ko[4];
             if (kend == kKC) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ko[u] = (4 * u + kq) * l_ld;
@@ -531,19 +629,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-#ifdef PARSY_ABL_NOLOAD
-                c.a0[u] = c.a1[u] = c.b0[u] = c.b1[u] = (double)(ko[u]);
-#else
-                c.a0[u] = l_p[l_oA0 + ko[u]];
-                c.b0[u] = l_p[l_oB0 + ko[u]];
-                c.a1[u] = l_p[l_oA1 + ko[u]];
-                c.b1[u] = l_p[l_oB1 + ko[u]];
-#endif
+                if (CHAIN) {
+                    c.a0[u] = ld_sc1(l_p + l_oA0 + ko[u]);
+                    c.b0[u] = ld_sc1(l_p + l_oB0 + ko[u]);
+                    c.a1[u] = ld_sc1(l_p + l_oA1 + ko[u]);
+                    c.b1[u] = ld_sc1(l_p + l_oB1 + ko[u]);
+                } else {
+                    c.a0[u] = l_p[l_oA0 + ko[u]];
+                    c.b0[u] = l_p[l_oB0 + ko[u]];
+                    c.a1[u] = l_p[l_oA1 + ko[u]];
+                    c.b1[u] = l_p[l_oB1 + ko[u]];
+                }
             }
-            if (!INNER) c.rel = relpos[l_orel];
+#endif
+            c.rel = relpos[l_orel];
             if (c.last) {
-                if (le < e_end) loader_enter();
-                else l_live = false;
+                if (le < e_end || l_kint < kready) {
+                    loader_enter();
+                } else {
+                    l_live = false;
+                    l_stalled = l_kint < n_int;
+                }
             } else if (l_live) {
                 l_k += kKC;
                 l_p += (int64_t)kKC * l_ld;
@@ -552,23 +658,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 
         double4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
         auto consume = [&](const Chunk& c) {
-            const int mi = c.mn & 255, nj = c.mn >> 8;
+            const int mi = c.mn & 255, nj = (c.mn >> 8) & 255;
             const bool two_r = mi > 16, two_c = nj > 16;
             const bool up = two_c && !diag_sub;  // rows 0..15 x columns 16..31: strictly upper in a diagonal sub-tile
-            // straight-line on purpose (no early exit on a ragged or padding chunk): k past the
-            // end contributes 0 through the A operand, B holds finite panel values
+            if (c.kend > 0) {
+                // k past a ragged end contributes 0 through the A operand (B holds finite panel values)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool kin = 4 * u + kq < c.kend;
-                const double a0 = kin ? c.a0[u] : 0.0, a1 = kin ? c.a1[u] : 0.0;
+                for (int u = 0; u < 4; ++u) {
+                    const bool kin = 4 * u + kq < c.kend;
+                    const double a0 = kin ? c.a0[u] : 0.0, a1 = kin ? c.a1[u] : 0.0;
 #ifdef PARSY_ABL_NOMFMA
-                c00[0] += a0 * c.b0[u] + a1 * c.b1[u];
-                continue;
+                    c00[0] += a0 * c.b0[u] + a1 * c.b1[u];
+                    continue;
 #endif
-                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b0[u], c00, 0, 0, 0);
-                if (up) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b1[u], c01, 0, 0, 0);
-                if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b0[u], c10, 0, 0, 0);
-                if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b1[u], c11, 0, 0, 0);
+                    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b0[u], c00, 0, 0, 0);
+                    if (up) c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c.b1[u], c01, 0, 0, 0);
+                    if (two_r) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b0[u], c10, 0, 0, 0);
+                    if (two_r && two_c) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c.b1[u], c11, 0, 0, 0);
+                }
             }
 #ifdef PARSY_ABL_NOSCATTER
             if (false) {
@@ -577,9 +684,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 #endif
                 // scatter-subtract through the relative indices (C/D layout of
                 // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg).  Lanes 0..31
-                // hold the sub-tile row of descendant row `lane` of the row window, lanes 32..63 the
-                // sub-tile column of descendant row `lane - 32` of the column window (-1: outside).
-                const int relv = (l31 < (lane < 32 ? mi : nj)) ? (INNER ? l31 : c.rel - (lane < 32 ? subrow0 : subcol0)) : -1;
+                // hold the sub-tile row of source row `lane` of the row window, lanes 32..63 the
+                // sub-tile column of source row `lane - 32` of the column window (-1: outside).
+                const bool ident = (c.mn >> 16) != 0;
+                const int relv = (l31 < (lane < 32 ? mi : nj))
+                                     ? (ident ? l31 : c.rel - (lane < 32 ? subrow0 : subcol0)) : -1;
                 const int C0 = __builtin_amdgcn_ds_bpermute((32 + l15) * 4, relv);
                 const int C1 = __builtin_amdgcn_ds_bpermute((48 + l15) * 4, relv);
                 // Cells outside the update (padding of the 16x16 fragments, the strict upper triangle
@@ -612,49 +721,77 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             }
         };
 
-        // rounds of kInFlight chunks, one back edge: the stream is done when the last chunk of
-        // a round is padding (kend == 0; padding multiplies by zero and scatters nothing)
+        // rounds of kInFlight chunks, one back edge; the stream is done when a round issued
+        // nothing but padding (kend == 0: multiplies nothing, scatters nothing)
         Chunk q[kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) issue(q[i]);
+        store_subtile();
+        if (stamp_wg) STAMP(15);
         bool more = true;
         while (more) {
+            // the loader passes at most kInFlight entries per round: make sure the next block
+            // column of the supernode is published before it gets there
+            if (CHAIN && l_kint < n_int && l_kint >= kready && (l_stalled || e_end - le <= kInFlight)) {
+                ensure_ready(l_kint);
+                if (l_stalled && !gave_up) {
+                    loader_enter();
+                    l_live = true;
+                }
+                l_stalled = false;
+                if (gave_up) {  // abandon the rest of the stream
+                    l_live = false;
+                    l_kint = n_int;
+                    le = e_end;
+                }
+            }
+            more = false;
 #pragma unroll
             for (int sidx = 0; sidx < kInFlight; ++sidx) {
                 consume(q[sidx]);
-                if (sidx == kInFlight - 1) more = q[sidx].kend != 0;
                 issue(q[sidx]);
+                more = more || q[sidx].kend != 0;
             }
+            more = more || l_stalled;
+            if (CHAIN && diag_tile && l_kint == n_int) TRACE(tJ, 11 + (more ? 0 : 1));
         }
+    } else if (wave_on) {
+        store_subtile();
     }
+    if (gave_up) atomicMin(info, -1);
     __syncthreads();
-
     if (stamp_wg) STAMP(9);
-    // The block column that has just received its last update is finished here: its diagonal
-    // tile is factored on the spot and parked in a scratch slot (FIXUP copies it into the
-    // panel); in a fused launch the tiles below it wait for that block and do their TRSM
-    // straight out of LDS, otherwise PANEL does it in the next launch.
-    const bool col_final = finalize && (INNER ? td.col0 == (jb + 1) * kTile : td.col0 == 0);
-    const bool diag_tile = td.row0 == td.col0;
-    const bool trsm_here = fused && col_final && !diag_tile;
+    if (CHAIN && diag_tile) TRACE(tJ, 1);
+
     auto write_back = [&](int min_row) {  // min_row: first row of the TILE that is written
         if (wave_on) {
             for (int e = lane; e < kSub * kSub; e += 64) {
                 const int cc = e >> 5, rr = e & 31;
-                if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc) && kSub * wa + rr >= min_row)
-                    G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] = Tw[cc * kLdSub + rr];
+                if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc) && kSub * wa + rr >= min_row) {
+                    double* dst = &G[(int64_t)(subcol0 + cc) * r + subrow0 + rr];
+                    if (CHAIN) st_sc1(dst, Tw[cc * kLdSub + rr]);
+                    else *dst = Tw[cc * kLdSub + rr];
+                }
             }
         }
     };
-    if (!trsm_here) write_back(0);
-    if (!col_final) return;
+    if (!CHAIN) {
+        write_back(0);
+        return;
+    }
+    auto publish = [&]() {
+        // the tile was stored write-through (sc1): every storing wave drains its stores, the
+        // workgroup meets, one lane raises the tile's flag (Guideline 16, R1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&tflags[D.tflag0 + tI * nbc + tJ], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const int nb = min(kTile, w - td.col0);
     int trsm_min_row = 0;
-    const int slot_id = D.dslot + td.col0 / kTile;
-    double* __restrict__ slot = dscratch + (int64_t)slot_id * (kTile * kTile);
 
     if (diag_tile) {
-        __syncthreads();
         STAMP(10);
         const int ti = tid & 15, tj = tid >> 4;
         double a[4][4];
@@ -671,74 +808,72 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         STAMP(11);
         potrf64_regs(a, colbuf, ti, tj, nb, bad);
         STAMP(12);
+        TRACE(tJ, 2);
         if (bad) atomicMin(info, D.c0 + td.col0 + bad);  // only threads that saw a bad pivot
+        // the factored block goes to the panel (zeros above the diagonal, as the layout wants)
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri) {
                 const int i = 4 * ti + ri, c = 4 * tj + ci;
-                slot[c * kTile + i] = (c < nb && i < nb && i >= c) ? a[ri][ci] : 0.0;
+                if (c < nb && i < nb) st_sc1(&G[(int64_t)(td.col0 + c) * r + td.col0 + i], (i >= c) ? a[ri][ci] : 0.0);
             }
-        if (fused) {
-            // publish (agent-scope release, cdna_hip_programming.md Guideline 16): every storing
-            // wave drains its stores, the workgroup meets, one lane releases and raises the flag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&flags[slot_id], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        STAMP(13);
         // a block column narrower than the tile leaves rows of the panel below the diagonal
-        // block inside this very tile: solve them here (PANEL does it when not fused)
-        if (!(fused && nb < kTile && td.row0 + nb < r)) return;
-        trsm_min_row = nb;
-        __syncthreads();  // the parked block (global) is visible to the whole workgroup
-    } else if (!trsm_here) {
-        return;
-    } else if (tid == 0) {
-        if (td.row0 == td.col0 + kTile) STAMP(24);
-        // ---- wait for the parked diagonal block (bounded)
-        const unsigned long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(&flags[slot_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(16);
+        // block inside this very tile: solve them here before publishing
+        if (!(nb < kTile && td.row0 + nb < r)) {
+            publish();
+            STAMP(13);
+            TRACE(tJ, 3);
+            return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        trsm_min_row = nb;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ok = ok;
-    }
-    if (!diag_tile) {
+        __syncthreads();  // the factored block (global) is visible to the whole workgroup
+    } else {
+        if (tid == 0) {
+            // ---- wait for the diagonal tile of this block column (bounded)
+            const unsigned long long t0 = wall_clock64();
+            int ok = 1;
+            while (__hip_atomic_load(&tflags[D.tflag0 + tJ * nbc + tJ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                   epoch) {
+                if (wall_clock64() - t0 > kSpinTicks ||
+                    __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_ok = ok;
+        }
         __syncthreads();
+        if (sub_tile) TRACE(tJ, 4);
         if (!s_ok) {
-            if (tid == 0) atomicMin(info, -1);  // status < 0: a fused wait timed out
+            if (tid == 0) atomicMin(info, -1);  // status < 0: a wait timed out / was abandoned
             write_back(0);
+            publish();  // (so that nobody else waits for this tile)
             return;
         }
     }
-    if (td.row0 == td.col0 + kTile) STAMP(25);
     // ---- X := B inv(Ljj') on the rows of the LDS tile
     double* __restrict__ Dg = dgbuf;
     double* __restrict__ invd = colbuf;
     {
+        const double* __restrict__ DB = G + (int64_t)td.col0 * r + td.col0;  // factored diagonal block, ld r
         double dtmp[kTile * kTile / kThreads];
 #pragma unroll
-        for (int q = 0; q < kTile * kTile / kThreads; ++q) dtmp[q] = slot[q * kThreads + tid];
+        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+            const int e = q * kThreads + tid;
+            const int c = e >> 6, i = e & 63;
+            dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * r + i]) : 0.0;
+        }
 #pragma unroll
         for (int q = 0; q < kTile * kTile / kThreads; ++q) {
             const int e = q * kThreads + tid;
             Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
         }
-        if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / slot[tid * kTile + tid] : 1.0;
+        if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * r + tid]) : 1.0;
     }
     __syncthreads();
-    if (td.row0 == td.col0 + kTile) STAMP(26);
     // inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
     // transposed into the (unused) strict upper triangle of the same sub-block:
     // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  The TRSM below is then all products
@@ -795,145 +930,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         }
     }
     __syncthreads();
-    if (td.row0 == td.col0 + kTile) STAMP(27);
+    if (sub_tile) TRACE(tJ, 5);
     write_back(trsm_min_row);
-    if (td.row0 == td.col0 + kTile) STAMP(28);
+    publish();
+    if (sub_tile) TRACE(tJ, 6);
 }
 
 #ifdef PARSY_STAMPS
 extern "C" void parsy_debug_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
 }
+extern "C" void parsy_debug_trace(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 16 * 512);
+}
 #endif
 
-void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
-                       int finalize, int epoch, double* L, hipStream_t stream) {
+void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
-    if (inner)
-        hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                           P.wave_entries, P.wave_ptr, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
-                           fused, finalize);
-    else
-        hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                           P.wave_entries, P.wave_ptr, P.tiles + first, jb, L, P.dscratch, P.info, P.flags, epoch,
-                           fused, finalize);
+    hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
+                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, (int*)nullptr, 0);
 }
 
-// ---------------------------------------------------------------------------
-// PANEL: TRSM of one 128-row chunk below diagonal block jb, staged in LDS.  The
-// factored diagonal block is read from its scratch slot, where the tile kernel parked
-// it (nobody rewrites the slot during this launch).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_chol_panel(const SnDesc* __restrict__ sn,
-                                                         const PanelDesc* __restrict__ pds,
-                                                         double* __restrict__ L,
-                                                         const double* __restrict__ dscratch) {
-    __shared__ double Dg[kTile * kLdDiag];
-    __shared__ double invd[kTile];
-    __shared__ double Bs[kTile][kPanelRows + 1];
-    const int tid = threadIdx.x;
-    const PanelDesc pd = pds[blockIdx.x];
-    const SnDesc D = sn[pd.sn];
-    const int r = D.r, cb = pd.jb * kTile, wbk = min(kTile, D.w - cb);
-    double* __restrict__ G = L + D.px;
-    if (blockIdx.x == 0) STAMP(0);
-
-    // all loads of the chunk are issued before the first LDS store (one latency, not 32)
-    const double* __restrict__ slot = dscratch + (int64_t)(D.dslot + pd.jb) * (kTile * kTile);
-    {
-        constexpr int kPer = kTile * kPanelRows / kThreads;  // 32
-        double tmp[kPer], dtmp[kTile * kTile / kThreads];
-        const int rr = tid & (kPanelRows - 1), chalf = tid >> 7;
-        const int row = pd.row0 + rr;
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const int c = 2 * q + chalf;
-            tmp[q] = (c < wbk && row < r) ? G[(int64_t)(cb + c) * r + row] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < kTile * kTile / kThreads; ++q) dtmp[q] = slot[q * kThreads + tid];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) Bs[2 * q + chalf][rr] = tmp[q];
-#pragma unroll
-        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
-            const int e = q * kThreads + tid;
-            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
-        }
-    }
-    if (tid < kTile) invd[tid] = (tid < wbk) ? 1.0 / slot[tid * kTile + tid] : 1.0;
-    __syncthreads();
-    if (blockIdx.x == 0) STAMP(1);
-
-    // X := B * inv(Ljj') by forward substitution, 16 columns at a time: the low half of
-    // the workgroup solves the 16x16 triangle of its row, then both halves apply the
-    // rank-16 update to the remaining columns (odd / even columns).
-    const int row = tid & (kPanelRows - 1), half = tid >> 7;
-    for (int c0 = 0; c0 < wbk; c0 += 16) {
-        if (half == 0) {
-            double xb[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = Bs[c0 + j][row];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double acc = xb[j];
-#pragma unroll
-                for (int i = 0; i < j; ++i) acc = fma(-xb[i], Dg[(c0 + i) * kLdDiag + c0 + j], acc);
-                xb[j] = acc * invd[c0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) Bs[c0 + j][row] = xb[j];
-        }
-        __syncthreads();
-        if (c0 + 16 < wbk) {
-            double xk[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) xk[k] = Bs[c0 + k][row];
-            for (int j = c0 + 16 + half; j < wbk; j += 2) {
-                double acc = Bs[j][row];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc = fma(-xk[k], Dg[(c0 + k) * kLdDiag + j], acc);
-                Bs[j][row] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) STAMP(2);
-    for (int e = tid; e < kTile * kPanelRows; e += kThreads) {
-        const int c = e >> 7, rr = e & (kPanelRows - 1);
-        const int grow = pd.row0 + rr;
-        if (c < wbk && grow < r) G[(int64_t)(cb + c) * r + grow] = Bs[c][rr];
-    }
-    if (blockIdx.x == 0) STAMP(3);
-}
-
-void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
+void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
+                       hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_panel, dim3(count), dim3(kThreads), 0, stream, P.sn, P.panels + first, L,
-                       P.dscratch);
-}
-
-// FIXUP: copy parked diagonal blocks into their panels (lower triangle only).
-__global__ __launch_bounds__(kThreads) void k_chol_fixup(const SnDesc* __restrict__ sn,
-                                                         const int32_t* __restrict__ list,
-                                                         double* __restrict__ L,
-                                                         const double* __restrict__ dscratch) {
-    const SnDesc D = sn[list[blockIdx.x]];
-    const int r = D.r, nbc = (D.w + kTile - 1) / kTile;
-    double* __restrict__ G = L + D.px;
-    for (int jb = blockIdx.y; jb < nbc; jb += gridDim.y) {
-        const int cb = jb * kTile, wbk = min(kTile, D.w - cb);
-        const double* __restrict__ slot = dscratch + (int64_t)(D.dslot + jb) * (kTile * kTile);
-        for (int e = threadIdx.x; e < kTile * kTile; e += kThreads) {
-            const int c = e >> 6, i = e & 63;
-            if (c < wbk && i < wbk && i >= c) G[(int64_t)(cb + c) * r + cb + i] = slot[e];
-        }
-    }
-}
-
-void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_fixup, dim3(count, 32), dim3(kThreads), 0, stream, P.sn,
-                       P.fix_list + first, L, P.dscratch);
+    hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
+                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, P.tickets + ticket,
+                       epoch);
 }
 
 }  // namespace parsy

@@ -40,13 +40,17 @@ int plan_upload_launches(parsy_plan* pl) {
     const Schedule& S = pl->S;
     if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
     if (upload(pl, S.tiles, pl->dp.tiles, true)) return -1;
-    if (upload(pl, S.panels, pl->dp.panels, true)) return -1;
-    if (upload(pl, S.fix_list, pl->dp.fix_list, true)) return -1;
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
     if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
     if (upload(pl, S.bsolve_blocks, pl->dp.bsolve_blocks, true)) return -1;
+    {
+        void* d = nullptr;
+        PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
+        pl->launch_owned.push_back(d);
+        pl->dp.tickets = (int*)d;
+    }
     return 0;
 }
 
@@ -62,11 +66,6 @@ static int plan_upload(parsy_plan* pl) {
     if (upload(pl, S.wave_ptr, pl->dp.wave_ptr, false)) return -1;
     {
         void* d = nullptr;
-        const size_t bytes = std::max<int64_t>(S.n_dslots, 1) * kTile * kTile * sizeof(double);
-        PARSY_HIP(hipMalloc(&d, bytes));
-        pl->owned.push_back(d);
-        pl->dp.dscratch = (double*)d;
-        pl->device_bytes += (int64_t)bytes;
         PARSY_HIP(hipMalloc(&d, sizeof(int)));
         pl->owned.push_back(d);
         pl->dp.info = (int*)d;
@@ -76,6 +75,12 @@ static int plan_upload(parsy_plan* pl) {
         pl->owned.push_back(d);
         pl->dp.flags = (int*)d;
         PARSY_HIP(hipMemset(d, 0, fbytes));
+        const size_t tbytes = std::max<int64_t>(S.n_tflags, 1) * sizeof(int);
+        PARSY_HIP(hipMalloc(&d, tbytes));
+        pl->owned.push_back(d);
+        pl->dp.tflags = (int*)d;
+        PARSY_HIP(hipMemset(d, 0, tbytes));
+        pl->device_bytes += (int64_t)(fbytes + tbytes);
     }
     {
         // lowest priority: the side stream only fills what the main stream's chain leaves idle
@@ -171,8 +176,8 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         const bool on_side = overlap && l.side;
         if (!on_side) {
             // everything enqueued so far on the main stream belongs to levels < l.level
-            if (overlap && l.kind <= kLaunchFixup) record_levels_below(l.level);
-            if (overlap && l.kind == kLaunchTiles && !l.early && early_seen[l.level])
+            if (overlap && l.kind <= kLaunchChain) record_levels_below(l.level);
+            if (overlap && l.kind == kLaunchChain && early_seen[l.level])
                 (void)hipStreamWaitEvent(stream, pl->ev_early_done[l.level], 0);
         }
         profile_mark(pl, l.kind, stream, cursor);
@@ -183,19 +188,14 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                     record_levels_below(l.wait_level + 1);
                     (void)hipStreamWaitEvent(pl->side_stream,
                                              l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
-                    launch_chol_tiles(pl->dp, l.first, l.count, false, 0, 0, 0, pl->epoch, L, pl->side_stream);
+                    launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
                     (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
                     early_seen[l.level] = 1;
                 } else {
-                    launch_chol_tiles(pl->dp, l.first, l.count, false, 0, l.fused, l.early ? 0 : 1, pl->epoch, L,
-                                      stream);
+                    launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }
                 break;
-            case kLaunchInner:
-                launch_chol_tiles(pl->dp, l.first, l.count, true, l.jb, l.fused, 1, pl->epoch, L, stream);
-                break;
-            case kLaunchPanel: launch_chol_panel(pl->dp, l.first, l.count, L, stream); break;
-            case kLaunchFixup: launch_chol_fixup(pl->dp, l.first, l.count, L, stream); break;
+            case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused)
@@ -262,6 +262,7 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
     if (init) PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
     // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)
     PARSY_HIP(hipMemsetAsync(pl->dp.info, 0x7f, sizeof(int), stream));
+    PARSY_HIP(hipMemsetAsync(pl->dp.tickets, 0, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int), stream));
     if (init) launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
     PARSY_HIP(hipEventRecord(pl->ev_init, stream));
     run_launches(pl, S.chol, d_L, d_L, nullptr, 0, 0, stream);

@@ -19,16 +19,15 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int64_t* wave_ptr = nullptr;
     const int32_t* small_list = nullptr;
     const TileDesc* tiles = nullptr;
-    const PanelDesc* panels = nullptr;
-    const int32_t* fix_list = nullptr;
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
     const int32_t* solve_wide_list = nullptr;
     const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
-    double* dscratch = nullptr;  // parked 64x64 diagonal blocks
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
-    int* flags = nullptr;        // per parked diagonal block: epoch of the factorization that parked it
+    int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
+    int* tflags = nullptr;       // Cholesky chain: per tile, epoch of the factorization that published it
+    int* tickets = nullptr;      // one counter per CHAIN launch (zeroed at the start of a factorization)
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -36,10 +35,9 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
                       hipStream_t stream);
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
                        hipStream_t stream);
-void launch_chol_tiles(const DevicePattern& P, int first, int count, bool inner, int jb, int fused,
-                       int finalize, int epoch, double* L, hipStream_t stream);
-void launch_chol_panel(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
-void launch_chol_fixup(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
+                       hipStream_t stream);
 
 void launch_solve_small(const DevicePattern& P, int first, int count, const double* L, double* x,
                         int nrhs, int ldx, hipStream_t stream);

@@ -38,7 +38,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         d.upd0 = 0;
         d.nupd = 0;
         d.dslot = -1;
-        d.pad = 0;
+        d.tflag0 = -1;
         if (d.w <= 0 || d.r < d.w) throw std::runtime_error("schedule: malformed supernode");
         if ((int64_t)d.w * d.r > 0x7fffffffLL)
             throw std::runtime_error("schedule: a single panel exceeds 2^31 entries");
@@ -124,6 +124,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
         T.dslot = (int32_t)S.n_dslots;
         S.n_dslots += nbc;
+        if (S.n_tflags + (int64_t)nbc * nbr > 0x7fffffffLL) throw std::runtime_error("schedule: too many tiles");
+        T.tflag0 = (int32_t)S.n_tflags;
+        S.n_tflags += (int64_t)nbc * nbr;
         for (int jb = 1; jb < nbc; ++jb) {
             const double K = (double)jb * kTile, wb = std::min(kTile, T.w - jb * kTile);
             S.inner_flops += K * wb * (wb + 1) + 2.0 * K * (double)(T.r - jb * kTile - wb) * wb;
@@ -190,19 +193,16 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
 
 void build_launches(Schedule& S, const uint8_t* active) {
     const int ns = S.nsuper;
-    // PARSY_FORCE_UNFUSED=1 schedules the fallback forms everywhere (separate PANEL launches,
-    // per-block-column solve launches): the paths taken when a launch would hold more waiting
-    // workgroups than may safely be resident.  Used by the tests to cover them on small inputs.
+    // PARSY_FORCE_UNFUSED=1 schedules the solve's fallback form everywhere (per-block-column
+    // launches): the path taken when a chain launch would not be resident.  Used by the tests.
     const char* fu = std::getenv("PARSY_FORCE_UNFUSED");
     const bool force_unfused = fu && fu[0] == '1';
-    const int max_waiting = force_unfused ? -1 : kMaxWaitingTiles;
     const int max_chain = force_unfused ? -1 : kMaxChainWorkgroups;
     S.active.assign(ns, 1);
     if (active) S.active.assign(active, active + ns);
     S.small_list.clear();
     S.tiles.clear();
-    S.panels.clear();
-    S.fix_list.clear();
+    S.n_chain_launches = 0;
     S.chol.clear();
     S.solve_small_list.clear();
     S.solve_panels.clear();
@@ -243,89 +243,44 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (L.count > 0) S.chol.push_back(L);
         }
         if (!S.solve_only && !bigs.empty()) {
-            // ---- TILES: external updates; block column 0 becomes final in the LATE launch ------
-            Launch L{kLaunchTiles, 0, 0, lev, 0, 0, 0, 0, -1, 0};
-            int maxnb = 0, waiting = 0;
-            for (int t : bigs) waiting += ceil_div(S.sn[t].r, kTile) - 1;
-            L.fused = waiting <= max_waiting;
-            for (int phase = 0; phase < 2; ++phase) {
+            // ---- TILES: the early part of the external updates, longest streams first ------
+            {
+                Launch Lt{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0, 0, 1, lev - 2, 1};
                 std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
                 for (int t : bigs) {
                     const SnDesc& T = S.sn[t];
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
-                    maxnb = std::max(maxnb, nbc);
                     const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
-                    for (int J = 0; J < nbc; ++J) {
+                    for (int J = 0; J < nbc; ++J)
                         for (int I = J; I < nbr; ++I) {
-                            const int32_t wgt = tw[((size_t)J * nbr + I) * 2 + phase];
-                            // tiles nothing reaches are skipped, except (late launch) those of block
-                            // column 0 that must factor (diagonal) or solve (fused launch) their block
-                            const bool needed = wgt > 0 || (phase == 1 && J == 0 && (I == 0 || L.fused));
-                            if (!needed) continue;
-                            const int32_t prio = (phase == 1 && J == 0 && I == 0) ? INT32_MAX : wgt;
-                            wt.push_back({prio, TileDesc{t, I * kTile, J * kTile, 0,
-                                                         S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2 + phase) * 4}});
+                            const int32_t wgt = tw[((size_t)J * nbr + I) * 2];
+                            if (wgt > 0)
+                                wt.push_back({wgt, TileDesc{t, I * kTile, J * kTile, 0,
+                                                            S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2) * 4}});
                         }
-                    }
                 }
-                // longest update streams first (a launch ends with its longest tile)
                 std::stable_sort(wt.begin(), wt.end(),
                                  [](const auto& a, const auto& b) { return a.first > b.first; });
-                Launch Lt = L;
-                Lt.first = (int32_t)S.tiles.size();
                 for (auto& x : wt) S.tiles.push_back(x.second);
                 Lt.count = (int32_t)S.tiles.size() - Lt.first;
-                Lt.early = phase == 0;
-                Lt.side = phase == 0;
-                Lt.wait_level = lev - 2;  // early updates need every level up to lev-2 complete
-                if (phase == 0) Lt.fused = 0;
-                if (Lt.count > 0) {
-                    if (phase == 0) early_launches.push_back(Lt);
-                    else S.chol.push_back(Lt);
-                }
-                if (phase == 1) L.count = Lt.count;
+                if (Lt.count > 0) early_launches.push_back(Lt);
             }
-            bool prev_fused = L.fused && L.count > 0;
-            for (int jb = 0; jb < maxnb; ++jb) {
-                // ---- PANEL(jb): only when the launch that finalised column jb was not fused ----
-                if (!prev_fused) {
-                    Launch Lp{kLaunchPanel, (int32_t)S.panels.size(), 0, lev, jb, 0, 0, 0, -1, 0};
-                    for (int t : bigs) {
-                        const SnDesc& T = S.sn[t];
-                        if (ceil_div(T.w, kTile) <= jb) continue;
-                        const int wb = std::min(kTile, T.w - jb * kTile);
-                        for (int row0 = jb * kTile + wb; row0 < T.r; row0 += kPanelRows)
-                            S.panels.push_back(PanelDesc{t, jb, row0, 0});
-                    }
-                    Lp.count = (int32_t)S.panels.size() - Lp.first;
-                    if (Lp.count > 0) S.chol.push_back(Lp);
-                }
-                // ---- INNER(jb): right-looking update of everything right of block column jb;
-                // block column jb+1 becomes final
-                Launch Li{kLaunchInner, (int32_t)S.tiles.size(), 0, lev, jb, 0, 0, 0, -1, 0};
-                int wait_i = 0;
+            // ---- CHAIN: every tile of the level's tiled supernodes in block-column order
+            // (producers before consumers: tile (I,J) reads tiles (I,k), (J,k), k < J, and (J,J))
+            Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
+            int maxnb = 0;
+            for (int t : bigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
+            for (int J = 0; J < maxnb; ++J)
                 for (int t : bigs) {
                     const SnDesc& T = S.sn[t];
-                    if (ceil_div(T.w, kTile) > jb + 1) wait_i += ceil_div(T.r, kTile) - (jb + 1) - 1;
+                    const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+                    if (J >= nbc) continue;
+                    for (int I = J; I < nbr; ++I)
+                        S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0,
+                                                   S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2 + 1) * 4});
                 }
-                Li.fused = wait_i <= max_waiting;
-                for (int pass = 0; pass < 3; ++pass)  // diagonal tiles, then column jb+1, then the rest
-                    for (int t : bigs) {
-                        const SnDesc& T = S.sn[t];
-                        const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
-                        for (int J = jb + 1; J < nbc; ++J)
-                            for (int I = J; I < nbr; ++I) {
-                                const int cls = (J == jb + 1) ? (I == J ? 0 : 1) : 2;
-                                if (cls == pass) S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0, -1});
-                            }
-                    }
-                Li.count = (int32_t)S.tiles.size() - Li.first;
-                if (Li.count > 0) S.chol.push_back(Li);
-                prev_fused = Li.fused && Li.count > 0;
-            }
-            Launch Lf{kLaunchFixup, (int32_t)S.fix_list.size(), (int32_t)bigs.size(), lev, 0, 0, 0, 0, -1, 0};
-            S.fix_list.insert(S.fix_list.end(), bigs.begin(), bigs.end());
-            S.chol.push_back(Lf);
+            Lc.count = (int32_t)S.tiles.size() - Lc.first;
+            S.chol.push_back(Lc);
         }
         // ---- forward solve ----------------------------------------------------------
         {

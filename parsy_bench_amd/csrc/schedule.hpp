@@ -8,22 +8,21 @@
 // Cholesky, one etree level (wavefront) at a time:
 //   SMALL   one workgroup per supernode whose panel (rows x width doubles) fits
 //           the LDS budget: assemble, apply every update, POTRF+TRSM, store.
-//   TILES   (split in two launches: updates from descendants at least two levels below the
-//           target run EARLY on a side stream, concurrently with the previous level's block
-//           column chain; the rest runs LATE on the main stream and finalises)
-//           every other supernode is cut into 64x64 tiles of its panel (lower
-//           trapezoid only); one workgroup per tile applies the external updates
-//           with FP64 MFMA (one wave per 32x32 sub-tile, accumulating in LDS).  The
-//           workgroup of the diagonal tile of block column 0 then factors that
-//           block (POTRF 64x64) and parks it in a scratch slot.
-//   then per 64-wide block column jb of those supernodes:
-//   PANEL   TRSM of 128-row chunks below diagonal block jb (read from its slot)
-//   INNER   right-looking in-supernode update: every tile right of block column jb
-//           gets -= L(I,jb) L(J,jb)' (same MFMA kernel, K = 64, identity row map);
-//           the workgroup of diagonal tile jb+1 factors and parks it.
-//   FIXUP   once per level: parked diagonal blocks are copied into the panels.
-// The solve mirrors it (SOLVE_SMALL: width <= 64; SOLVE_PANEL per block column;
-// one SOLVE_FIXUP at the end).
+//   TILES   every other supernode is cut into 64x64 tiles of its panel (lower trapezoid
+//           only).  The updates from descendants at least two levels below the target are
+//           applied EARLY, by a launch on a side stream that runs concurrently with the
+//           previous level's chain (one workgroup per tile, FP64 MFMA, one wave per 32x32
+//           sub-tile accumulating in LDS).
+//   CHAIN   one launch per level finishes those supernodes as a dataflow over their tiles:
+//           a workgroup takes the next tile (I,J) in block-column order from a ticket
+//           counter, applies the remaining external updates, then -- left-looking inside the
+//           supernode -- the updates by block columns k < J as soon as tiles (I,k) and (J,k)
+//           are published, then POTRF (I == J) or TRSM against the published diagonal tile,
+//           writes the tile and publishes it (one flag per tile, agent-scope release/acquire).
+//           Tickets are handed out in start order, so every tile a workgroup waits for belongs
+//           to a workgroup that has already started: no residency assumption, no deadlock.
+// The solve mirrors it (SOLVE_SMALL: width <= 64; wide supernodes: one chain launch per level,
+// or SOLVE_PANEL per block column + one SOLVE_FIXUP when the chain would not be resident).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -47,8 +46,8 @@ struct SnDesc {       // one per supernode
     int32_t c0, w, r; // first column, width, rows (incl. the w diagonal rows)
     int32_t nupd;     // number of update descriptors
     int32_t a0, a1;   // entries [a0,a1) of A2 belong to this supernode's columns
-    int32_t dslot;    // first 64x64 scratch slot for parked diagonal blocks (-1: SMALL)
-    int32_t pad;
+    int32_t dslot;    // first 64x64 slot of the per-block-column scratch (solve: inverse blocks; -1: SMALL)
+    int32_t tflag0;   // first tile flag of a tiled supernode: tile (I,J) has flag tflag0 + I*ceil(w/64) + J
 };
 
 struct UpdDesc {      // one per (target, descendant) pair, in the reference's update order
@@ -73,8 +72,8 @@ struct TileDesc {     // one workgroup of the TILES / INNER kernels
     int32_t sn;
     int32_t row0, col0;   // tile origin inside the panel (multiples of 64, row0 >= col0)
     int32_t pad;
-    int64_t wp;           // TILES: wave_ptr[wp + q .. wp + q + 1] = WaveEntry range of wave q (sub-tile
-                          // rows 32*(q>>1).., columns 32*(q&1)..); INNER: unused
+    int64_t wp;           // wave_ptr[wp + q .. wp + q + 1] = WaveEntry range of wave q (sub-tile rows
+                          // 32*(q>>1).., columns 32*(q&1)..): early list (TILES) / late list (CHAIN)
 };
 
 struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
@@ -86,7 +85,7 @@ struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
 };
 
 enum LaunchKind : int32_t {
-    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchInner = 2, kLaunchPanel = 3, kLaunchFixup = 4,
+    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2,  // 3, 4: retired (PANEL, FIXUP)
     kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
 };
 
@@ -94,19 +93,14 @@ struct Launch {
     int32_t kind;
     int32_t first, count;  // range in the kind's descriptor array
     int32_t level;
-    int32_t jb;            // block column (INNER / PANEL / SOLVE_PANEL)
+    int32_t jb;            // SMALL: stage size; CHAIN: index of its ticket counter; SOLVE_PANEL / BACK: block column
     int32_t lds_bytes;     // dynamic LDS (SMALL)
-    int32_t fused;         // TILES / INNER: the workgroups of the block column that becomes final
-                           // wait for its diagonal block and do the TRSM themselves (no PANEL launch)
-    int32_t side;          // 1: runs on the plan's side stream (TILES_EARLY), 0: main stream
+    int32_t fused;         // SOLVE_PANEL: 1 = chain launch of the whole level
+    int32_t side;          // 1: runs on the plan's side stream (TILES), 0: main stream
     int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only)
-    int32_t early;         // TILES only: 1 = the "early" half of the update lists, no finalisation
+    int32_t early;         // TILES: always 1 (kept for the launch dumps)
 };
 
-// Upper bound on workgroups that may wait inside one fused launch.  They occupy residency
-// slots while they wait; keeping them well below the 2 x 256 slots of the tile kernel
-// guarantees that the workgroup they wait for is always dispatched.
-constexpr int kMaxWaitingTiles = 320;
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
@@ -115,7 +109,9 @@ struct Schedule {
     int64_t nnzA = 0, ssize = 0, xsize = 0, nnzL = 0;
     int max_width = 0, max_rows = 0, n_small = 0, n_big = 0;
     int n_solve_wide = 0;          // supernodes wider than a tile (solve: block-column chain)
-    int64_t n_dslots = 0;          // parked diagonal blocks (64*64 doubles each)
+    int64_t n_dslots = 0;          // block columns of the tiled supernodes (64*64 doubles of scratch each)
+    int64_t n_tflags = 0;          // tiles of the tiled supernodes (one publication flag each)
+    int n_chain_launches = 0;      // CHAIN launches (one ticket counter each)
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;
     double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)
     double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (INNER launches)
@@ -130,9 +126,7 @@ struct Schedule {
 
     // Cholesky launch data
     std::vector<int32_t> small_list;
-    std::vector<TileDesc> tiles;       // TILES and INNER descriptors
-    std::vector<PanelDesc> panels;
-    std::vector<int32_t> fix_list;     // big supernodes per level (FIXUP)
+    std::vector<TileDesc> tiles;       // TILES and CHAIN descriptors
     std::vector<Launch> chol;
 
     // solve launch data

@@ -1,5 +1,5 @@
-"""Diagnostic: run one factorization with the stamped build and print phase times (us)
-of the last PANEL workgroup 0 and of the last diagonal-tile workgroup."""
+"""Diagnostic: run a few factorizations with the stamped build (tools/build_stamps.sh) and print, for
+the last supernode, the per-block-column timeline of the chain: diagonal tile (J,J) and tile (J+1,J)."""
 import ctypes as C, sys
 from pathlib import Path
 import numpy as np
@@ -13,14 +13,22 @@ sym = I.analyze(A, perm)
 plan = api.Plan(sym, 0)
 for _ in range(3):
     lv, sec = plan.factor(sym.A2x)
-st = np.zeros(32, dtype=np.uint64)
-N.lib().parsy_debug_stamps(st.ctypes.data_as(C.c_void_p))
-t = st.astype(np.float64) / 100.0  # 100 MHz -> us
-print("factor ms", sec * 1e3)
-print("PANEL wg0: load %.2f  trsm %.2f  store %.2f us" % (t[1] - t[0], t[2] - t[1], t[3] - t[2]))
-print("diag tile: update %.2f  writeback+sync %.2f  gather %.2f  potrf %.2f  park %.2f us" % (
-    t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[13] - t[12]))
-print("root tile(0,0) thread0: entries %d chunks %d | store %.1f issue %.1f consume %.1f barrier %.1f | loop %.1f us" % (
-    st[22], st[21], st[16] / 100.0, st[17] / 100.0, st[18] / 100.0, st[19] / 100.0, st[20] / 100.0))
-print("tile below diag: wait %.2f  load Dg %.2f  trsm %.2f  store %.2f us;  diag publish->(wait end) %.2f" % (
-    t[25] - t[24], t[26] - t[25], t[27] - t[26], t[28] - t[27], t[25] - t[13]))
+print("factor ms", sec * 1e3, "status", plan.status())
+tr = np.zeros(16 * 512, dtype=np.uint64)
+N.lib().parsy_debug_trace(tr.ctypes.data_as(C.c_void_p))
+t = tr.reshape(512, 16).astype(np.float64) / 100.0  # us
+w = int(np.diff(sym.super)[-1]); nbc = (w + 63) // 64
+t0 = t[0, 0]
+print("root: %d block columns; times in us relative to the start of diag tile 0" % nbc)
+print("  J | diag: start  stream_end  potrf_end  published | below: start  saw_flag  trsm_end  published | step")
+prev = None
+for J in range(nbc):
+    d = t[J]
+    step = (d[3] - prev) if prev is not None else 0.0
+    print("%3d | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f %8.1f | %6.1f" % (
+        J, d[0] - t0, d[1] - t0, d[2] - t0, d[3] - t0, d[7] - t0, d[4] - t0, d[5] - t0, d[6] - t0, step))
+    prev = d[3]
+    if J > 0:
+        pb = t[J - 1][6]
+        print("      diag wave0 last entry: below published %.1f | first poll miss %.1f  flag seen %.1f  acquired %.1f  round(more) %.1f  last round %.1f  | stream_end %.1f" % (
+            pb - t0, d[8] - t0, d[9] - t0, d[10] - t0, d[11] - t0, d[12] - t0, d[1] - t0))

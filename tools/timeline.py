@@ -1,0 +1,32 @@
+"""Print the kernel timeline of the LAST factorization found in a rocprofv3 --kernel-trace csv
+(start offset, duration, gap to the previous kernel end on any stream, grid, name)."""
+import csv
+import sys
+
+path = sys.argv[1]
+rows = list(csv.DictReader(open(path)))
+ks = []
+for r in rows:
+    ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+               int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 256) or 256),
+               r.get("Stream_Id", r.get("Queue_Id", "?"))))
+ks.sort()
+# a factorization starts with k_scatter_a
+starts = [i for i, k in enumerate(ks) if "k_scatter_a" in k[2]]
+if not starts:
+    sys.exit("no k_scatter_a in trace")
+b = starts[-1]
+e = len(ks)
+t0 = ks[b][0]
+prev_end = t0
+tot = {}
+for s, en, name, grid, wg, q in ks[b:e]:
+    short = name.split("(")[0].replace("parsy::", "").replace("void ", "")
+    if "solve" in short:
+        break
+    print(f"{(s - t0) / 1e3:9.1f} us  dur {(en - s) / 1e3:8.1f}  gap {(s - prev_end) / 1e3:7.1f}  wgs {grid // max(wg, 1):6d}  q={q}  {short}")
+    prev_end = max(prev_end, en)
+    tot[short] = tot.get(short, 0) + (en - s) / 1e3
+print("total span us", (prev_end - t0) / 1e3)
+for k, v in sorted(tot.items(), key=lambda x: -x[1]):
+    print(f"  {k}: {v:.1f} us")
