@@ -326,6 +326,7 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
 //   (2) every thread of that block column factors the micro-block itself (4 pivots in
 //       registers) and solves its own 4x4 block against it, then publishes the 4 new columns,
 //   (3) everybody applies the rank-4 update to its block.
+// inv_out (64 doubles of LDS, optional) receives the reciprocals of the factor's diagonal.
 // Two barriers per 4 columns.  Entries outside the block (nb < 64) must be an identity so the
 // loop is uniform; strictly-upper entries pick up garbage that is never stored.  `scr` is
 // 16 + 64*5 doubles of LDS.  On return a[][] holds the factor; `bad` receives (1-based) the
@@ -334,7 +335,7 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
 // ---------------------------------------------------------------------------
 static constexpr int kPotrfScratch = 16 + kTile * 5;
 __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restrict__ scr, int ti, int tj,
-                                             int nb, int& bad) {
+                                             int nb, int& bad, double* __restrict__ inv_out = nullptr) {
     double* __restrict__ bufD = scr;        // 4x4 micro-block, row-major
     double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
     const bool lower = ti >= tj;
@@ -374,6 +375,10 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
                 for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
                     for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
+                if (inv_out) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) inv_out[4 * tjj + jj] = (4 * tjj + jj < nb) ? inv[jj] : 1.0;
+                }
             } else {
                 // X l' = A  (4x4, row by row)
 #pragma unroll
@@ -411,6 +416,77 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
     }
 }
 
+typedef __attribute__((address_space(3))) double lds_f64;
+
+// X := B inv(Ljj') on the 64 rows of the LDS tile `tile` (sub-tile layout of the tile kernel: 4 x
+// 32x33); Dg holds Ljj (Dg[c * 65 + i], zeros above the diagonal), invd the reciprocals of its
+// diagonal.  One workgroup barrier is expected before the call, one ends it.  The walker inlines
+// it (values in flight across it); the other two places share one out-of-line copy, which keeps
+// their register allocation apart from the stream's.
+__device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ tile, lds_f64* __restrict__ Dg,
+                                                       lds_f64* __restrict__ invd, int nb) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    auto cell = [&](int i, int c) -> lds_f64& {
+        return tile[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
+    };
+    // inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
+    // transposed into the (unused) strict upper triangle of the same sub-block:
+    // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  The TRSM below is then all products
+    // (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.
+    if (tid < kTile) {
+        const int b16 = (tid >> 4) * 16, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // all reads of the sub-block precede the in-place writes
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+    }
+    __syncthreads();
+    // each wave owns 16 rows of the tile for the whole solve: no barrier between blocks
+    const int rbase = 16 * wave;
+    for (int b16 = 0; b16 < nb; b16 += 16) {
+        double4_t acc = {0, 0, 0, 0};
+        for (int p16 = 0; p16 < b16; p16 += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = p16 + kq + 4 * u;
+                const double av = cell(rbase + l15, k);                // X[row][k]
+                const double bv = Dg[k * kLdDiag + b16 + l15];         // L[b16 + j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cell(rbase + kq + 4 * v, b16 + l15) -= acc[v];
+        double4_t acc2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kq + 4 * u, j = l15;
+            const double av = cell(rbase + l15, b16 + k);              // R[row][k]
+            double wv = 0.0;                                            // inv(L_bb)'[k][j] = inv(L_bb)[j][k]
+            if (j > k) wv = Dg[(b16 + j) * kLdDiag + b16 + k];
+            else if (j == k) wv = invd[b16 + k];
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, wv, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cell(rbase + kq + 4 * v, b16 + l15) = acc2[v];
+    }
+    __syncthreads();
+}
+__device__ __noinline__ void invert_and_trsm(lds_f64* __restrict__ tile, lds_f64* __restrict__ Dg,
+                                             lds_f64* __restrict__ invd, int nb) {
+    invert_and_trsm_inline(tile, Dg, invd, nb);
+}
+
 static constexpr int kKC = 16;        // k extent of one chunk of an update stream
 static constexpr int kInFlight = 4;   // chunks in flight per wave (operands prefetched into registers)
 static constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
@@ -444,12 +520,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             const TileDesc* __restrict__ tiles,
                                                             double* __restrict__ L,
                                                             int* __restrict__ info,
-                                                            int* __restrict__ tflags,
+                                                            int* __restrict__ tflags, int nflags_arg,
                                                             int* __restrict__ ticket, int epoch) {
     __shared__ double T[4][kSub * kLdSub];
     __shared__ double colbuf[kPotrfScratch];
-    __shared__ double dgbuf[kTile * kLdDiag];  // diagonal block + its 16x16 inverses (TRSM)
-    __shared__ int32_t s_ok, s_task;
+    __shared__ double dgbuf[4 * kSub * kLdSub];  // diagonal block + its 16x16 inverses (TRSM) / the walker's next diagonal tile
+    __shared__ double s_invd[kTile];  // reciprocals of the diagonal of the block being solved against
+    __shared__ int32_t s_ok, s_task, s_cnt, s_cnt2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -465,11 +542,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     double* __restrict__ G = L + D.px;
     const int tI = td.row0 / kTile, tJ = td.col0 / kTile, nbc = (w + kTile - 1) / kTile;
     const bool diag_tile = td.row0 == td.col0;
-    const bool stamp_wg = CHAIN && diag_tile && td.col0 + kTile >= w;  // last diagonal tile of a supernode
-    if (stamp_wg) STAMP(8);
-    const bool sub_tile = td.row0 == td.col0 + kTile;
-    if (CHAIN && diag_tile) TRACE(tJ, 0);
-    if (CHAIN && sub_tile) TRACE(tJ, 7);
+    // roles of the chain launch (see the walker below)
+    const bool walker = CHAIN && tI == 0 && tJ == 0;
+    const bool prep_c = CHAIN && diag_tile && tJ > 0;           // diagonal tile (J,J), J >= 1
+    const bool prep_b = CHAIN && tI == tJ + 1 && tI < nbc;      // tile (J+1,J) left of a diagonal tile
 
     const int wa = wave >> 1, wb = wave & 1;
     const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
@@ -504,7 +580,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     if (wave_on) {
         le = wptr[td.wp + wave];
         e_end = wptr[td.wp + wave + 1];
-        if (CHAIN) n_int = tJ;
+        if (CHAIN) n_int = prep_c ? tJ - 1 : tJ;  // block column J-1 reaches a diagonal tile through the walker
     }
     bool gave_up = false;
     if (le < e_end || n_int > 0) {
@@ -545,20 +621,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                 if (!diag_tile)
                     ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
                 if (ok) break;
-                if (diag_tile && k == n_int - 1 && spins == 0) TRACE(tJ, 8);
                 if ((spins & 15) == 15 &&
                     (wall_clock64() - t0 > kSpinTicks ||
                      __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
                     gave_up = true;
                     return;
                 }
-                if (spins < 8) __builtin_amdgcn_s_sleep(8);
+                // the last block column of a tile the walker is waiting for is on the critical path:
+                // poll it tightly (few such tiles at any time); everything else polls lazily
+                if (spins < 8 || ((prep_b || prep_c) && k == n_int - 1)) __builtin_amdgcn_s_sleep(4);
                 else __builtin_amdgcn_s_sleep(48);
                 ++spins;
             }
-            if (diag_tile && k == n_int - 1) TRACE(tJ, 9);
             extend_ready();
-            if (diag_tile && k == n_int - 1) TRACE(tJ, 10);
         };
 
         // loader state (wave-uniform except the lane offsets).  Every chunk issues the same 16
@@ -727,7 +802,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) issue(q[i]);
         store_subtile();
-        if (stamp_wg) STAMP(15);
         bool more = true;
         while (more) {
             // the loader passes at most kInFlight entries per round: make sure the next block
@@ -753,187 +827,297 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                 more = more || q[sidx].kend != 0;
             }
             more = more || l_stalled;
-            if (CHAIN && diag_tile && l_kint == n_int) TRACE(tJ, 11 + (more ? 0 : 1));
         }
     } else if (wave_on) {
         store_subtile();
     }
     if (gave_up) atomicMin(info, -1);
     __syncthreads();
-    if (stamp_wg) STAMP(9);
-    if (CHAIN && diag_tile) TRACE(tJ, 1);
 
-    auto write_back = [&](int min_row) {  // min_row: first row of the TILE that is written
-        if (wave_on) {
-            for (int e = lane; e < kSub * kSub; e += 64) {
-                const int cc = e >> 5, rr = e & 31;
-                if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc) && kSub * wa + rr >= min_row) {
-                    double* dst = &G[(int64_t)(subcol0 + cc) * r + subrow0 + rr];
-                    if (CHAIN) st_sc1(dst, Tw[cc * kLdSub + rr]);
-                    else *dst = Tw[cc * kLdSub + rr];
-                }
+    // ---------------------------------------------------------------------------------------
+    // After the stream.  Tiles live in LDS in the sub-tile layout of T (4 x 32x33); the tile
+    // buffer and the buffer of the diagonal block (64x65, with its 16x16 inverses) are T and
+    // dgbuf in either order.
+    // ---------------------------------------------------------------------------------------
+    double* const Tflat = &T[0][0];
+    auto cell = [&](double* buf, int i, int c) -> double& {
+        return buf[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
+    };
+    // this wave's quadrant of the tile at (row0, col0): rows >= min_row of the tile go to the panel
+    auto write_tile = [&](double* buf, int row0, int col0, int min_row) {
+        const int sr = row0 + kSub * wa, sc = col0 + kSub * wb;
+        const int nr = min(kSub, r - sr), nc = min(kSub, w - sc);
+        if (sr < sc || nr <= 0 || nc <= 0) return;
+        const double* __restrict__ Q = buf + wave * (kSub * kLdSub);
+        for (int e = lane; e < kSub * kSub; e += 64) {
+            const int cc = e >> 5, rr = e & 31;
+            if (rr < nr && cc < nc && (sr + rr >= sc + cc) && kSub * wa + rr >= min_row) {
+                double* dst = &G[(int64_t)(sc + cc) * r + sr + rr];
+                if (CHAIN) st_sc1(dst, Q[cc * kLdSub + rr]);
+                else *dst = Q[cc * kLdSub + rr];
             }
         }
     };
     if (!CHAIN) {
-        write_back(0);
+        write_tile(Tflat, td.row0, td.col0, 0);
         return;
     }
-    auto publish = [&]() {
+    const int nflags = nflags_arg;
+    auto publish = [&](int flag_index) {
         // the tile was stored write-through (sc1): every storing wave drains its stores, the
-        // workgroup meets, one lane raises the tile's flag (Guideline 16, R1)
+        // workgroup meets, one lane raises the flag (Guideline 16, R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(&tflags[D.tflag0 + tI * nbc + tJ], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_store(&tflags[flag_index], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    const int nb = min(kTile, w - td.col0);
-    int trsm_min_row = 0;
-
-    if (diag_tile) {
-        STAMP(10);
-        const int ti = tid & 15, tj = tid >> 4;
-        double a[4][4];
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = 4 * ti + ri, c = 4 * tj + ci;
-                double v = (i == c) ? 1.0 : 0.0;
-                if (c < nb && i < nb && i >= c) v = T[(i >> 5) * 2 + (c >> 5)][(c & 31) * kLdSub + (i & 31)];
-                a[ri][ci] = v;
-            }
-        int bad;
-        STAMP(11);
-        potrf64_regs(a, colbuf, ti, tj, nb, bad);
-        STAMP(12);
-        TRACE(tJ, 2);
-        if (bad) atomicMin(info, D.c0 + td.col0 + bad);  // only threads that saw a bad pivot
-        // the factored block goes to the panel (zeros above the diagonal, as the layout wants)
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = 4 * ti + ri, c = 4 * tj + ci;
-                if (c < nb && i < nb) st_sc1(&G[(int64_t)(td.col0 + c) * r + td.col0 + i], (i >= c) ? a[ri][ci] : 0.0);
-            }
-        // a block column narrower than the tile leaves rows of the panel below the diagonal
-        // block inside this very tile: solve them here before publishing
-        if (!(nb < kTile && td.row0 + nb < r)) {
-            publish();
-            STAMP(13);
-            TRACE(tJ, 3);
-            return;
-        }
-        trsm_min_row = nb;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the factored block (global) is visible to the whole workgroup
-    } else {
+    auto wait_flags = [&](int f0, int f1) -> bool {  // workgroup-wide bounded wait for two flags
         if (tid == 0) {
-            // ---- wait for the diagonal tile of this block column (bounded)
             const unsigned long long t0 = wall_clock64();
-            int ok = 1;
-            while (__hip_atomic_load(&tflags[D.tflag0 + tJ * nbc + tJ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-                   epoch) {
-                if (wall_clock64() - t0 > kSpinTicks ||
-                    __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) {
+            int ok = 1, spins = 0;
+            while (__hip_atomic_load(&tflags[f0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch ||
+                   __hip_atomic_load(&tflags[f1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                if ((++spins & 15) == 0 &&
+                    (wall_clock64() - t0 > kSpinTicks ||
+                     __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
                     ok = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(4);
             }
             s_ok = ok;
         }
         __syncthreads();
-        if (sub_tile) TRACE(tJ, 4);
-        if (!s_ok) {
-            if (tid == 0) atomicMin(info, -1);  // status < 0: a wait timed out / was abandoned
-            write_back(0);
-            publish();  // (so that nobody else waits for this tile)
+        if (!s_ok && tid == 0) atomicMin(info, -1);  // status < 0: a wait timed out / was abandoned
+        return s_ok != 0;
+    };
+    double* __restrict__ invd = s_invd;
+    const int my_flag = D.tflag0 + tI * nbc + tJ;
+
+    if (prep_b || prep_c) {
+        // prepared for the walker: every update except the walker's own is in; it goes to the panel
+        // and is announced with the tile's PREP flag
+        write_tile(Tflat, td.row0, td.col0, 0);
+        publish(nflags + my_flag);
+        return;
+    }
+
+    if (!walker) {
+        // ---- a tile below the diagonal: wait for the diagonal tile of its block column, TRSM, publish
+        const int nb = min(kTile, w - td.col0);
+        const int fd = D.tflag0 + tJ * nbc + tJ;
+        if (!wait_flags(fd, fd)) {
+            write_tile(Tflat, td.row0, td.col0, 0);
+            publish(my_flag);  // (so that nobody else waits for this tile)
             return;
         }
+        {
+            const double* DB = G + (int64_t)td.col0 * r + td.col0;  // factored diagonal block, ld r
+            double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+            for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+                const int e = q * kThreads + tid;
+                const int c = e >> 6, i = e & 63;
+                dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * r + i]) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+                const int e = q * kThreads + tid;
+                dgbuf[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
+            }
+            if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * r + tid]) : 1.0;
+        }
+        __syncthreads();
+        invert_and_trsm((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, nb);
+        write_tile(Tflat, td.row0, td.col0, 0);
+        publish(my_flag);
+        return;
     }
-    // ---- X := B inv(Ljj') on the rows of the LDS tile
-    double* __restrict__ Dg = dgbuf;
-    double* __restrict__ invd = colbuf;
+
+    // ---------------------------------------------------------------------------------------
+    // The walker: ONE workgroup per tiled supernode runs down its diagonal, so that the critical
+    // path POTRF(J) -> TRSM of tile (J+1,J) -> SYRK into tile (J+1,J+1) -> POTRF(J+1) never
+    // leaves this workgroup's LDS.  Other workgroups prepare tiles (J+1,J) and (J+1,J+1) (all
+    // updates by block columns < J) and announce them with PREP flags; the walker publishes the
+    // finished diagonal tiles and the tiles (J+1,J) with the ordinary flags.
+    // X tile in T, diagonal block / next diagonal tile in dgbuf.
+    // ---------------------------------------------------------------------------------------
     {
-        const double* __restrict__ DB = G + (int64_t)td.col0 * r + td.col0;  // factored diagonal block, ld r
-        double dtmp[kTile * kTile / kThreads];
+        double* Cb = Tflat;  // buffer that holds the current diagonal tile
+        const int ti = tid & 15, tj = tid >> 4;
+        for (int J = 0; J < nbc; ++J) {
+            const int col0 = J * kTile, nb = min(kTile, w - col0);
+            TRACE(J, 0);
+            double a[4][4];
 #pragma unroll
-        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
-            const int e = q * kThreads + tid;
-            const int c = e >> 6, i = e & 63;
-            dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * r + i]) : 0.0;
-        }
+            for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int q = 0; q < kTile * kTile / kThreads; ++q) {
-            const int e = q * kThreads + tid;
-            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
-        }
-        if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * r + tid]) : 1.0;
-    }
-    __syncthreads();
-    // inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
-    // transposed into the (unused) strict upper triangle of the same sub-block:
-    // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  The TRSM below is then all products
-    // (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.
-    if (tid < kTile) {
-        const int b16 = (tid >> 4) * 16, c = tid & 15;
-        double y[16];
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = 4 * ti + ri, c = 4 * tj + ci;
+                    double v = (i == c) ? 1.0 : 0.0;
+                    if (c < nb && i < nb && i >= c) v = cell(Cb, i, c);
+                    a[ri][ci] = v;
+                }
+            const bool has_next = J + 1 < nbc;
+            const bool tail_rows = !has_next && nb < kTile && col0 + nb < r;
+            const int f_diag = D.tflag0 + J * nbc + J;
+            const int row1 = col0 + kTile;  // tiles (J+1,J) and (J+1,J+1)
+            const int f_b = D.tflag0 + (J + 1) * nbc + J, f_c = f_b + 1;
+            // prepared tile (J+1,J) -> registers -> T, prepared diagonal tile (J+1,J+1) -> registers
+            double bv[kSub * kSub / 64], cpart[kSub * kSub / 64];
+            auto load_b = [&]() {  // tile (J+1,J), all four quadrants
+                const int sr = row1 + kSub * wa, nr = min(kSub, r - sr), scb = col0 + kSub * wb;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    const int cc = e >> 5, rr = e & 31;
+                    bv[q] = (rr < nr) ? ld_sc1(&G[(int64_t)(scb + cc) * r + sr + rr]) : 0.0;
+                }
+            };
+            auto load_c = [&]() {  // diagonal tile (J+1,J+1), lower part
+                const int sr = row1 + kSub * wa, nr = min(kSub, r - sr);
+                const int scc = row1 + kSub * wb, ncc = min(kSub, w - scc);
 #pragma unroll
-        for (int rr = 1; rr < 16; ++rr) {
-            double sacc = 0.0;
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    const int cc = e >> 5, rr = e & 31;
+                    const bool inc = rr < nr && cc < ncc && (sr + rr >= scc + cc);
+                    cpart[q] = inc ? ld_sc1(&G[(int64_t)(scc + cc) * r + sr + rr]) : 0.0;
+                }
+            };
+            if (tid == 0) {
+                s_cnt = 0;  // arrival counters of this step's two barrier-free publications
+                s_cnt2 = 0;
+            }
+            int bad;
+            potrf64_regs(a, colbuf, ti, tj, nb, bad, s_invd);
+            TRACE(J, 2);
+            if (bad) atomicMin(info, D.c0 + col0 + bad);  // only threads that saw a bad pivot
+            // the factored block goes to the panel (the part above the diagonal is zero since the
+            // panel was assembled and nobody writes there)
 #pragma unroll
-            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
-            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
-        }
-        __builtin_amdgcn_s_waitcnt(0);  // all reads of the sub-block precede the in-place writes
+            for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int rr = 1; rr < 16; ++rr)
-            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
-    }
-    __syncthreads();
-    {
-        // each wave owns 16 rows of the tile for the whole solve: no barrier between blocks
-        const int rbase = 16 * wave;
-        auto TT = [&](int i, int c) -> double& {
-            return T[(i >> 5) * 2 + (c >> 5)][(c & 31) * kLdSub + (i & 31)];
-        };
-        for (int b16 = 0; b16 < nb; b16 += 16) {
-            double4_t acc = {0, 0, 0, 0};
-            for (int p16 = 0; p16 < b16; p16 += 16) {
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = 4 * ti + ri, c = 4 * tj + ci;
+                    if (c < nb && i < nb && i >= c) st_sc1(&G[(int64_t)(col0 + c) * r + col0 + i], a[ri][ci]);
+                }
+            if (!has_next && !tail_rows) {
+                publish(f_diag);
+                TRACE(J, 3);
+                break;
+            }
+            // Ljj into the block buffer straight from the registers
+            double* Dg = (tail_rows && Cb != Tflat) ? Tflat : dgbuf;
+            auto fill_dg = [&]() {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = p16 + kq + 4 * u;
-                    const double av = TT(rbase + l15, k);                  // X[row][k]
-                    const double bv = Dg[k * kLdDiag + b16 + l15];         // L[b16 + j][k]
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) {
+                        const int i = 4 * ti + ri, c = 4 * tj + ci;
+                        Dg[c * kLdDiag + i] = (c < nb && i < nb && i >= c) ? a[ri][ci] : 0.0;
+                    }
+            };
+            if (tail_rows) {
+                // a last block column narrower than the tile leaves rows of the panel below the diagonal
+                // block inside this very tile: solve them here, then publish
+                fill_dg();
+                __syncthreads();
+                invert_and_trsm((lds_f64*)Cb, (lds_f64*)Dg, (lds_f64*)invd, nb);
+                write_tile(Cb, col0, col0, nb);
+                publish(f_diag);
+                TRACE(J, 3);
+                break;
+            }
+            fill_dg();  // (dgbuf: the diagonal tile was gathered before the POTRF's barriers)
+            {
+                // every wave waits for the two prepared tiles itself (bounded) and then loads its
+                // quadrants: no workgroup barrier between the poll and the loads
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                while (__hip_atomic_load(&tflags[nflags + f_b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch ||
+                       __hip_atomic_load(&tflags[nflags + f_c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    if ((++spins & 15) == 0 &&
+                        (wall_clock64() - t0 > kSpinTicks ||
+                         __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                        atomicMin(info, -1);  // status < 0; go on (with whatever is there) so that nobody hangs
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            load_b();
+            TRACE(J, 4);
+            // Diagonal tile J is published as soon as its stores have landed, without a workgroup
+            // barrier: every wave drains its own stores (behind the loads it has to wait for anyway)
+            // and counts itself in LDS; the last one raises the flag.  The tiles of block column J
+            // can start their TRSM.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const int arrived = __hip_atomic_fetch_add(&s_cnt2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (arrived == kThreads / 64 - 1)
+                    __hip_atomic_store(&tflags[f_diag], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int q = 0; q < kSub * kSub / 64; ++q) {
+                const int e = q * 64 + lane;
+                Tw[(e >> 5) * kLdSub + (e & 31)] = bv[q];
+            }
+            __syncthreads();  // Ljj and the tile are in LDS
+            TRACE(J, 3);
+            load_c();  // lands behind the TRSM
+            invert_and_trsm_inline((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, kTile);
+            TRACE(J, 5);
+            write_tile(Tflat, row1, col0, 0);  // X = final tile (J+1,J)
+            // X is published the same way (drain half way through the SYRK below).
+            auto publish_x_wave = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const int arrived = __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (arrived == kThreads / 64 - 1)
+                        __hip_atomic_store(&tflags[f_b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            // next diagonal tile: C' - X X' on this wave's quadrant (dgbuf is free again)
+            {
+                double* __restrict__ Cq = dgbuf + wave * (kSub * kLdSub);
+#pragma unroll
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    Cq[(e >> 5) * kLdSub + (e & 31)] = cpart[q];
+                }
+                if (wa >= wb) {
+                    double4_t s00 = {0, 0, 0, 0}, s01 = {0, 0, 0, 0}, s10 = {0, 0, 0, 0}, s11 = {0, 0, 0, 0};
+                    for (int half = 0; half < 2; ++half) {
+#pragma unroll 2
+                        for (int ks = half * (kTile / 8); ks < (half + 1) * (kTile / 8); ++ks) {
+                            const int k = 4 * ks + kq;
+                            const double x0 = cell(Tflat, kSub * wa + l15, k), x1 = cell(Tflat, kSub * wa + 16 + l15, k);
+                            const double y0 = cell(Tflat, kSub * wb + l15, k), y1 = cell(Tflat, kSub * wb + 16 + l15, k);
+                            s00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, s00, 0, 0, 0);
+                            if (wa != wb) s01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, s01, 0, 0, 0);
+                            s10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, s10, 0, 0, 0);
+                            s11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, s11, 0, 0, 0);
+                        }
+                        if (half == 0) publish_x_wave();
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int r0 = kq + 4 * v;
+                        Cq[l15 * kLdSub + r0] -= s00[v];
+                        if (wa != wb) Cq[(16 + l15) * kLdSub + r0] -= s01[v];
+                        Cq[l15 * kLdSub + 16 + r0] -= s10[v];
+                        Cq[(16 + l15) * kLdSub + 16 + r0] -= s11[v];
+                    }
+                } else {
+                    publish_x_wave();
                 }
             }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) TT(rbase + kq + 4 * v, b16 + l15) -= acc[v];
-            double4_t acc2 = {0, 0, 0, 0};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = kq + 4 * u, j = l15;
-                const double av = TT(rbase + l15, b16 + k);                // R[row][k]
-                double wv = 0.0;                                            // inv(L_bb)'[k][j] = inv(L_bb)[j][k]
-                if (j > k) wv = Dg[(b16 + j) * kLdDiag + b16 + k];
-                else if (j == k) wv = invd[b16 + k];
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, wv, acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) TT(rbase + kq + 4 * v, b16 + l15) = acc2[v];
+            __syncthreads();  // the next diagonal tile is complete in dgbuf
+            TRACE(J, 6);
+            Cb = dgbuf;
         }
     }
-    __syncthreads();
-    if (sub_tile) TRACE(tJ, 5);
-    write_back(trsm_min_row);
-    publish();
-    if (sub_tile) TRACE(tJ, 6);
 }
 
 #ifdef PARSY_STAMPS
@@ -948,14 +1132,14 @@ extern "C" void parsy_debug_trace(unsigned long long* out) {
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, (int*)nullptr, 0);
+                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, 0, (int*)nullptr, 0);
 }
 
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, P.tickets + ticket,
+                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, P.n_tflags, P.tickets + ticket,
                        epoch);
 }
 

@@ -75,7 +75,8 @@ static int plan_upload(parsy_plan* pl) {
         pl->owned.push_back(d);
         pl->dp.flags = (int*)d;
         PARSY_HIP(hipMemset(d, 0, fbytes));
-        const size_t tbytes = std::max<int64_t>(S.n_tflags, 1) * sizeof(int);
+        const size_t tbytes = 2 * std::max<int64_t>(S.n_tflags, 1) * sizeof(int);
+        pl->dp.n_tflags = (int)S.n_tflags;
         PARSY_HIP(hipMalloc(&d, tbytes));
         pl->owned.push_back(d);
         pl->dp.tflags = (int*)d;

@@ -27,6 +27,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
     int* tflags = nullptr;       // Cholesky chain: per tile, epoch of the factorization that published it
+                                 // ([0, n_tflags): finished tiles, [n_tflags, 2 n_tflags): tiles prepared for the walker)
+    int n_tflags = 0;
     int* tickets = nullptr;      // one counter per CHAIN launch (zeroed at the start of a factorization)
 };
 

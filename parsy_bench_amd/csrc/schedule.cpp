@@ -265,8 +265,10 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 Lt.count = (int32_t)S.tiles.size() - Lt.first;
                 if (Lt.count > 0) early_launches.push_back(Lt);
             }
-            // ---- CHAIN: every tile of the level's tiled supernodes in block-column order
-            // (producers before consumers: tile (I,J) reads tiles (I,k), (J,k), k < J, and (J,J))
+            // ---- CHAIN: every tile of the level's tiled supernodes, producers before consumers.
+            // Group J of a supernode: the walker (J = 0 only: it owns every diagonal tile), the two tiles
+            // the walker needs prepared for its step J -- (J+1,J) and (J+1,J+1) -- and then the other
+            // tiles of block column J, which wait for diagonal tile J.
             Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
             int maxnb = 0;
             for (int t : bigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
@@ -275,9 +277,17 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     const SnDesc& T = S.sn[t];
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     if (J >= nbc) continue;
-                    for (int I = J; I < nbr; ++I)
-                        S.tiles.push_back(TileDesc{t, I * kTile, J * kTile, 0,
-                                                   S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2 + 1) * 4});
+                    auto push = [&](int I, int Jc) {
+                        S.tiles.push_back(TileDesc{t, I * kTile, Jc * kTile, 0,
+                                                   S.sn_wp0[t] + (((int64_t)Jc * nbr + I) * 2 + 1) * 4});
+                    };
+                    if (J == 0) push(0, 0);
+                    const bool next_diag = J + 1 < nbc;
+                    if (next_diag) {
+                        push(J + 1, J);
+                        push(J + 1, J + 1);
+                    }
+                    for (int I = next_diag ? J + 2 : J + 1; I < nbr; ++I) push(I, J);
                 }
             Lc.count = (int32_t)S.tiles.size() - Lc.first;
             S.chol.push_back(Lc);
