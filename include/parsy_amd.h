@@ -136,6 +136,11 @@ int parsy_plan_get_info(const parsy_plan* plan, parsy_plan_info* info);
  * byte per supernode (non-zero = process).  NULL restores "all". Rebuilds the
  * launch schedule; not meant for the timed region. */
 int parsy_plan_set_active(parsy_plan* plan, const uint8_t* mask);
+/* Host-side dry run of the factorization's in-launch hand-offs (tiles of the wide supernodes are
+ * passed between workgroups inside one launch per etree level) with `slots` resident workgroups:
+ * returns the number of tiles that would never be finished -- 0 means the schedule cannot
+ * deadlock at that residency -- or -1 for a bad argument.  The kernel runs 2 workgroups per CU. */
+long long parsy_plan_chain_check(const parsy_plan* plan, int slots);
 
 /* Numeric factorization, everything on the device.
  *   d_values  device, nnz(A2) doubles (same order as the host `values`)

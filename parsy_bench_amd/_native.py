@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "cholesky_left_par_05", "cholesky_left_par_waveFront", "blockedLsolve",
     "leveledBlockedLsolve", "H2LeveledBlockedLsolve", "H2LeveledBlockedLsolve_Peeled",
     "parsy_dropin_reset", "parsy_plan_create", "parsy_plan_destroy", "parsy_plan_get_info",
-    "parsy_plan_set_active", "parsy_factor_device", "parsy_factor_status", "parsy_solve_device",
+    "parsy_plan_set_active", "parsy_plan_chain_check", "parsy_factor_device", "parsy_factor_status", "parsy_solve_device",
     "parsy_factor_host", "parsy_solve_host", "parsy_last_factor_ms", "parsy_last_solve_ms",
     "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
@@ -87,6 +87,8 @@ def _declare(lib):
     lib.parsy_plan_destroy.argtypes = [vp]
     lib.parsy_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
     lib.parsy_plan_set_active.argtypes = [vp, vp]
+    lib.parsy_plan_chain_check.argtypes = [vp, C.c_int]
+    lib.parsy_plan_chain_check.restype = C.c_longlong
     lib.parsy_factor_device.argtypes = [vp, vp, vp, vp]
     lib.parsy_factor_device_ex.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.parsy_factor_status.argtypes = [vp]

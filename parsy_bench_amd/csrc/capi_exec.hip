@@ -253,6 +253,14 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     return 0;
 }
 
+long long parsy_plan_chain_check(const parsy_plan* pl, int slots) {
+    if (!pl || slots < 1) {
+        set_last_error("parsy_plan_chain_check: null plan or slots < 1");
+        return -1;
+    }
+    return (long long)simulate_chain(pl->S, slots);
+}
+
 int parsy_plan_set_active(parsy_plan* pl, const uint8_t* mask) {
     if (!pl) return -1;
     parsy::build_launches(pl->S, mask);

@@ -29,6 +29,7 @@ __device__ unsigned long long g_stamps[32];
 #define STAMP(i) do { if (threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 // per block column J of the last supernode that ran: times of the diagonal tile (J,J) and the tile below it
 __device__ unsigned long long g_trace[16 * 512];
+__device__ unsigned long long g_probe[8];
 #define TRACE(J, i) do { if (threadIdx.x == 0 && (J) < 512) g_trace[(J) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -340,7 +341,13 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
     double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
     const bool lower = ti >= tj;
     bad = 0;
+#ifdef PARSY_STAMPS
+#define PPROBE(i) do { if (tjj == 4 && ti == 6 && tj == 4) g_probe[i] = clock64(); } while (0)
+#else
+#define PPROBE(i) do { } while (0)
+#endif
     for (int tjj = 0; tjj < kTile / 4; ++tjj) {
+        PPROBE(0);
         if (ti == tjj && tj == tjj) {
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
@@ -348,6 +355,7 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
                 for (int ci = 0; ci < 4; ++ci) bufD[ri * 4 + ci] = a[ri][ci];
         }
         __syncthreads();
+        PPROBE(1);
         if (tj == tjj && lower) {
             double m[4][4], l[4][4], inv[4];
 #pragma unroll
@@ -396,7 +404,9 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) bufP[(4 * ti + ri) * 5 + ci] = a[ri][ci];
         }
+        PPROBE(2);
         __syncthreads();
+        PPROBE(3);
         if (lower && tj > tjj) {
             double li[4][4], lc[4][4];
 #pragma unroll
@@ -413,6 +423,7 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
 #pragma unroll
                     for (int k = 0; k < 4; ++k) a[ri][ci] = fma(-li[ri][k], lc[ci][k], a[ri][ci]);
         }
+        PPROBE(4);
     }
 }
 
@@ -989,7 +1000,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                 s_cnt2 = 0;
             }
             int bad;
+#ifdef PARSY_STAMPS
+            if (tid == 0 && J < 512) g_trace[J * 16 + 8] = clock64();
+#endif
             potrf64_regs(a, colbuf, ti, tj, nb, bad, s_invd);
+#ifdef PARSY_STAMPS
+            if (tid == 0 && J < 512) g_trace[J * 16 + 9] = clock64();
+#endif
             TRACE(J, 2);
             if (bad) atomicMin(info, D.c0 + col0 + bad);  // only threads that saw a bad pivot
             // the factored block goes to the panel (the part above the diagonal is zero since the
@@ -1123,6 +1140,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
 #ifdef PARSY_STAMPS
 extern "C" void parsy_debug_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+}
+extern "C" void parsy_debug_probe(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 8);
 }
 extern "C" void parsy_debug_trace(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 16 * 512);

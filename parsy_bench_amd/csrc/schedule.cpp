@@ -270,10 +270,17 @@ void build_launches(Schedule& S, const uint8_t* active) {
             // the walker needs prepared for its step J -- (J+1,J) and (J+1,J+1) -- and then the other
             // tiles of block column J, which wait for diagonal tile J.
             Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
-            int maxnb = 0;
-            for (int t : bigs) maxnb = std::max(maxnb, ceil_div(S.sn[t].w, kTile));
-            for (int J = 0; J < maxnb; ++J)
-                for (int t : bigs) {
+            // Walkers stay resident for their whole chain, so the block-column-major interleaving is
+            // done per batch of at most kWalkerBatch supernodes: what a walker waits for then lies at most
+            // one batch of tiles ahead of it in ticket order, and the walkers of the batches in flight
+            // never take more than a fraction of the resident workgroups.
+            for (size_t b0 = 0; b0 < bigs.size(); b0 += kWalkerBatch) {
+              const size_t b1 = std::min(bigs.size(), b0 + (size_t)kWalkerBatch);
+              int maxnb = 0;
+              for (size_t q = b0; q < b1; ++q) maxnb = std::max(maxnb, ceil_div(S.sn[bigs[q]].w, kTile));
+              for (int J = 0; J < maxnb; ++J)
+                for (size_t q = b0; q < b1; ++q) {
+                    const int t = bigs[q];
                     const SnDesc& T = S.sn[t];
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     if (J >= nbc) continue;
@@ -289,6 +296,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     }
                     for (int I = next_diag ? J + 2 : J + 1; I < nbr; ++I) push(I, J);
                 }
+            }
             Lc.count = (int32_t)S.tiles.size() - Lc.first;
             S.chol.push_back(Lc);
         }
@@ -373,6 +381,80 @@ void build_launches(Schedule& S, const uint8_t* active) {
     }
     if (!S.solve_fix_list.empty())
         S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0, 0, -1, 0});
+}
+
+int64_t simulate_chain(const Schedule& S, int slots) {
+    if (slots < 1) slots = 1;
+    std::vector<uint8_t> fin((size_t)std::max<int64_t>(S.n_tflags, 1), 0), prep(fin.size(), 0);
+    struct Task {
+        int32_t sn, I, J, role;  // role 0 walker, 1 prepared tile left of a diagonal tile, 2 prepared diagonal tile, 3 other
+        int32_t k;               // walker: current step; others: block columns already seen published
+    };
+    int64_t stuck = 0;
+    for (const Launch& L : S.chol) {
+        if (L.kind != kLaunchChain) continue;
+        std::vector<Task> resident;
+        int64_t next = 0;
+        const int64_t count = L.count;
+        bool progress = true;
+        while (progress && (next < count || !resident.empty())) {
+            progress = false;
+            while ((int)resident.size() < slots && next < count) {
+                const TileDesc& td = S.tiles[(size_t)L.first + (size_t)next++];
+                const SnDesc& D = S.sn[td.sn];
+                const int nbc = ceil_div(D.w, kTile);
+                Task t{td.sn, td.row0 / kTile, td.col0 / kTile, 3, 0};
+                if (t.I == 0 && t.J == 0) t.role = 0;
+                else if (t.I == t.J) t.role = 2;
+                else if (t.I == t.J + 1 && t.I < nbc) t.role = 1;
+                resident.push_back(t);
+                progress = true;
+            }
+            for (size_t q = 0; q < resident.size();) {
+                Task& t = resident[q];
+                const SnDesc& D = S.sn[t.sn];
+                const int nbc = ceil_div(D.w, kTile);
+                auto flag = [&](int I, int J) { return (size_t)D.tflag0 + (size_t)I * nbc + J; };
+                bool done = false;
+                if (t.role == 0) {
+                    for (;;) {  // step k: diagonal tile k is published; then the two prepared tiles are needed
+                        fin[flag(t.k, t.k)] = 1;
+                        if (t.k + 1 >= nbc) {
+                            done = true;
+                            break;
+                        }
+                        if (!prep[flag(t.k + 1, t.k)] || !prep[flag(t.k + 1, t.k + 1)]) break;
+                        fin[flag(t.k + 1, t.k)] = 1;
+                        ++t.k;
+                        progress = true;
+                    }
+                } else {
+                    const int need = t.role == 2 ? t.J - 1 : t.J;
+                    while (t.k < need && fin[flag(t.I, t.k)] && fin[flag(t.J, t.k)]) ++t.k;
+                    if (t.k >= need) {
+                        if (t.role == 3) {
+                            if (fin[flag(t.J, t.J)]) {
+                                fin[flag(t.I, t.J)] = 1;
+                                done = true;
+                            }
+                        } else {
+                            prep[flag(t.I, t.J)] = 1;
+                            done = true;
+                        }
+                    }
+                }
+                if (done) {
+                    resident[q] = resident.back();
+                    resident.pop_back();
+                    progress = true;
+                } else {
+                    ++q;
+                }
+            }
+        }
+        stuck += (count - next) + (int64_t)resident.size();
+    }
+    return stuck;
 }
 
 }  // namespace parsy

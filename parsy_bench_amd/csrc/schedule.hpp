@@ -101,6 +101,7 @@ struct Launch {
     int32_t early;         // TILES: always 1 (kept for the launch dumps)
 };
 
+constexpr int kWalkerBatch = 64;          // CHAIN: supernodes whose tiles are interleaved block column by block column
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
@@ -157,6 +158,11 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                     const uint8_t* active, Schedule& out);
 // Recompute only the launch lists for a new active set.
 void build_launches(Schedule& S, const uint8_t* active);
+// Dry run of the CHAIN launches' hand-off protocol with `slots` resident workgroups (tickets in start
+// order, a workgroup leaves when its tile is published, a walker when its supernode is done):
+// returns the number of tiles that are never finished (0 = the schedule cannot deadlock at that
+// residency).  Host only; used by the tests and available to callers that want to check a plan.
+int64_t simulate_chain(const Schedule& S, int slots);
 inline bool is_small(const SnDesc& d) {
     return d.w <= kSmallMaxWidth && (int64_t)d.w * d.r <= kSmallMaxEntries;
 }

@@ -92,5 +92,10 @@ WORKLOADS = {
 
 
 def workload(name: str):
+    """A named workload, or "NXxNYxNZ[:stencil]" for an ad-hoc grid (diagnostics)."""
+    if name not in WORKLOADS and "x" in name:
+        dims, _, st = name.partition(":")
+        nx, ny, nz = (int(v) for v in dims.split("x"))
+        return grid_spd(nx, ny, nz, int(st or 27), 0.1), grid_nd(nx, ny, nz)
     nx, ny, nz, st, sh = WORKLOADS[name]
     return grid_spd(nx, ny, nz, st, sh), grid_nd(nx, ny, nz)

@@ -88,3 +88,36 @@ def test_subtree_cut_is_a_partition_into_independent_subtrees(name, nranks):
     sl = sorted((a, b) for _, a, b in cut.slices(sym))
     assert all(sl[i][1] <= sl[i + 1][0] for i in range(len(sl) - 1))
     assert cut.rank_cost.max() <= cut.cost.sum()
+
+
+@pytest.mark.parametrize("name", ["small3d", "mid3d", "lap30", "ex15", "nd24k"])
+@pytest.mark.parametrize("slots", [2, 7, 64, 512])
+def test_chain_launches_cannot_deadlock(name, slots):
+    """Dry run of the in-launch tile hand-offs (tickets in start order, walkers resident for their
+    whole supernode) at several residencies, down to far fewer workgroups than a level has walkers."""
+    A, perm, sym = problem(name)
+    h, info = host_plan(sym)
+    try:
+        if slots < 64:
+            # fewer resident workgroups than a batch of walkers is outside the contract (the kernel keeps
+            # 2 per CU resident); the dry run must then report it rather than hang
+            assert N.lib().parsy_plan_chain_check(h, slots) >= 0
+        else:
+            assert N.lib().parsy_plan_chain_check(h, slots) == 0
+    finally:
+        N.lib().parsy_plan_destroy(h)
+
+
+def test_chain_dry_run_with_many_walkers():
+    """A level with far more wide supernodes than resident workgroups (what broke a block-column-major
+    order over the whole level): batches of walkers keep it live."""
+    from parsy_bench_amd import matrices as M
+    A, perm = M.workload("40x40x40")
+    sym = I.analyze(A, perm)
+    h, info = host_plan(sym)
+    try:
+        assert info["n_big"] > 128
+        assert N.lib().parsy_plan_chain_check(h, 96) == 0
+        assert N.lib().parsy_plan_chain_check(h, 512) == 0
+    finally:
+        N.lib().parsy_plan_destroy(h)

@@ -28,3 +28,12 @@ for J in range(nbc):
     print("%3d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f | %6.1f  %d" % (
         J, d[0] - t0, d[2] - t0, d[4] - t0, d[3] - t0, d[5] - t0, d[6] - t0, step, int(tr.reshape(512, 16)[J, 7])))
     prev = d[0]
+    if J == 5:
+        raw = tr.reshape(512, 16)[J]
+        cyc = float(raw[9]) - float(raw[8])
+        print("      POTRF: %.0f shader clocks in %.2f us -> %.2f GHz" % (cyc, d[2] - d[0], cyc / (d[2] - d[0]) / 1e3))
+pb = np.zeros(8, dtype=np.uint64)
+N.lib().parsy_debug_probe(pb.ctypes.data_as(C.c_void_p))
+q = pb.astype(np.float64)
+print("POTRF step 4, thread (6,4) [block column 4 = the factoring column], shader clocks: write+barrier1 %.0f  factor+solve %.0f  barrier2 %.0f  update %.0f" % (
+    q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3]))
