@@ -312,6 +312,24 @@ def test_full_size_round_trip(api, oracle, name):
     assert ok and np.abs(lv - lo).max() <= 1e-10 * np.abs(lo).max()
 
 
+def test_levels_with_hundreds_of_walkers(api, oracle):
+    """A larger 3-D grid: levels with hundreds of wide supernodes, each with a workgroup that stays
+    resident for the whole supernode (the walker).  The launches must neither deadlock nor time out
+    (status < 0).  (The host dry run in test_schedule_host.py covers residencies below a level's walkers.)"""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("56x56x56")
+    plan = api.Plan(sym, 0)
+    assert plan.info["n_big"] > 512
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    blas = oracle.bind_system_blas()
+    try:
+        ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym), threads=8)
+    finally:
+        oracle.unbind_blas()
+    assert ok and np.abs(lv - lo).max() <= 1e-10 * np.abs(lo).max()
+
+
 def test_unfused_fallback_paths(api, oracle, monkeypatch):
     """The solve schedule used when a chain launch would not be resident (per-block-column
     launches + fix-up) gives the same answers."""
