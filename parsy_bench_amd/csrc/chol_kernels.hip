@@ -58,6 +58,114 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 }
 
 // ---------------------------------------------------------------------------
+// POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked: thread
+// (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers.  Four columns per step:
+//   (1) the owner of the 4x4 diagonal micro-block broadcasts it through LDS,
+//   (2) every thread of that block column factors the micro-block itself (4 pivots in
+//       registers) and solves its own 4x4 block against it, then publishes the 4 new columns,
+//   (3) everybody applies the rank-4 update to its block.
+// inv_out (64 doubles of LDS, optional) receives the reciprocals of the factor's diagonal.
+// Two barriers per 4 columns.  Entries outside the block (nb < 64) must be an identity so the
+// loop is uniform; strictly-upper entries pick up garbage that is never stored.  `scr` is
+// 16 + 64*5 doubles of LDS.  On return a[][] holds the factor; `bad` receives (1-based) the
+// first column whose pivot was not positive.  Pivots use rsqrt (1/sqrt(d) directly: the
+// divide-after-sqrt chain is the critical path of every block step).
+// ---------------------------------------------------------------------------
+static constexpr int kPotrfScratch = 16 + kTile * 5;
+__device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restrict__ scr, int ti, int tj,
+                                             int nb, int& bad, double* __restrict__ inv_out = nullptr) {
+    double* __restrict__ bufD = scr;        // 4x4 micro-block, row-major
+    double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
+    const bool lower = ti >= tj;
+    bad = 0;
+#ifdef PARSY_STAMPS
+#define PPROBE(i) do { if (tjj == 4 && ti == 6 && tj == 4) g_probe[i] = clock64(); } while (0)
+#else
+#define PPROBE(i) do { } while (0)
+#endif
+    const int nsteps = (nb + 3) / 4;  // panels beyond the block are an identity: nothing to do
+    for (int tjj = 0; tjj < nsteps; ++tjj) {
+        PPROBE(0);
+        if (ti == tjj && tj == tjj) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) bufD[ri * 4 + ci] = a[ri][ci];
+        }
+        __syncthreads();
+        PPROBE(1);
+        if (tj == tjj && lower) {
+            double m[4][4], l[4][4], inv[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) m[ri][ci] = bufD[ri * 4 + ci];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                double d = m[jj][jj];
+#pragma unroll
+                for (int k = 0; k < jj; ++k) d = fma(-l[jj][k], l[jj][k], d);
+                if (!(d > 0.0) && bad == 0 && 4 * tjj + jj < nb) bad = 4 * tjj + jj + 1;
+                inv[jj] = rsqrt(d);
+                l[jj][jj] = d * inv[jj];
+#pragma unroll
+                for (int ii = jj + 1; ii < 4; ++ii) {
+                    double v = m[ii][jj];
+#pragma unroll
+                    for (int k = 0; k < jj; ++k) v = fma(-l[ii][k], l[jj][k], v);
+                    l[ii][jj] = v * inv[jj];
+                }
+            }
+            if (ti == tjj) {
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                    for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
+                if (inv_out) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) inv_out[4 * tjj + jj] = (4 * tjj + jj < nb) ? inv[jj] : 1.0;
+                }
+            } else {
+                // X l' = A  (4x4, row by row)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        double v = a[ri][jj];
+#pragma unroll
+                        for (int k = 0; k < jj; ++k) v = fma(-a[ri][k], l[jj][k], v);
+                        a[ri][jj] = v * inv[jj];
+                    }
+            }
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) bufP[(4 * ti + ri) * 5 + ci] = a[ri][ci];
+        }
+        PPROBE(2);
+        __syncthreads();
+        PPROBE(3);
+        if (lower && tj > tjj) {
+            double li[4][4], lc[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    li[q][k] = bufP[(4 * ti + q) * 5 + k];
+                    lc[q][k] = bufP[(4 * tj + q) * 5 + k];
+                }
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[ri][ci] = fma(-li[ri][k], lc[ci][k], a[ri][ci]);
+        }
+        PPROBE(4);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // SMALL: one workgroup per supernode, whole panel resident in LDS.  The updates are a
 // stream of (descendant, k-slice) blocks -- the rows of the descendant from `lb` down, at
 // most kSmallStage doubles -- pumped through a double-buffered LDS stage by all threads
@@ -80,6 +188,12 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
     const SnDesc D = sn[list[blockIdx.x]];
     const int r = D.r, w = D.w, total = r * w;
     double* __restrict__ G = L + D.px;
+#ifdef PARSY_STAMPS
+#define STRACE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_trace[(256 + D.nupd) * 16 + (i)] = wall_clock64(); g_trace[(256 + D.nupd) * 16 + 8] = w; g_trace[(256 + D.nupd) * 16 + 9] = r; } } while (0)
+#else
+#define STRACE(i) do { } while (0)
+#endif
+    STRACE(0);
     const int total_pad = (total + 1) & ~1;
     double* __restrict__ S0 = P + total_pad;
     int32_t* __restrict__ R0 = reinterpret_cast<int32_t*>(S0 + 2 * stage_cap);
@@ -99,6 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
         }
     }
 
+    STRACE(1);
     // ---- stream state: block = (update u, k0, kc) with m * kc <= kSmallStage -----------------
     struct Blk {
         double v[kSmallPerThread];
@@ -180,15 +295,13 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
         if (m > stage_cap) {  // not staged (see issue): straight from the descendant's panel
             const double* __restrict__ src = L + CU.src;
             const int32_t* __restrict__ relg = relpos + CU.rel;
-            for (int e = tid; e < m * n1; e += kThreads) {
-                const int j = e / m, i = e - j * m;
-                if (i >= j) {
+            for (int j = tid >> 6; j < n1; j += kThreads / 64)
+                for (int i = j + (tid & 63); i < m; i += 64) {
                     double acc = 0.0;
                     for (int kk = 0; kk < CU.K; ++kk)
                         acc = fma(src[i + (int64_t)kk * CU.ld], src[j + (int64_t)kk * CU.ld], acc);
                     P[relg[j] * r + relg[i]] -= acc;
                 }
-            }
             ck = 0;
             ++cu;
             consumer_enter();
@@ -198,15 +311,31 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
         const double* __restrict__ S = S0 + stage * stage_cap;
         const int32_t* __restrict__ rel = R0 + (cu & 3) * kSmallRelCap;  // came with the update's first block
         const int32_t* __restrict__ relg = relpos + CU.rel;  // rows beyond the staged indices (rare)
-        const int pairs = m * n1;
-        for (int e = tid; e < pairs; e += kThreads) {
-            const int j = e / m, i = e - j * m;
-            if (i >= j) {
-                double acc = 0.0;
-                for (int kk = 0; kk < kc; ++kk) acc = fma(S[kk * m + i], S[kk * m + j], acc);
+        // one wave per group of four columns j0..j0+3 of the pair block, lanes along the rows
+        // i >= j0: the row operand is read once per k for four products, the column operands
+        // are LDS broadcasts (no integer division anywhere)
+        for (int j0 = 4 * (tid >> 6); j0 < n1; j0 += 4 * (kThreads / 64)) {
+            int rj[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = min(j0 + c, n1 - 1);
+                rj[c] = j < kSmallRelCap ? rel[j] : relg[j];
+            }
+            const int jc1 = min(j0 + 1, m - 1), jc2 = min(j0 + 2, m - 1), jc3 = min(j0 + 3, m - 1);
+            for (int i = j0 + (tid & 63); i < m; i += 64) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < kc; ++kk) {
+                    const double* __restrict__ Sk = S + kk * m;
+                    const double a = Sk[i];
+                    acc[0] = fma(a, Sk[j0], acc[0]);
+                    acc[1] = fma(a, Sk[jc1], acc[1]);
+                    acc[2] = fma(a, Sk[jc2], acc[2]);
+                    acc[3] = fma(a, Sk[jc3], acc[3]);
+                }
                 const int ri = i < kSmallRelCap ? rel[i] : relg[i];
-                const int rj = j < kSmallRelCap ? rel[j] : relg[j];
-                P[rj * r + ri] -= acc;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (j0 + c < n1 && i >= j0 + c) P[rj[c] * r + ri] -= acc[c];
             }
         }
         ck += kc;
@@ -244,35 +373,75 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
         ++p;
     }
 
-    // right-looking POTRF on the w diagonal rows with the r-w rows below carried
-    // along (= POTRF followed by TRSM 'R','L','T','N', reference :204,:218)
-    for (int j = 0; j < w; ++j) {
-        const double d = P[j * r + j];
-        const double s = sqrt(d);
-        const double inv = 1.0 / s;
-        if (tid == 0 && !(d > 0.0)) atomicMin(info, D.c0 + j + 1);
-        __syncthreads();
-        for (int i = j + tid; i < r; i += kThreads) P[j * r + i] = (i == j) ? s : P[j * r + i] * inv;
-        __syncthreads();
-        const int nc = w - j - 1, nr = r - j - 1;
-        for (int e = tid; e < nc * nr; e += kThreads) {
-            const int cc = e / nr;
-            const int c = j + 1 + cc, i = j + 1 + (e - cc * nr);
-            if (i >= c) P[c * r + i] = fma(-P[j * r + i], P[j * r + c], P[c * r + i]);
-        }
-        __syncthreads();
+    STRACE(2);
+    // POTRF of the w x w diagonal block (register-blocked, four columns per step), then the rows
+    // below it: X L' = B by forward substitution, one row per thread, L and its reciprocal
+    // diagonal read from LDS as broadcasts (= POTRF followed by TRSM 'R','L','T','N',
+    // reference :204,:218).
+    double* __restrict__ scratch = reinterpret_cast<double*>(R0 + 4 * kSmallRelCap);  // kPotrfScratch + 64 doubles
+    double* __restrict__ invd = scratch + kPotrfScratch;
+    {
+        const int ti = tid & 15, tj = tid >> 4;
+        double a[4][4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = 4 * ti + ri, c = 4 * tj + ci;
+                double v = (i == c) ? 1.0 : 0.0;
+                if (c < w && i < w && i >= c) v = P[c * r + i];
+                a[ri][ci] = v;
+            }
+        int bad;
+        potrf64_regs(a, scratch, ti, tj, w, bad, invd);
+        if (bad) atomicMin(info, D.c0 + bad);  // only threads that saw a bad pivot
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = 4 * ti + ri, c = 4 * tj + ci;
+                if (c < w && i < w && i >= c) P[c * r + i] = a[ri][ci];
+            }
     }
+    __syncthreads();
+    STRACE(3);
+    for (int i = w + tid; i < r; i += kThreads) {
+        // four columns at a time: one read of x_k serves four products
+        for (int j0 = 0; j0 < w; j0 += 4) {
+            const int j1 = min(j0 + 1, w - 1), j2 = min(j0 + 2, w - 1), j3 = min(j0 + 3, w - 1);
+            double x0 = P[j0 * r + i], x1 = P[j1 * r + i], x2 = P[j2 * r + i], x3 = P[j3 * r + i];
+            for (int k = 0; k < j0; ++k) {
+                const double* __restrict__ Pk = P + k * r;
+                const double xk = Pk[i];
+                x0 = fma(-xk, Pk[j0], x0);
+                x1 = fma(-xk, Pk[j1], x1);
+                x2 = fma(-xk, Pk[j2], x2);
+                x3 = fma(-xk, Pk[j3], x3);
+            }
+            x0 *= invd[j0];
+            x1 = fma(-x0, P[j0 * r + j1], x1) * invd[j1];
+            x2 = fma(-x1, P[j1 * r + j2], fma(-x0, P[j0 * r + j2], x2)) * invd[j2];
+            x3 = fma(-x2, P[j2 * r + j3], fma(-x1, P[j1 * r + j3], fma(-x0, P[j0 * r + j3], x3))) * invd[j3];
+            P[j0 * r + i] = x0;
+            if (j0 + 1 < w) P[j1 * r + i] = x1;
+            if (j0 + 2 < w) P[j2 * r + i] = x2;
+            if (j0 + 3 < w) P[j3 * r + i] = x3;
+        }
+    }
+    __syncthreads();
 
+    STRACE(4);
     for (int e = tid; e < total; e += kThreads) G[e] = P[e];
+    STRACE(5);
 }
 
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
-    // panel (padded to 16 B) + two staged blocks + four index-ring slots
+    // panel (padded to 16 B) + two staged blocks + four index-ring slots + the POTRF's scratch
     stage_cap = min(max(stage_cap, 2), kSmallStage);
     const size_t lds = (size_t)((lds_bytes + 15) & ~15) + 2 * (size_t)stage_cap * sizeof(double) +
-                       4 * kSmallRelCap * sizeof(int32_t);
+                       4 * kSmallRelCap * sizeof(int32_t) + (kPotrfScratch + kTile) * sizeof(double);
     hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.sn,
                        P.upd, P.relpos, P.small_list + first, L, P.info, stage_cap);
 }
@@ -318,113 +487,6 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
     r0 = l0;
     r1 = l1;
     r2 = l2;
-}
-
-// ---------------------------------------------------------------------------
-// POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked: thread
-// (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers.  Four columns per step:
-//   (1) the owner of the 4x4 diagonal micro-block broadcasts it through LDS,
-//   (2) every thread of that block column factors the micro-block itself (4 pivots in
-//       registers) and solves its own 4x4 block against it, then publishes the 4 new columns,
-//   (3) everybody applies the rank-4 update to its block.
-// inv_out (64 doubles of LDS, optional) receives the reciprocals of the factor's diagonal.
-// Two barriers per 4 columns.  Entries outside the block (nb < 64) must be an identity so the
-// loop is uniform; strictly-upper entries pick up garbage that is never stored.  `scr` is
-// 16 + 64*5 doubles of LDS.  On return a[][] holds the factor; `bad` receives (1-based) the
-// first column whose pivot was not positive.  Pivots use rsqrt (1/sqrt(d) directly: the
-// divide-after-sqrt chain is the critical path of every block step).
-// ---------------------------------------------------------------------------
-static constexpr int kPotrfScratch = 16 + kTile * 5;
-__device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restrict__ scr, int ti, int tj,
-                                             int nb, int& bad, double* __restrict__ inv_out = nullptr) {
-    double* __restrict__ bufD = scr;        // 4x4 micro-block, row-major
-    double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
-    const bool lower = ti >= tj;
-    bad = 0;
-#ifdef PARSY_STAMPS
-#define PPROBE(i) do { if (tjj == 4 && ti == 6 && tj == 4) g_probe[i] = clock64(); } while (0)
-#else
-#define PPROBE(i) do { } while (0)
-#endif
-    for (int tjj = 0; tjj < kTile / 4; ++tjj) {
-        PPROBE(0);
-        if (ti == tjj && tj == tjj) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) bufD[ri * 4 + ci] = a[ri][ci];
-        }
-        __syncthreads();
-        PPROBE(1);
-        if (tj == tjj && lower) {
-            double m[4][4], l[4][4], inv[4];
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) m[ri][ci] = bufD[ri * 4 + ci];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                double d = m[jj][jj];
-#pragma unroll
-                for (int k = 0; k < jj; ++k) d = fma(-l[jj][k], l[jj][k], d);
-                if (!(d > 0.0) && bad == 0 && 4 * tjj + jj < nb) bad = 4 * tjj + jj + 1;
-                inv[jj] = rsqrt(d);
-                l[jj][jj] = d * inv[jj];
-#pragma unroll
-                for (int ii = jj + 1; ii < 4; ++ii) {
-                    double v = m[ii][jj];
-#pragma unroll
-                    for (int k = 0; k < jj; ++k) v = fma(-l[ii][k], l[jj][k], v);
-                    l[ii][jj] = v * inv[jj];
-                }
-            }
-            if (ti == tjj) {
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                    for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
-                if (inv_out) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) inv_out[4 * tjj + jj] = (4 * tjj + jj < nb) ? inv[jj] : 1.0;
-                }
-            } else {
-                // X l' = A  (4x4, row by row)
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        double v = a[ri][jj];
-#pragma unroll
-                        for (int k = 0; k < jj; ++k) v = fma(-a[ri][k], l[jj][k], v);
-                        a[ri][jj] = v * inv[jj];
-                    }
-            }
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) bufP[(4 * ti + ri) * 5 + ci] = a[ri][ci];
-        }
-        PPROBE(2);
-        __syncthreads();
-        PPROBE(3);
-        if (lower && tj > tjj) {
-            double li[4][4], lc[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    li[q][k] = bufP[(4 * ti + q) * 5 + k];
-                    lc[q][k] = bufP[(4 * tj + q) * 5 + k];
-                }
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[ri][ci] = fma(-li[ri][k], lc[ci][k], a[ri][ci]);
-        }
-        PPROBE(4);
-    }
 }
 
 typedef __attribute__((address_space(3))) double lds_f64;
@@ -955,6 +1017,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     {
         double* Cb = Tflat;  // buffer that holds the current diagonal tile
         const int ti = tid & 15, tj = tid >> 4;
+        if (tid < kTile) s_invd[tid] = 1.0;  // (entries past a narrow last block are never written by the POTRF)
         for (int J = 0; J < nbc; ++J) {
             const int col0 = J * kTile, nb = min(kTile, w - col0);
             TRACE(J, 0);

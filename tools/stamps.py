@@ -37,3 +37,11 @@ N.lib().parsy_debug_probe(pb.ctypes.data_as(C.c_void_p))
 q = pb.astype(np.float64)
 print("POTRF step 4, thread (6,4) [block column 4 = the factoring column], shader clocks: write+barrier1 %.0f  factor+solve %.0f  barrier2 %.0f  update %.0f" % (
     q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3]))
+print("SMALL kernel, workgroup 0 of a launch, by number of updates: w r | load  updates  potrf  trsm  store (us)")
+T = tr.reshape(512, 16)
+for nu in range(0, 64):
+    row = T[256 + nu]
+    if row[5] == 0:
+        continue
+    x = row[:6].astype(np.float64) / 100.0
+    print("  nupd %2d: w %2d r %3d | %5.1f %6.1f %6.1f %6.1f %5.1f" % (nu, int(row[8]), int(row[9]), x[1]-x[0], x[2]-x[1], x[3]-x[2], x[4]-x[3], x[5]-x[4]))
