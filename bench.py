@@ -290,10 +290,22 @@ def main():
         tile_launches = (pf["launches"]["TILES"] + pf["launches"]["CHAIN"]) // runs
         tile_flops = info["tile_update_flops"] + info["inner_flops"]
         achieved = tile_flops / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0
+        # HBM bytes per launch of the tile kernel from the PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+        # rocprofv3 runs, calibrated on known byte counts in the kernel's access shapes: tools/collect_pmc.sh);
+        # counters cannot be collected inside this run, so the committed summary of the same build is quoted
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
+            if pmc.get("workload") == args.workload and "k_chol_tiles" in pmc.get("kernels", {}):
+                traffic = pmc["kernels"]["k_chol_tiles"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
+        except (OSError, ValueError):
+            pass
         out["roofline"] = {
             "kernel": "k_chol_tiles (TILES + CHAIN launches: FP64-MFMA SYRK/GEMM updates, POTRF/TRSM of the tiles)",
             "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_src,
             "launches_per_factorization": int(tile_launches),
             "algorithmic_flops_per_factorization": tile_flops,
             "avg_launch_ms": tile_ms / max(tile_launches, 1),

@@ -190,7 +190,7 @@ double parsy_last_solve_ms(parsy_plan* plan);
  *   parsy_plan_profile_collect(plan): after the stream is synchronised, add the
  *     elapsed time of every launch of the last factor/solve to its kernel kind.
  *   parsy_plan_profile_get: accumulated ms and launch counts per kind (8 entries:
- *     0 SMALL, 1 TILES, 2 INNER, 3 PANEL, 4 FIXUP, 5 SOLVE_SMALL, 6 SOLVE_PANEL,
+ *     0 SMALL, 1 TILES, 2 CHAIN, 3 and 4 unused, 5 SOLVE_SMALL, 6 SOLVE_PANEL,
  *     7 SOLVE_FIXUP; the arrays passed must hold 8 entries) and the number of collected runs. */
 int parsy_plan_profile(parsy_plan* plan, int enable);
 int parsy_plan_profile_collect(parsy_plan* plan);

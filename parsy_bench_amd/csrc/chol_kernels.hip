@@ -10,6 +10,8 @@
 // descriptors are the flat arrays of schedule.hpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <climits>
 
 #include "kernels.hpp"
@@ -585,30 +587,32 @@ static constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 10
 //   start order and tiles are listed producers-first, so a workgroup only ever waits for
 //   workgroups that have started.  Every wait is bounded; a timeout (or any failure flag) makes
 //   all waiters give up and parsy_factor_status() report < 0.
+struct TileLds {  // LDS of one workgroup of the tile kernel
+    double T[4][kSub * kLdSub];       // the tile, one 32x33 sub-tile per wave
+    double colbuf[kPotrfScratch];     // POTRF scratch
+    double dgbuf[4 * kSub * kLdSub];  // diagonal block + its 16x16 inverses (TRSM) / the walker's next diagonal tile
+    double s_invd[kTile];             // reciprocals of the diagonal of the block being solved against
+    int32_t s_ok, s_task, s_cnt, s_cnt2;
+};
+
 template <bool CHAIN>
-__global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
-                                                            const int32_t* __restrict__ relpos,
-                                                            const WaveEntry* __restrict__ wents,
-                                                            const int64_t* __restrict__ wptr,
-                                                            const TileDesc* __restrict__ tiles,
-                                                            double* __restrict__ L,
-                                                            int* __restrict__ info,
-                                                            int* __restrict__ tflags, int nflags_arg,
-                                                            int* __restrict__ ticket, int epoch) {
-    __shared__ double T[4][kSub * kLdSub];
-    __shared__ double colbuf[kPotrfScratch];
-    __shared__ double dgbuf[4 * kSub * kLdSub];  // diagonal block + its 16x16 inverses (TRSM) / the walker's next diagonal tile
-    __shared__ double s_invd[kTile];  // reciprocals of the diagonal of the block being solved against
-    __shared__ int32_t s_ok, s_task, s_cnt, s_cnt2;
+__device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDesc* __restrict__ sn,
+                                          const int32_t* __restrict__ relpos,
+                                          const WaveEntry* __restrict__ wents,
+                                          const int64_t* __restrict__ wptr,
+                                          const int64_t* __restrict__ split_ranges,
+                                          double* __restrict__ tile_scratch,
+                                          const TileDesc* __restrict__ tiles, double* __restrict__ L,
+                                          int* __restrict__ info, int* __restrict__ tflags,
+                                          const int nflags_arg, const int epoch) {
+    double (&T)[4][kSub * kLdSub] = S.T;
+    double (&colbuf)[kPotrfScratch] = S.colbuf;
+    double (&dgbuf)[4 * kSub * kLdSub] = S.dgbuf;
+    double (&s_invd)[kTile] = S.s_invd;
+    int32_t &s_ok = S.s_ok, &s_cnt = S.s_cnt, &s_cnt2 = S.s_cnt2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int task = blockIdx.x;
-    if (CHAIN) {
-        if (tid == 0) s_task = atomicAdd(ticket, 1);
-        __syncthreads();
-        task = s_task;
-    }
     const TileDesc td = tiles[task];
     const SnDesc D = sn[td.sn];
     const int r = D.r, w = D.w;
@@ -619,6 +623,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     const bool walker = CHAIN && tI == 0 && tJ == 0;
     const bool prep_c = CHAIN && diag_tile && tJ > 0;           // diagonal tile (J,J), J >= 1
     const bool prep_b = CHAIN && tI == tJ + 1 && tI < nbc;      // tile (J+1,J) left of a diagonal tile
+    // the chain's waves go first where they share a SIMD with the side stream's TILES waves (priority 0)
+    if (CHAIN) {
+        if (walker || prep_b || prep_c) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(1);
+    }
 
     const int wa = wave >> 1, wb = wave & 1;
     const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
@@ -629,6 +638,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     const bool diag_sub = subrow0 == subcol0;
 
     // the sub-tile's current values: loads first, LDS stores after the stream's first loads
+    // A tile whose early stream is split over several TILES workgroups: part 0 works on the tile in
+    // place, parts 1.. on partial tiles (start from 0, dense 64x64 in the tile scratch) that the chain
+    // launch adds, in part order, when it loads the tile.
+    const int split_part = CHAIN ? 0 : (td.part & 255);
+    const int split_n = CHAIN ? td.part : (td.part >> 8);
     double tv[kSub * kSub / 64];
     if (wave_on) {
 #pragma unroll
@@ -636,7 +650,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
             const int e = q * 64 + lane;
             const int cc = e >> 5, rr = e & 31;
             const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
-            tv[q] = in ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+            tv[q] = (in && split_part == 0) ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+        }
+        if (CHAIN && split_n > 1) {
+            for (int part = 1; part < split_n; ++part) {
+                const double* __restrict__ PT = tile_scratch + td.sp + (int64_t)(part - 1) * (kTile * kTile);
+#pragma unroll
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    const int cc = e >> 5, rr = e & 31;
+                    const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
+                    if (in) tv[q] += PT[(kSub * wb + cc) * kTile + kSub * wa + rr];
+                }
+            }
         }
     }
     auto store_subtile = [&]() {
@@ -651,8 +677,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     int64_t le = 0, e_end = 0;       // next external entry / end of the list
     int l_kint = 0, n_int = 0;       // next internal block column / their number (CHAIN)
     if (wave_on) {
-        le = wptr[td.wp + wave];
-        e_end = wptr[td.wp + wave + 1];
+        if (!CHAIN && split_n > 1) {
+            le = split_ranges[td.wp + 2 * wave];
+            e_end = split_ranges[td.wp + 2 * wave + 1];
+        } else {
+            le = wptr[td.wp + wave];
+            e_end = wptr[td.wp + wave + 1];
+        }
         if (CHAIN) n_int = prep_c ? tJ - 1 : tJ;  // block column J-1 reaches a diagonal tile through the walker
     }
     bool gave_up = false;
@@ -932,7 +963,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
         }
     };
     if (!CHAIN) {
-        write_tile(Tflat, td.row0, td.col0, 0);
+        if (split_part == 0) {
+            write_tile(Tflat, td.row0, td.col0, 0);
+        } else if (wave_on) {
+            double* __restrict__ PT = tile_scratch + td.sp + (int64_t)(split_part - 1) * (kTile * kTile);
+            for (int e = lane; e < kSub * kSub; e += 64) {
+                const int cc = e >> 5, rr = e & 31;
+                PT[(kSub * wb + cc) * kTile + kSub * wa + rr] = Tw[cc * kLdSub + rr];
+            }
+        }
         return;
     }
     const int nflags = nflags_arg;
@@ -1200,6 +1239,41 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
     }
 }
 
+// TILES: one workgroup per tile (or per part of a tile with a split stream).
+__global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
+                                                            const int32_t* __restrict__ relpos,
+                                                            const WaveEntry* __restrict__ wents,
+                                                            const int64_t* __restrict__ wptr,
+                                                            const int64_t* __restrict__ split_ranges,
+                                                            double* __restrict__ tile_scratch,
+                                                            const TileDesc* __restrict__ tiles,
+                                                            double* __restrict__ L) {
+    __shared__ TileLds S;
+    tile_task<false>(S, blockIdx.x, sn, relpos, wents, wptr, split_ranges, tile_scratch, tiles, L, nullptr, nullptr, 0,
+                     0);
+}
+
+// CHAIN: one workgroup per tile of the launch's list; which one is decided by a ticket taken when the
+// workgroup starts (see tile_task).  (Persistent workers -- fewer workgroups than tiles, each looping
+// over tickets, to leave the side stream more room -- were slower: the levels with many supernodes
+// want every slot.)
+__global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __restrict__ sn,
+                                                            const int32_t* __restrict__ relpos,
+                                                            const WaveEntry* __restrict__ wents,
+                                                            const int64_t* __restrict__ wptr,
+                                                            const int64_t* __restrict__ split_ranges,
+                                                            double* __restrict__ tile_scratch,
+                                                            const TileDesc* __restrict__ tiles,
+                                                            double* __restrict__ L, int* __restrict__ info,
+                                                            int* __restrict__ tflags, int nflags,
+                                                            int* __restrict__ ticket, int epoch) {
+    __shared__ TileLds S;
+    if (threadIdx.x == 0) S.s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    tile_task<true>(S, S.s_task, sn, relpos, wents, wptr, split_ranges, tile_scratch, tiles, L, info, tflags, nflags,
+                    epoch);
+}
+
 #ifdef PARSY_STAMPS
 extern "C" void parsy_debug_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
@@ -1214,16 +1288,16 @@ extern "C" void parsy_debug_trace(unsigned long long* out) {
 
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_tiles<false>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, 0, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_chol_tiles, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos, P.wave_entries,
+                       P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L);
 }
 
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_tiles<true>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos,
-                       P.wave_entries, P.wave_ptr, P.tiles + first, L, P.info, P.tflags, P.n_tflags, P.tickets + ticket,
-                       epoch);
+    hipLaunchKernelGGL(k_chol_chain, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos, P.wave_entries,
+                       P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L, P.info, P.tflags,
+                       P.n_tflags, P.tickets + ticket, epoch);
 }
 
 }  // namespace parsy

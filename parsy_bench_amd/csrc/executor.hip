@@ -64,6 +64,15 @@ static int plan_upload(parsy_plan* pl) {
     if (upload(pl, S.rows, pl->dp.rows, false)) return -1;
     if (upload(pl, S.wave_entries, pl->dp.wave_entries, false)) return -1;
     if (upload(pl, S.wave_ptr, pl->dp.wave_ptr, false)) return -1;
+    if (upload(pl, S.split_ranges, pl->dp.split_ranges, false)) return -1;
+    {
+        void* d = nullptr;
+        const size_t sbytes = (size_t)std::max<int64_t>(S.n_split_doubles, 1) * sizeof(double);
+        PARSY_HIP(hipMalloc(&d, sbytes));
+        pl->owned.push_back(d);
+        pl->dp.tile_scratch = (double*)d;
+        pl->device_bytes += (int64_t)sbytes;
+    }
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, sizeof(int)));

@@ -17,6 +17,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* rows = nullptr;
     const WaveEntry* wave_entries = nullptr;  // update streams of the tile kernel
     const int64_t* wave_ptr = nullptr;
+    const int64_t* split_ranges = nullptr;     // shares of the wave lists of tiles whose early stream is split
+    double* tile_scratch = nullptr;            // partial tiles of the split streams
     const int32_t* small_list = nullptr;
     const TileDesc* tiles = nullptr;
     const int32_t* solve_small_list = nullptr;

@@ -177,15 +177,42 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         // weight of every tile = 16-wide k chunks of its longest wave stream
         S.sn_tw0[t] = (int64_t)S.tile_w.size();
         S.tile_w.resize(S.tile_w.size() + (size_t)nbc * nbr * 2, 0);
+        S.tile_split.resize(S.tile_w.size() / 2, -1);
         int32_t* tw = &S.tile_w[S.sn_tw0[t]];
+        int64_t* tsplit = &S.tile_split[S.sn_tw0[t] / 2];
         const int64_t* wp = &S.wave_ptr[S.sn_wp0[t]];
-        for (size_t tp = 0; tp < (size_t)nbc * nbr * 2; ++tp)
+        for (size_t tp = 0; tp < (size_t)nbc * nbr * 2; ++tp) {
+            int64_t wchunks[4];
             for (int q = 0; q < 4; ++q) {
                 int64_t chunks = 0;
                 for (int64_t e = wp[tp * 4 + q]; e < wp[tp * 4 + q + 1]; ++e)
                     chunks += ceil_div(S.wave_entries[(size_t)e].K, 16);
+                wchunks[q] = chunks;
                 tw[tp] = std::max<int32_t>(tw[tp], (int32_t)std::min<int64_t>(chunks, INT32_MAX));
             }
+            // A launch ends with its longest wave stream: long EARLY streams are cut into parts that
+            // separate workgroups apply to partial tiles (summed, in a fixed order, when the chain
+            // launch loads the tile).  Every wave's list is cut where its own chunk count reaches p/nparts.
+            if ((tp & 1) == 0 && tw[tp] > kSplitChunks) {
+                const int nparts = std::min<int>(kSplitMaxParts, ceil_div(tw[tp], kSplitTarget));
+                Schedule::SplitDesc sd{(int64_t)S.split_ranges.size(), S.n_split_doubles, nparts, 0};
+                S.n_split_doubles += (int64_t)(nparts - 1) * kTile * kTile;
+                S.split_ranges.resize(S.split_ranges.size() + (size_t)nparts * 8, 0);
+                int64_t* rg = &S.split_ranges[(size_t)sd.ranges];
+                for (int q = 0; q < 4; ++q) {
+                    int64_t e = wp[tp * 4 + q], done = 0;
+                    for (int part = 0; part < nparts; ++part) {
+                        rg[part * 8 + 2 * q] = e;
+                        const int64_t goal = wchunks[q] * (part + 1) / nparts;
+                        while (e < wp[tp * 4 + q + 1] && (part == nparts - 1 || done < goal))
+                            done += ceil_div(S.wave_entries[(size_t)e++].K, 16);
+                        rg[part * 8 + 2 * q + 1] = e;
+                    }
+                }
+                tsplit[tp / 2] = (int64_t)S.split_desc.size();
+                S.split_desc.push_back(sd);
+            }
+        }
     }
 
     build_launches(S, active);
@@ -254,9 +281,18 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     for (int J = 0; J < nbc; ++J)
                         for (int I = J; I < nbr; ++I) {
                             const int32_t wgt = tw[((size_t)J * nbr + I) * 2];
-                            if (wgt > 0)
+                            if (wgt <= 0) continue;
+                            const int64_t si = S.tile_split[S.sn_tw0[t] / 2 + (size_t)J * nbr + I];
+                            if (si < 0) {
                                 wt.push_back({wgt, TileDesc{t, I * kTile, J * kTile, 0,
-                                                            S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2) * 4}});
+                                                            S.sn_wp0[t] + (((int64_t)J * nbr + I) * 2) * 4, -1}});
+                            } else {
+                                const Schedule::SplitDesc& sd = S.split_desc[(size_t)si];
+                                for (int part = 0; part < sd.nparts; ++part)
+                                    wt.push_back({ceil_div(wgt, sd.nparts),
+                                                  TileDesc{t, I * kTile, J * kTile, part | (sd.nparts << 8),
+                                                           sd.ranges + part * 8, sd.sp}});
+                            }
                         }
                 }
                 std::stable_sort(wt.begin(), wt.end(),
@@ -285,8 +321,11 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     if (J >= nbc) continue;
                     auto push = [&](int I, int Jc) {
-                        S.tiles.push_back(TileDesc{t, I * kTile, Jc * kTile, 0,
-                                                   S.sn_wp0[t] + (((int64_t)Jc * nbr + I) * 2 + 1) * 4});
+                        const int64_t si = S.tile_split[S.sn_tw0[t] / 2 + (size_t)Jc * nbr + I];
+                        S.tiles.push_back(TileDesc{t, I * kTile, Jc * kTile,
+                                                   si < 0 ? 0 : S.split_desc[(size_t)si].nparts,
+                                                   S.sn_wp0[t] + (((int64_t)Jc * nbr + I) * 2 + 1) * 4,
+                                                   si < 0 ? -1 : S.split_desc[(size_t)si].sp});
                     };
                     if (J == 0) push(0, 0);
                     const bool next_diag = J + 1 < nbc;

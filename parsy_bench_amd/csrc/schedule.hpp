@@ -68,12 +68,15 @@ struct WaveEntry {    // one (descendant, 32x32 sub-tile) pair of the tile kerne
     int32_t mn;       // rows in the row window | rows in the column window << 8  (1..32 each)
 };
 
-struct TileDesc {     // one workgroup of the TILES / INNER kernels
+struct TileDesc {     // one workgroup of the TILES / CHAIN kernels
     int32_t sn;
     int32_t row0, col0;   // tile origin inside the panel (multiples of 64, row0 >= col0)
-    int32_t pad;
+    int32_t part;         // tiles whose early update stream is split over several workgroups:
+                          // TILES: part index | number of parts << 8; CHAIN: number of parts (0 / 1: not split)
     int64_t wp;           // wave_ptr[wp + q .. wp + q + 1] = WaveEntry range of wave q (sub-tile rows
-                          // 32*(q>>1).., columns 32*(q&1)..): early list (TILES) / late list (CHAIN)
+                          // 32*(q>>1).., columns 32*(q&1)..): early list (TILES) / late list (CHAIN);
+                          // a split TILES task: split_ranges[wp + 2q], [wp + 2q + 1] = its share of wave q's list
+    int64_t sp;           // split tiles: offset (doubles) in the tile scratch of the partial tiles of parts 1..
 };
 
 struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
@@ -101,6 +104,9 @@ struct Launch {
     int32_t early;         // TILES: always 1 (kept for the launch dumps)
 };
 
+constexpr int kSplitChunks = 192;        // early wave streams longer than this (16-wide k chunks) are split ...
+constexpr int kSplitTarget = 128;        // ... into parts of about this length (at most kSplitMaxParts)
+constexpr int kSplitMaxParts = 4;
 constexpr int kWalkerBatch = 64;          // CHAIN: supernodes whose tiles are interleaved block column by block column
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
@@ -144,6 +150,11 @@ struct Schedule {
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches
     std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow
+    std::vector<int64_t> split_ranges;    // split tiles: per part 4 x (begin, end) into wave_entries
+    std::vector<int64_t> tile_split;      // per (tiled supernode, J, I) as tile_w / 2: index into split_desc or -1
+    struct SplitDesc { int64_t ranges; int64_t sp; int32_t nparts; int32_t pad; };
+    std::vector<SplitDesc> split_desc;    // ranges: first index in split_ranges (8 per part); sp: scratch offset
+    int64_t n_split_doubles = 0;          // tile scratch: (nparts - 1) * 64 * 64 doubles per split tile
     std::vector<int64_t> sn_wp0;       // per supernode: first index into wave_ptr (-1: SMALL)
     std::vector<int64_t> sn_tw0;       // per supernode: first index into tile_w (-1: SMALL)
     std::vector<int32_t> tile_w;       // per (tiled supernode, J, I, phase): 16-wide k chunks of the longest of its
