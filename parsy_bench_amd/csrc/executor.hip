@@ -217,7 +217,9 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
             case kLaunchSolveFixup:
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
-            case kLaunchBackBlock: launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
+            case kLaunchBackBlock:
+                launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, l.fused, pl->epoch, stream);
+                break;
         }
     }
     profile_mark(pl, -1, stream, cursor);
@@ -233,10 +235,22 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         set_last_error("parsy_backsolve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
+    const int64_t need = (int64_t)ldx * nrhs;
+    // one epoch per pass of right-hand sides (what the chain launches publish / wait for)
+    const int passes = (nrhs + 3) / 4;
+    if (pl->epoch > INT_MAX - 2 * passes - 2) pl->epoch = 0;
+    pl->epoch += 1;
+    if (pl->S.max_width > kTile && pl->xscratch_len < need) {
+        if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
+        pl->xscratch = nullptr;
+        PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
+        pl->xscratch_len = need;
+    }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
     run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+    pl->epoch += passes;
     pl->have_s = true;
     return 0;
 }

@@ -51,8 +51,8 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
                          hipStream_t stream);
-void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x, int nrhs,
-                         int ldx, hipStream_t stream);
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
+                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

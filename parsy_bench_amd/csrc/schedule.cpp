@@ -400,14 +400,41 @@ void build_launches(Schedule& S, const uint8_t* active) {
         }
         S.chol.swap(merged);
     }
-    // ---- backward solve: root level first; within a level the narrow supernodes and, for the
-    // wide ones, the block columns from the last one down (one launch per block-column index)
+    // ---- backward solve: root level first.  Per level one chain launch for the block columns of
+    // the wide supernodes (last block column first: block jb waits for the published x of blocks
+    // jb+1.. of its supernode; every workgroup of the launch must be resident) and one launch for the
+    // supernodes of a single block; when the chain would not be resident, one launch per block-column
+    // index from the last one down.
     S.bsolve_blocks.clear();
     S.bsolve.clear();
     for (int lev = S.nlevels - 1; lev >= 0; --lev) {
-        int maxnb = 0;
-        for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q)
-            if (S.active[S.levelSet[q]]) maxnb = std::max(maxnb, ceil_div(S.sn[S.levelSet[q]].w, kTile));
+        int maxnb = 0, wide_blocks = 0;
+        for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+            const int t = S.levelSet[q];
+            if (!S.active[t]) continue;
+            const int nbc = ceil_div(S.sn[t].w, kTile);
+            maxnb = std::max(maxnb, nbc);
+            if (nbc > 1) wide_blocks += nbc;
+        }
+        if (wide_blocks > 0 && wide_blocks <= max_chain) {
+            Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 1, 0, -1, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                const int nbc = ceil_div(S.sn[t].w, kTile);
+                if (!S.active[t] || nbc < 2) continue;
+                for (int jb = nbc - 1; jb >= 0; --jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
+            }
+            Lc.count = (int32_t)S.bsolve_blocks.size() - Lc.first;
+            S.bsolve.push_back(Lc);
+            Launch Ln{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 0, 0, -1, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (S.active[t] && ceil_div(S.sn[t].w, kTile) == 1) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
+            }
+            Ln.count = (int32_t)S.bsolve_blocks.size() - Ln.first;
+            if (Ln.count > 0) S.bsolve.push_back(Ln);
+            continue;
+        }
         for (int jb = maxnb - 1; jb >= 0; --jb) {
             Launch Lb{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, jb, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {

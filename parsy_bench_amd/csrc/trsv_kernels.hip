@@ -445,10 +445,16 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            const PanelDesc* __restrict__ pds,
                                                            const int32_t* __restrict__ rows,
                                                            const double* __restrict__ L,
-                                                           double* __restrict__ x, int nrhs, int ldx) {
+                                                           double* __restrict__ x, double* __restrict__ xscratch,
+                                                           int nrhs, int ldx, int chain, int* __restrict__ flags,
+                                                           int epoch0, int* __restrict__ info) {
+    // chain != 0: every block column of the wide supernodes of a level is in this launch (all
+    // resident); block jb takes the x of blocks jb+1.. of its supernode as they are published
+    // (xscratch, 8-byte agent-scope atomics both sides + a flag per block and pass).
     __shared__ double Dg[kTile * kLdDiag];
     __shared__ double invd[kTile];
     __shared__ double ts[kTile][NQ];
+    __shared__ int s_ok;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const PanelDesc pd = pds[blockIdx.x];
     const SnDesc D = sn[pd.sn];
@@ -495,8 +501,11 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
             if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
     }
 
-    for (int q0 = 0; q0 < nrhs; q0 += NQ) {
+    const int nbc = (w + kTile - 1) / kTile;
+    int pass = 0;
+    for (int q0 = 0; q0 < nrhs; q0 += NQ, ++pass) {
         const int nq = min(NQ, nrhs - q0);
+        const int epoch = epoch0 + pass;
         __syncthreads();
         for (int e = tid; e < kTile * NQ; e += kThreads) {
             const int c = e & 63, q = e >> 6;
@@ -510,7 +519,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
             for (int ci = 0; ci < kTile / 4; ++ci)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[ci][q] = 0.0;
-            for (int k = kbeg + lane; k < r; k += 64) {
+            // rows below the supernode's own columns (ancestors: final before this launch); without
+            // the chain also the rows of the later blocks (solved by earlier launches)
+            for (int k = (chain ? w : kbeg) + lane; k < r; k += 64) {
                 const int xr = (k < w) ? (D.c0 + k) : ri[k];
                 double xk[NQ];
 #pragma unroll
@@ -521,6 +532,42 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                     const double lv = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv, xk[q], acc[ci][q]);
+                }
+            }
+            if (chain) {
+                // the later blocks of this supernode, last one first, each as soon as it is published
+                for (int I = nbc - 1; I > pd.jb; --I) {
+                    const unsigned long long t0 = wall_clock64();
+                    bool ok = true;
+                    // epochs only grow: a later pass may already have raised the flag
+                    while (__hip_atomic_load(&flags[D.dslot + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
+                        if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (!ok) {
+                        if (lane == 0) atomicMin(info, -1);
+                        break;  // (the result is wrong and reported; nobody may hang)
+                    }
+                    const int k = I * kTile + lane;
+                    if (k < w) {
+                        double xk[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            xk[q] = (q < nq) ? __hip_atomic_load(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + k],
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : 0.0;
+#pragma unroll
+                        for (int ci = 0; ci < kTile / 4; ++ci) {
+                            const int c = wave + 4 * ci;
+                            const double lv = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv, xk[q], acc[ci][q]);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -563,19 +610,30 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
         for (int e = tid; e < wbk * nq; e += kThreads) {
             const int q = e / wbk, c = e - q * wbk;
             x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = ts[c][q];
+            if (chain)
+                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], ts[c][q], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (chain) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(&flags[D.dslot + pd.jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x, int nrhs,
-                         int ldx, hipStream_t stream) {
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
+                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, hipStream_t stream) {
     if (count <= 0) return;
     if (nrhs == 1)
         hipLaunchKernelGGL(k_bsolve_block<1>, dim3(count), dim3(kThreads), 0, stream, P.sn,
-                           P.bsolve_blocks + first, P.rows, L, x, nrhs, ldx);
+                           P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
+                           P.info);
     else
         hipLaunchKernelGGL(k_bsolve_block<4>, dim3(count), dim3(kThreads), 0, stream, P.sn,
-                           P.bsolve_blocks + first, P.rows, L, x, nrhs, ldx);
+                           P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
+                           P.info);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.

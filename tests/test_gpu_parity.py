@@ -346,6 +346,11 @@ def test_unfused_fallback_paths(api, oracle, monkeypatch):
     X, _ = plan.solve(lo, np.stack([b, 2 * b, b + 1.0], axis=1))
     xo = oracle.blocked_lsolve(sym, lo, b + 1.0, "serial")
     assert np.abs(X[:, 0] - 1.0).max() <= 1e-9 and np.abs(X[:, 2] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+    # the backward solve's fallback (one launch per block-column index) against the checker
+    y = np.linspace(-1.0, 1.0, sym.n)
+    Xb, _ = plan.solve2(lo, y[:, None], forward=False)
+    xb = oracle.blocked_ltsolve(sym, lo, y)
+    assert np.abs(Xb[:, 0] - xb).max() <= SOLVE_TOL * max(1.0, np.abs(xb).max())
     monkeypatch.delenv("PARSY_FORCE_UNFUSED")
     plan2 = api.Plan(sym, 0)
     assert plan2.info["solve_launches"] < info["solve_launches"]  # the chain schedule has fewer launches
