@@ -339,6 +339,14 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
             const int cb = jb * kTile, wbk = min(kTile, w - cb);
             const int owner = cb / kSolveRows;
             if (chunk < owner) break;  // no rows at or below this block column
+            // this thread's row of L against block column jb: all 64 loads are issued here, BEFORE the
+            // wait for x_jb, so that their latency hides behind the hand-off
+            const bool below = kv && k >= cb + wbk;
+            double lv[kTile];
+            if (below) {
+#pragma unroll
+                for (int c = 0; c < kTile; ++c) lv[c] = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+            }
             __syncthreads();           // xs / ts of the previous block column are free
             if (chunk == owner) {
                 const int lr = k - cb;  // row inside the block for the 64 threads that hold it
@@ -400,11 +408,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
                 __syncthreads();
             }
             // rows strictly below the diagonal block: acc += L[k, cb..cb+wbk) x_jb
-            // (all 64 loads of the row in flight at once: one memory latency per block column)
-            if (kv && k >= cb + wbk) {
-                double lv[kTile];
-#pragma unroll
-                for (int c = 0; c < kTile; ++c) lv[c] = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+            if (below) {
 #pragma unroll
                 for (int c = 0; c < kTile; ++c)
 #pragma unroll

@@ -18,3 +18,14 @@ for _ in range(reps):
     plan.factor_device(values.data_ptr(), L.data_ptr(), 0)
 torch.cuda.synchronize()
 print("status", plan.status(), "ms", plan.last_factor_ms())
+nsolve = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if nsolve:
+    x = torch.ones(sym.n, dtype=torch.float64, device=dev)
+    for _ in range(nsolve):
+        plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+        torch.cuda.synchronize()
+    print("forward solve ms", plan.last_solve_ms())
+    for _ in range(nsolve):
+        plan.backsolve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+        torch.cuda.synchronize()
+    print("backward solve ms", plan.last_solve_ms())

@@ -15,14 +15,18 @@ ks.sort()
 starts = [i for i, k in enumerate(ks) if "k_scatter_a" in k[2]]
 if not starts:
     sys.exit("no k_scatter_a in trace")
+SOLVE = len(sys.argv) > 2 and sys.argv[2] == "solve"
 b = starts[-1]
 e = len(ks)
+if SOLVE:  # the last forward + backward solve instead: from the last k_diag_inverse on
+    dinv = [i for i, k in enumerate(ks) if "k_diag_inverse" in k[2]]
+    b = dinv[-1]
 t0 = ks[b][0]
 prev_end = t0
 tot = {}
 for s, en, name, grid, wg, q in ks[b:e]:
     short = name.split("(")[0].replace("parsy::", "").replace("void ", "")
-    if "solve" in short:
+    if "solve" in short and not SOLVE:
         break
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(en - s) / 1e3:8.1f}  gap {(s - prev_end) / 1e3:7.1f}  wgs {grid // max(wg, 1):6d}  q={q}  {short}")
     prev_end = max(prev_end, en)
