@@ -541,6 +541,14 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
             if (chain) {
                 // the later blocks of this supernode, last one first, each as soon as it is published
                 for (int I = nbc - 1; I > pd.jb; --I) {
+                    // this lane's row of block I against the wave's 16 columns: loaded BEFORE the wait
+                    const int k = I * kTile + lane;
+                    double lv[kTile / 4];
+#pragma unroll
+                    for (int ci = 0; ci < kTile / 4; ++ci) {
+                        const int c = wave + 4 * ci;
+                        lv[ci] = (c < wbk && k < w) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+                    }
                     const unsigned long long t0 = wall_clock64();
                     bool ok = true;
                     // epochs only grow: a later pass may already have raised the flag
@@ -556,7 +564,6 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                         if (lane == 0) atomicMin(info, -1);
                         break;  // (the result is wrong and reported; nobody may hang)
                     }
-                    const int k = I * kTile + lane;
                     if (k < w) {
                         double xk[NQ];
 #pragma unroll
@@ -565,12 +572,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                              : 0.0;
 #pragma unroll
-                        for (int ci = 0; ci < kTile / 4; ++ci) {
-                            const int c = wave + 4 * ci;
-                            const double lv = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+                        for (int ci = 0; ci < kTile / 4; ++ci)
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv, xk[q], acc[ci][q]);
-                        }
+                            for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv[ci], xk[q], acc[ci][q]);
                     }
                 }
             }
