@@ -163,6 +163,37 @@ def test_not_positive_definite_reports_the_column(api, oracle):
     assert plan.status() == 0
 
 
+@pytest.mark.parametrize("where", ["first_block", "second_block", "small_supernode"])
+def test_not_positive_definite_in_every_kind_of_supernode(api, oracle, where):
+    """A failing pivot inside a wide supernode (the walker's POTRF, first and later block columns) and
+    inside an LDS-resident one: the first failing column is reported, nothing hangs, and the plan is
+    usable afterwards."""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("mid3d")
+    w = np.diff(sym.super)
+    wide = int(np.argmax(w))  # the root separator: several block columns
+    assert w[wide] > 128
+    if where == "first_block":
+        col = int(sym.super[wide]) + 5
+    elif where == "second_block":
+        col = int(sym.super[wide]) + 64 + 17
+    else:
+        col = int(sym.super[0]) + (int(w[0]) - 1)  # last column of the first (leaf) supernode
+    vals = sym.A2x.copy()
+    d = int(sym.A2p[col])
+    assert sym.A2i[d] == col
+    vals[d] = -1e3
+    plan = api.Plan(sym, 0)
+    plan.factor(vals)
+    ok, lo, _ = oracle.cholesky_05(sym, vals, I.trivial_hlevel(sym))
+    assert not ok
+    assert plan.status() == col + 1
+    lv2, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok and np.abs(lv2 - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
 def _check_small(api, oracle, A, perm, nrhs=2):
     from parsy_bench_amd import inspector as I
     sym = I.analyze(A, perm)
