@@ -563,7 +563,8 @@ __device__ __noinline__ void invert_and_trsm(lds_f64* __restrict__ tile, lds_f64
 }
 
 static constexpr int kKC = 16;        // k extent of one chunk of an update stream
-static constexpr int kInFlight = 4;   // chunks in flight per wave (operands prefetched into registers)
+static constexpr int kInFlightChain = 4;  // chunks in flight per wave (operands prefetched into registers)
+static constexpr int kInFlightTiles = 3;  // ... in the TILES launch: fewer registers, three workgroups per CU
 static constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 // One workgroup per 64x64 tile of a panel, one wave per 32x32 sub-tile, and the four waves run
@@ -605,6 +606,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                                           const TileDesc* __restrict__ tiles, double* __restrict__ L,
                                           int* __restrict__ info, int* __restrict__ tflags,
                                           const int nflags_arg, const int epoch) {
+    constexpr int kInFlight = CHAIN ? kInFlightChain : kInFlightTiles;
     double (&T)[4][kSub * kLdSub] = S.T;
     double (&colbuf)[kPotrfScratch] = S.colbuf;
     double (&dgbuf)[4 * kSub * kLdSub] = S.dgbuf;
@@ -1240,7 +1242,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
 }
 
 // TILES: one workgroup per tile (or per part of a tile with a split stream).
-__global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __restrict__ sn,
+__global__ __launch_bounds__(kThreads, 3) void k_chol_tiles(const SnDesc* __restrict__ sn,
                                                             const int32_t* __restrict__ relpos,
                                                             const WaveEntry* __restrict__ wents,
                                                             const int64_t* __restrict__ wptr,
@@ -1248,7 +1250,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_tiles(const SnDesc* __rest
                                                             double* __restrict__ tile_scratch,
                                                             const TileDesc* __restrict__ tiles,
                                                             double* __restrict__ L) {
-    __shared__ TileLds S;
+    // only the tile itself lives in LDS here (the T member comes first in TileLds; nothing else of it
+    // is touched when CHAIN == false): 33 KB and <= 168 registers, so three workgroups fit a CU --
+    // or two beside a workgroup of the chain launch
+    __shared__ double Tonly[4 * kSub * kLdSub];
+    TileLds& S = *reinterpret_cast<TileLds*>(Tonly);
     tile_task<false>(S, blockIdx.x, sn, relpos, wents, wptr, split_ranges, tile_scratch, tiles, L, nullptr, nullptr, 0,
                      0);
 }
