@@ -174,8 +174,9 @@ void build_launches(Schedule& S, const uint8_t* active);
 // returns the number of tiles that are never finished (0 = the schedule cannot deadlock at that
 // residency).  Host only; used by the tests and available to callers that want to check a plan.
 int64_t simulate_chain(const Schedule& S, int slots);
+constexpr int kSmallMaxUpdates = 8;   // supernodes with more updates go the tiled way (MFMA streams, parallel tiles)
 inline bool is_small(const SnDesc& d) {
-    return d.w <= kSmallMaxWidth && (int64_t)d.w * d.r <= kSmallMaxEntries;
+    return d.w <= kSmallMaxWidth && (int64_t)d.w * d.r <= kSmallMaxEntries && d.nupd <= kSmallMaxUpdates;
 }
 
 }  // namespace parsy
