@@ -31,7 +31,7 @@ cf, cfn = per_kernel(sys.argv[2], "FETCH_SIZE")
 cw, cwn = per_kernel(sys.argv[3], "WRITE_SIZE")
 bf, bfn = per_kernel(sys.argv[4], "FETCH_SIZE")
 bw, bwn = per_kernel(sys.argv[5], "WRITE_SIZE")
-nfact = int(sys.argv[6])
+nfact = int(pick(bfn, "k_scatter_a")) or int(sys.argv[6])  # one A scatter per factorization
 
 bytes_per_fetch_8 = calib["calib_read8_mfma_bytes"] * pick(cfn, "calib_read8_mfma") / pick(cf, "calib_read8_mfma")
 bytes_per_fetch_16 = calib["calib_read16_bytes"] * pick(cfn, "calib_read16") / pick(cf, "calib_read16")
