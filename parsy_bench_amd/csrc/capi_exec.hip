@@ -289,7 +289,7 @@ int parsy_factor_status(parsy_plan* pl) {
     if (!pl || pl->device < 0) return -1;
     int v = 0;
     if (hipMemcpy(&v, pl->dp.info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v >= 0x7f7f7f7f ? 0 : v;  // < 0: a fused wait timed out (internal error)
+    return v >= 0x7f7f7f7f ? 0 : v;  // < 0: an in-launch wait timed out (internal error)
 }
 
 int parsy_solve_device(parsy_plan* pl, const double* d_lValues, double* d_x, int nrhs, int ldx,

@@ -449,13 +449,9 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
 }
 
 // ---------------------------------------------------------------------------
-// TILES / INNER: one workgroup per 64x64 tile of a panel, one wave per 32x32
-// sub-tile.  The sub-tile lives in LDS (each wave owns its own, so the update
-// loop needs no barrier and the summation order is fixed: update order, then
-// k).  The dense product of an update is formed in descendant coordinates with
-// v_mfma_f64_16x16x4_f64 straight from the descendant's column-major panel
-// (rows of a 16-row fragment are contiguous: 128-B segments per k), then
-// scatter-subtracted through the relative indices.
+// TILES / CHAIN: one workgroup per 64x64 tile of a panel, one wave per 32x32
+// sub-tile (see tile_task below).  The sub-tile lives in LDS (each wave owns its own, so the
+// update loop needs no barrier and the summation order is fixed: update order, then k).
 // ---------------------------------------------------------------------------
 // Hand-off accesses of the chain launch (tiles published inside a launch): 8-byte agent-scope
 // relaxed atomics = global_load/store_dwordx2 sc1 -- write-through stores, loads that bypass the

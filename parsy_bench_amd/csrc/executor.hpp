@@ -19,7 +19,7 @@ struct parsy_plan {
     std::vector<void*> launch_owned; // the launch-array blocks
     parsy::DevicePattern dp;
     int64_t device_bytes = 0;
-    int epoch = 0;            // factorization counter (value the fused launches publish / wait for)
+    int epoch = 0;            // factorization counter (value the chain launches publish / wait for)
 
     double* dinv = nullptr;       // inverse 64x64 diagonal blocks of the wide supernodes (solve)
     double* xscratch = nullptr;

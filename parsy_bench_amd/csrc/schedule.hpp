@@ -121,7 +121,7 @@ struct Schedule {
     int n_chain_launches = 0;      // CHAIN launches (one ticket counter each)
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;
     double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)
-    double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (INNER launches)
+    double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (CHAIN launches)
 
     std::vector<SnDesc> sn;
     std::vector<UpdDesc> upd;
