@@ -51,6 +51,10 @@ int plan_upload_launches(parsy_plan* pl) {
         pl->launch_owned.push_back(d);
         pl->dp.tickets = (int*)d;
     }
+    // hipMemcpy from pageable memory returns when the data is staged, hipMemset when it is enqueued:
+    // both are only ordered against the NULL stream.  The caller's stream may be a non-blocking one,
+    // so everything must have landed before the plan is handed out.
+    PARSY_HIP(hipDeviceSynchronize());
     return 0;
 }
 

@@ -343,6 +343,31 @@ def test_full_size_round_trip(api, oracle, name):
     assert ok and np.abs(lv - lo).max() <= 1e-10 * np.abs(lo).max()
 
 
+def test_first_factorization_on_a_callers_non_blocking_stream(api, oracle):
+    """A fresh plan used at once on a non-blocking stream (what torch.cuda.Stream() creates): the
+    plan's uploads (pageable hipMemcpy, hipMemset: ordered against the NULL stream only) must have
+    landed before parsy_plan_create returns.  The first factor must equal the default-stream one bitwise."""
+    torch = pytest.importorskip("torch")
+    A, perm, sym = problem("nd24k")
+    dev = torch.device("cuda", 0)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    L0 = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    L1 = torch.full((int(sym.xsize),), float("nan"), dtype=torch.float64, device=dev)
+    plan0 = api.Plan(sym, 0)
+    plan0.factor_device(values.data_ptr(), L0.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert plan0.status() == 0
+    st = torch.cuda.Stream(device=dev)
+    for _ in range(3):  # fresh plan each time: the race is between plan creation and its first use
+        plan = api.Plan(sym, 0)
+        plan.factor_device(values.data_ptr(), L1.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        assert plan.status() == 0
+        assert bool(torch.equal(L0, L1))
+        L1.fill_(float("nan"))
+        plan.close()
+
+
 def test_levels_with_hundreds_of_walkers(api, oracle):
     """A larger 3-D grid: levels with hundreds of wide supernodes, each with a workgroup that stays
     resident for the whole supernode (the walker).  The launches must neither deadlock nor time out
