@@ -40,5 +40,32 @@ for name, reps in (("mid3d", 1500), ("lap30", 600), ("nd24k", 600)):
             stat += st != 0
         print(f"{name:6s} {mode:14s}: {reps} rounds, {mism} factor mismatches, {stat} bad status, {time.time() - t0:.1f} s", flush=True)
         bad += mism + stat
+# the solve chains (forward: flags + published x blocks, atomics on shared rows -> equal to rounding;
+# backward: fixed order -> bitwise)
+for name, reps in (("lap30", 1000), ("nd24k", 1000)):
+    A, perm = M.workload(name)
+    sym = I.analyze(A, perm)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    plan = api.Plan(sym, 0)
+    L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    plan.factor_device(values.data_ptr(), L.data_ptr(), 0)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    b = torch.from_numpy(rng.standard_normal(sym.n)).to(dev)
+    x = b.clone(); plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0); torch.cuda.synchronize()
+    xf = x.clone()
+    y = b.clone(); plan.backsolve_device(L.data_ptr(), y.data_ptr(), 1, sym.n, 0); torch.cuda.synchronize()
+    yb = y.clone()
+    torch.cuda.synchronize()
+    worst = 0.0; bmis = 0; stat = 0
+    for i in range(reps):
+        x.copy_(b); plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+        y.copy_(b); plan.backsolve_device(L.data_ptr(), y.data_ptr(), 1, sym.n, 0)
+        torch.cuda.synchronize()
+        worst = max(worst, float((x - xf).abs().max() / xf.abs().max()))
+        bmis += not bool(torch.equal(y, yb))
+        stat += plan.status() != 0
+    print(f"{name:6s} solves: {reps} rounds, forward max rel deviation {worst:.2e}, backward mismatches {bmis}, bad status {stat}", flush=True)
+    bad += bmis + stat + (worst > 1e-12)
 print("SOAK", "OK" if bad == 0 else "FAILED")
 sys.exit(1 if bad else 0)
