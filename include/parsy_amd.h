@@ -253,6 +253,10 @@ int64_t parsy_grid_spd_lower(int nx, int ny, int nz, int stencil, double shift, 
                              int* Ai, double* Ax);
 /* Geometric nested dissection, perm[new] = old, nx*ny*nz entries. */
 int parsy_grid_nested_dissection(int nx, int ny, int nz, int leaf, int* perm);
+/* Fill-reducing ordering of an arbitrary symmetric pattern (lower triangle, CSC): nested dissection
+ * on the graph with level-structure separators (the reference calls METIS, cholesky/LSparsity.h:
+ * not in this build).  leaf <= 0 picks the default (64).  perm[new] = old, n entries.  0 on success. */
+int parsy_order_nd(int n, const int* Ap, const int* Ai, int leaf, int* perm);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ EXPORTED_SYMBOLS = [
     "parsy_factor_host", "parsy_solve_host", "parsy_last_factor_ms", "parsy_last_solve_ms",
     "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
-    "parsy_grid_nested_dissection", "parsy_plan_profile", "parsy_plan_profile_collect",
+    "parsy_grid_nested_dissection", "parsy_order_nd", "parsy_plan_profile", "parsy_plan_profile_collect",
     "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve2_host",
 ]
 
@@ -80,6 +80,7 @@ def _declare(lib):
     lib.parsy_grid_spd_lower.restype = C.c_int64
     lib.parsy_grid_spd_lower.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]
     lib.parsy_grid_nested_dissection.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.parsy_order_nd.argtypes = [C.c_int, vp, vp, C.c_int, vp]
     lib.parsy_plan_create.restype = vp
     lib.parsy_plan_create.argtypes = [C.c_int, C.c_int] + [vp] * 10 + [C.c_int]
     lib.parsy_plan_from_symbolic.restype = vp

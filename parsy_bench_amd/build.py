@@ -18,7 +18,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libparsy_amd.so"
 OBJ = PKG / "build"
 
-HOST_SOURCES = ["inspector.cpp", "gen.cpp", "capi_host.cpp", "schedule.cpp"]
+HOST_SOURCES = ["inspector.cpp", "gen.cpp", "ordering.cpp", "capi_host.cpp", "schedule.cpp"]
 HIP_SOURCES = ["executor.hip", "chol_kernels.hip", "trsv_kernels.hip", "capi_exec.hip"]
 ARCH = "gfx950"
 

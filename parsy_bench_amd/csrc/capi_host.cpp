@@ -6,6 +6,7 @@
 #include "../../include/parsy_amd.h"
 #include "errors.hpp"
 #include "gen.hpp"
+#include "ordering.hpp"
 #include "inspector.hpp"
 
 namespace parsy {
@@ -95,6 +96,22 @@ int64_t parsy_grid_spd_lower(int nx, int ny, int nz, int stencil, double shift, 
         return (int64_t)i.size();
     } catch (const std::exception& e) {
         parsy::set_last_error(std::string("parsy_grid_spd_lower: ") + e.what());
+        return -1;
+    }
+}
+
+int parsy_order_nd(int n, const int* Ap, const int* Ai, int leaf, int* perm) {
+    if (!perm) {
+        parsy::set_last_error("parsy_order_nd: perm is NULL");
+        return -1;
+    }
+    try {
+        std::vector<int> p;
+        parsy::order_nested_dissection(n, Ap, Ai, leaf, p);
+        std::copy(p.begin(), p.end(), perm);
+        return 0;
+    } catch (const std::exception& e) {
+        parsy::set_last_error(std::string("parsy_order_nd: ") + e.what());
         return -1;
     }
 }

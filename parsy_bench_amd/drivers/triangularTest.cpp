@@ -48,7 +48,12 @@ int main(int argc, char* argv[]) {
     std::vector<int> Ap, Ai, perm;
     std::vector<double> Ax;
     if (!parsy_io::read_lower_mtx(f1, n, Ap, Ai, Ax)) return -1;
-    if (argc > 8 && !parsy_io::read_ordering(argv[8], n, perm)) return -1;
+    if (argc > 8) {
+        if (!parsy_io::read_ordering(argv[8], n, perm)) return -1;
+    } else {
+        perm.resize(n);  // (the reference orders with METIS; this build with its own graph nested dissection)
+        if (parsy_order_nd(n, Ap.data(), Ai.data(), 0, perm.data()) != 0) return -1;
+    }
     const int nrelax[3] = {4, 16, 48};
     const double zrelax[3] = {0.8, 0.1, 0.05};
     parsy_symbolic* sym = parsy_analyze(n, Ap.data(), Ai.data(), Ax.data(), perm.empty() ? nullptr : perm.data(),

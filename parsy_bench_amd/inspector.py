@@ -64,6 +64,17 @@ class Symbolic:
                 pass
 
 
+def order_nd(A, leaf: int = 0) -> np.ndarray:
+    """Fill-reducing ordering of an arbitrary pattern (graph nested dissection, csrc/ordering.cpp);
+    perm[new] = old.  For matrices that come without an ordering (the reference calls METIS)."""
+    Ap = np.ascontiguousarray(A.Ap, dtype=np.int32)
+    Ai = np.ascontiguousarray(A.Ai, dtype=np.int32)
+    perm = np.empty(A.n, dtype=np.int32)
+    if N.lib().parsy_order_nd(A.n, N.ptr(Ap), N.ptr(Ai), leaf, N.ptr(perm)) != 0:
+        raise RuntimeError(N.last_error())
+    return perm
+
+
 def analyze(A, perm=None, nrelax=(4, 16, 48), zrelax=(0.8, 0.1, 0.05)) -> Symbolic:
     lib = N.lib()
     Ap = np.ascontiguousarray(A.Ap, dtype=np.int32)

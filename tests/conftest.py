@@ -37,3 +37,12 @@ def problem(name):
 
 
 _CACHE = {}
+
+
+@pytest.fixture(scope="module")
+def api():
+    """The product's Python binding; the -m gpu tier fails loudly without a device."""
+    from parsy_bench_amd import api as A
+    if A.device_count() < 1:
+        pytest.fail("no HIP device visible: the -m gpu tier must run on the GPU box")
+    return A

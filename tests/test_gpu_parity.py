@@ -18,14 +18,6 @@ RESID_TOL = 1e-10
 SOLVE_TOL = 1e-10
 
 
-@pytest.fixture(scope="module")
-def api():
-    from parsy_bench_amd import api as A
-    if A.device_count() < 1:
-        pytest.fail("no HIP device visible: the -m gpu tier must run on the GPU box")
-    return A
-
-
 def _factor_both(api, oracle, name):
     from parsy_bench_amd import inspector as I
     A, perm, sym = problem(name)
