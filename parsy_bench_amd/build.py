@@ -95,7 +95,7 @@ DRIVERS = PKG / "drivers"
 
 
 def build_drivers(hipcc=None, run=None, force: bool = False):
-    """choleskyTest / triangularTest: the reference's example drivers over the C ABI."""
+    """choleskyTest / triangularTest: the reference's example drivers over the C ABI; makingLowerHalf."""
     hipcc = hipcc or _hipcc()
     if run is None:
         def run(cmd):
@@ -107,6 +107,11 @@ def build_drivers(hipcc=None, run=None, force: bool = False):
             run([hipcc, "-x", "c++", "-O2", "-std=c++17", str(src), "-x", "none", "-o", str(out), str(LIB),
                  f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/.."])
         outs.append(out)
+    # the input converter of the reference's workflow (examples/MakingLowerHalf.cpp): plain host C++
+    src, out = DRIVERS / "makingLowerHalf.cpp", DRIVERS / "makingLowerHalf.bin"
+    if force or _stale(out, [src]):
+        run([hipcc, "-x", "c++", "-O2", "-std=c++17", str(src), "-x", "none", "-o", str(out)])
+    outs.append(out)
     return outs
 
 
