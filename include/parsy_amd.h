@@ -63,6 +63,16 @@ bool cholesky_left_par_05(int n, int* c, int* r, double* values, size_t* lC, int
                           int* partition, int chunk, int threads, int super_max, int col_max,
                           double* nodCost);
 
+/* The reference's PRUNE build of the same operator (parallel_PB_Cholesky_05.h:27-39 with
+ * `#define PRUNE`, :30-34 and :120-123): the update lists are passed instead of the etree and the
+ * upper pattern -- prunePtr (supNo+1) / pruneSet from getBlockedPruneSet
+ * (cholesky/Inspection_Prune.h).  A C ABI cannot overload, hence the suffix. */
+bool cholesky_left_par_05_prune(int n, int* c, int* r, double* values, size_t* lC, int* lR,
+                                size_t* Li_ptr, double* lValues, int* blockSet, int supNo,
+                                double* timing, int* prunePtr, int* pruneSet, int nLevels,
+                                int* levelPtr, int* levelSet, int nPar, int* parPtr, int* partition,
+                                int chunk, int threads, int super_max, int col_max, double* nodCost);
+
 /* Replaces cholesky_left_par_waveFront, reference
  * cholesky/Parallel_PB_Cholesky_wavefront.h:10-20.  levelPtr/levelSet are etree
  * level sets (common/TreeUtils.h:119).  Like the reference it reports `true`

@@ -57,7 +57,7 @@ class PlanInfo(C.Structure):
 
 # every symbol include/parsy_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "cholesky_left_par_05", "cholesky_left_par_waveFront", "blockedLsolve",
+    "cholesky_left_par_05", "cholesky_left_par_05_prune", "cholesky_left_par_waveFront", "blockedLsolve",
     "leveledBlockedLsolve", "H2LeveledBlockedLsolve", "H2LeveledBlockedLsolve_Peeled",
     "parsy_dropin_reset", "parsy_plan_create", "parsy_plan_destroy", "parsy_plan_get_info",
     "parsy_plan_set_active", "parsy_plan_chain_check", "parsy_factor_device", "parsy_factor_status", "parsy_solve_device",
@@ -108,6 +108,10 @@ def _declare(lib):
     lib.cholesky_left_par_05.restype = C.c_bool
     lib.cholesky_left_par_05.argtypes = (
         [C.c_int] + [vp] * 8 + [C.c_int] + [vp] * 5 + [C.c_int, vp, vp, C.c_int, vp, vp]
+        + [C.c_int] * 4 + [vp])
+    lib.cholesky_left_par_05_prune.restype = C.c_bool
+    lib.cholesky_left_par_05_prune.argtypes = (
+        [C.c_int] + [vp] * 8 + [C.c_int] + [vp] * 3 + [C.c_int, vp, vp, C.c_int, vp, vp]
         + [C.c_int] * 4 + [vp])
     lib.cholesky_left_par_waveFront.restype = C.c_bool
     lib.cholesky_left_par_waveFront.argtypes = (

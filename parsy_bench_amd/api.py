@@ -56,6 +56,20 @@ def cholesky_left_par_05(n, c, r, values, lC, lR, Li_ptr, lValues, blockSet, sup
         None))
 
 
+def cholesky_left_par_05_prune(n, c, r, values, lC, lR, Li_ptr, lValues, blockSet, supNo, timing, prunePtr,
+                               pruneSet, nLevels, levelPtr, levelSet, nPar, parPtr, partition, chunk, threads,
+                               super_max, col_max, nodCost=None) -> bool:
+    """The reference's PRUNE build of cholesky_left_par_05: update lists instead of etree + upper pattern."""
+    assert lValues.dtype == np.float64 and lValues.flags["C_CONTIGUOUS"]
+    a = [_i32(c), _i32(r), _f64(values), _sz(lC), _i32(lR), _sz(Li_ptr), _i32(blockSet), _i32(prunePtr),
+         _i32(pruneSet), _i32(levelPtr), _i32(parPtr), _i32(partition)]
+    ls = None if levelSet is None else _i32(levelSet)
+    return bool(N.lib().cholesky_left_par_05_prune(
+        n, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]), N.ptr(a[4]), N.ptr(a[5]), N.ptr(lValues),
+        N.ptr(a[6]), supNo, N.ptr(timing), N.ptr(a[7]), N.ptr(a[8]), nLevels, N.ptr(a[9]), N.ptr(ls), nPar,
+        N.ptr(a[10]), N.ptr(a[11]), chunk, threads, super_max, col_max, None))
+
+
 def cholesky_left_par_waveFront(n, c, r, values, lC, lR, Li_ptr, lValues, blockSet, supNo, timing,
                                 aTree, cT, rT, col2Sup, nLevels, levelPtr, levelSet, chunk, threads,
                                 super_max, col_max) -> bool:

@@ -128,6 +128,49 @@ parsy_plan* cached_chol_plan(int n, int supNo, const int* blockSet, const size_t
     return pl;
 }
 
+// the PRUNE operator: no etree, no upper pattern; the supernodal etree comes from L's pattern
+parsy_plan* cached_chol_plan_prune(int n, int supNo, const int* blockSet, const size_t* lC, const size_t* Li_ptr,
+                                   const int* lR, const int* prunePtr, const int* pruneSet, const int* c,
+                                   const int* r) {
+    uint64_t h = 1469598103934665603ULL;
+    h = fnv(h, blockSet, sizeof(int) * (supNo + 1));
+    h = fnv(h, lR, sizeof(int) * Li_ptr[n]);
+    h = fnv(h, c, sizeof(int) * (n + 1));
+    h = fnv(h, prunePtr, sizeof(int) * (supNo + 1));
+    h = fnv(h, pruneSet, sizeof(int) * prunePtr[supNo]);
+    CacheKey key{blockSet, lR, c, h, n, supNo, 2};
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    const int dev = pick_device();
+    if (dev >= parsy_device_count()) {
+        set_last_error("cholesky_left_par_05_prune: no usable HIP device " + std::to_string(dev) +
+                       " (this library has no CPU fallback)");
+        return nullptr;
+    }
+    std::vector<int> col2sup(n), sparent(supNo, -1);
+    for (int s = 0; s < supNo; ++s)
+        for (int k = blockSet[s]; k < blockSet[s + 1]; ++k) col2sup[k] = s;
+    for (int s = 0; s < supNo; ++s) {
+        const int w = blockSet[s + 1] - blockSet[s];
+        const size_t b = Li_ptr[blockSet[s]], e = Li_ptr[blockSet[s + 1]];
+        if (e - b > (size_t)w) sparent[s] = col2sup[lR[b + w]];
+    }
+    parsy::PatternRef P;
+    P.n = n;
+    P.nsuper = supNo;
+    P.super = blockSet;
+    P.col2sup = col2sup.data();
+    P.sparent = sparent.data();
+    P.i_ptr = Li_ptr;
+    P.s = lR;
+    P.prunePtr = prunePtr;
+    P.pruneSet = pruneSet;
+    parsy_plan* pl = parsy::plan_build(P, lC, c, r, dev);
+    if (pl) g_plans[key] = pl;
+    return pl;
+}
+
 parsy_plan* cached_solve_plan(int n, int supNo, const size_t* Lp, const int* Li, const size_t* Li_ptr,
                               const int* sup2col) {
     uint64_t h = 1469598103934665603ULL;
@@ -455,6 +498,38 @@ bool cholesky_left_par_05(int n, int* c, int* r, double* values, size_t* lC, int
         return false;
     }
     parsy_plan* pl = cached_chol_plan(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r);
+    double dev_s = 0;
+    if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
+        loud(who);
+        return false;
+    }
+    if (timing) {
+        timing[0] = now_s() - t0;
+        timing[1] = 0.0;
+        timing[2] = dev_s;
+    }
+    return parsy_factor_status(pl) == 0;
+}
+
+bool cholesky_left_par_05_prune(int n, int* c, int* r, double* values, size_t* lC, int* lR, size_t* Li_ptr,
+                                double* lValues, int* blockSet, int supNo, double* timing, int* prunePtr,
+                                int* pruneSet, int nLevels, int* levelPtr, int* levelSet, int nPar, int* parPtr,
+                                int* partition, int chunk, int threads, int super_max, int col_max,
+                                double* nodCost) {
+    (void)levelSet; (void)nPar; (void)chunk; (void)threads; (void)super_max; (void)col_max; (void)nodCost;
+    const char* who = "cholesky_left_par_05_prune";
+    const double t0 = now_s();
+    if (!c || !r || !values || !lC || !lR || !Li_ptr || !lValues || !blockSet || !prunePtr || !pruneSet || n < 0 ||
+        supNo < 0) {
+        set_last_error(std::string(who) + ": null or negative argument");
+        loud(who);
+        return false;
+    }
+    if (!validate_partition(supNo, nLevels, levelPtr, parPtr, partition, who)) {
+        loud(who);
+        return false;
+    }
+    parsy_plan* pl = cached_chol_plan_prune(n, supNo, blockSet, lC, Li_ptr, lR, prunePtr, pruneSet, c, r);
     double dev_s = 0;
     if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
         loud(who);

@@ -405,7 +405,14 @@ void build_update_lists(const PatternRef& S, std::vector<int64_t>& ptr, std::vec
     std::vector<char> mark(ns, 0);
     std::vector<int> tmp, lst;
     for (int t = 0; t < ns; ++t) {
-        ereach_supernodal(S, t, lst, mark, tmp);
+        if (S.prunePtr) {
+            if (S.prunePtr[t] > S.prunePtr[t + 1]) throw std::runtime_error("inspector: prunePtr is not monotone");
+            lst.assign(S.pruneSet + S.prunePtr[t], S.pruneSet + S.prunePtr[t + 1]);
+            for (int d : lst)
+                if (d < 0 || d >= t) throw std::runtime_error("inspector: prune set entry is not a descendant");
+        } else {
+            ereach_supernodal(S, t, lst, mark, tmp);
+        }
         const int c0 = S.super[t], c1 = S.super[t + 1];
         for (int d : lst) {
             const size_t b = S.i_ptr[S.super[d]], e = S.i_ptr[S.super[d + 1]];

@@ -87,6 +87,11 @@ struct PatternRef {
     const int* s = nullptr;         // row ids
     const int* A1p = nullptr;       // upper-triangle pattern
     const int* A1i = nullptr;
+    // the reference's PRUNE build passes the update lists themselves (getBlockedPruneSet,
+    // cholesky/Inspection_Prune.h) instead of aTree / A1: descendants of supernode t in update order
+    // are pruneSet[prunePtr[t] .. prunePtr[t+1])
+    const int* prunePtr = nullptr;
+    const int* pruneSet = nullptr;
 };
 PatternRef pattern_ref(const Symbolic& S);
 

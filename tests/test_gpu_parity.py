@@ -97,6 +97,13 @@ def test_dropin_cholesky_operators(api, oracle, name):
                                            sym.col2Sup, sym.nlevels, sym.levelPtr, sym.levelSet, 1, 4,
                                            sym.maxSupWid + 1, sym.maxCol + 1) is True
     assert np.array_equal(lw, lv)  # same plan, same schedule: bitwise
+    # the PRUNE build's signature: update lists (getBlockedPruneSet) instead of etree + upper pattern
+    lp = np.zeros(int(sym.xsize))
+    assert api.cholesky_left_par_05_prune(sym.n, sym.A2p, sym.A2i, sym.A2x, sym.p, sym.s, sym.i_ptr, lp,
+                                          sym.super, sym.nsuper, timing, sym.updPtr, sym.updSn, nl, levelPtr,
+                                          None, 0, parPtr, partition, 1, 4, sym.maxSupWid + 1,
+                                          sym.maxCol + 1) is True
+    assert np.array_equal(lp, lv)  # same update lists, same schedule: bitwise
     # a partition that is not a permutation of the supernodes is refused
     bad = partition.copy()
     bad[0] = bad[1]
