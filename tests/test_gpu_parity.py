@@ -367,6 +367,48 @@ def test_first_factorization_on_a_callers_non_blocking_stream(api, oracle):
         plan.close()
 
 
+def test_flan_class_size_on_device(api):
+    """BASELINE configs[2] stand-in (n = 1 560 896, 2.0e9 factor entries: too large for the CPU
+    checker in a test): size-independent properties on the device only -- b := L 1 on the stored
+    structure, forward solve gives 1; backward after forward solves L L' x = b; status 0."""
+    torch = pytest.importorskip("torch")
+    from parsy_bench_amd import inspector as I, matrices as M
+    A, perm = M.workload("flan")
+    sym = I.analyze(A, perm)
+    assert sym.nnzL > 2_000_000_000
+    dev = torch.device("cuda", 0)
+    plan = api.Plan(sym, 0)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    plan.factor_device(values.data_ptr(), L.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert plan.status() == 0
+    rows = torch.from_numpy(sym.s.astype(np.int64)).to(dev)
+    w = np.diff(sym.super)
+    r = np.diff(sym.i_ptr[sym.super].astype(np.int64))
+    b = torch.zeros(sym.n, dtype=torch.float64, device=dev)
+    for sn in range(sym.nsuper):  # b[rows of the panel] += row sums of the panel (common/Util.h:277)
+        c0 = int(sym.super[sn])
+        rs = slice(int(sym.i_ptr[c0]), int(sym.i_ptr[c0]) + int(r[sn]))
+        panel = L[int(sym.p[c0]): int(sym.p[c0]) + int(w[sn] * r[sn])].view(int(w[sn]), int(r[sn]))
+        b.index_add_(0, rows[rs], panel.sum(dim=0))
+    x = b.clone()
+    plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+    torch.cuda.synchronize()
+    assert float((x - 1.0).abs().max()) <= 1e-9
+    # L L' z = b  =>  L' z = 1: apply L' to z on the stored structure and compare with 1
+    plan.backsolve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+    torch.cuda.synchronize()
+    t = torch.zeros(sym.n, dtype=torch.float64, device=dev)
+    for sn in range(sym.nsuper):  # t[cols of the panel] = panel' z[rows]
+        c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
+        rs = slice(int(sym.i_ptr[c0]), int(sym.i_ptr[c0]) + int(r[sn]))
+        panel = L[int(sym.p[c0]): int(sym.p[c0]) + int(w[sn] * r[sn])].view(int(w[sn]), int(r[sn]))
+        t[c0:c1] = panel @ x[rows[rs]]
+    assert float((t - 1.0).abs().max()) <= 1e-8
+    assert plan.status() == 0
+
+
 def test_levels_with_hundreds_of_walkers(api, oracle):
     """A larger 3-D grid: levels with hundreds of wide supernodes, each with a workgroup that stays
     resident for the whole supernode (the walker).  The launches must neither deadlock nor time out
