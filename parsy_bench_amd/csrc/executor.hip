@@ -121,8 +121,13 @@ static int plan_upload(parsy_plan* pl) {
 parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
                        int device) {
     parsy_plan* pl = new parsy_plan;
+    int cus = 0;
+    if (device >= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    }
     try {
-        build_schedule(P, lC, A2p, A2i, nullptr, pl->S);
+        build_schedule(P, lC, A2p, A2i, nullptr, pl->S, cus);
     } catch (const std::exception& e) {
         set_last_error(std::string("plan: ") + e.what());
         delete pl;

@@ -13,8 +13,10 @@ namespace parsy {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
-                    const uint8_t* active, Schedule& S) {
+                    const uint8_t* active, Schedule& S, int compute_units) {
     S = Schedule();
+    // resident workgroups of the chain kernel = 2 per CU; walkers of one batch take at most a quarter
+    if (compute_units > 0) S.walker_batch = std::max(4, std::min(kWalkerBatch, compute_units / 2));
     const int n = P.n, ns = P.nsuper;
     S.n = n;
     S.nsuper = ns;
@@ -307,11 +309,11 @@ void build_launches(Schedule& S, const uint8_t* active) {
             // tiles of block column J, which wait for diagonal tile J.
             Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
             // Walkers stay resident for their whole chain, so the block-column-major interleaving is
-            // done per batch of at most kWalkerBatch supernodes: what a walker waits for then lies at most
+            // done per batch of at most walker_batch supernodes: what a walker waits for then lies at most
             // one batch of tiles ahead of it in ticket order, and the walkers of the batches in flight
             // never take more than a fraction of the resident workgroups.
-            for (size_t b0 = 0; b0 < bigs.size(); b0 += kWalkerBatch) {
-              const size_t b1 = std::min(bigs.size(), b0 + (size_t)kWalkerBatch);
+            for (size_t b0 = 0; b0 < bigs.size(); b0 += (size_t)S.walker_batch) {
+              const size_t b1 = std::min(bigs.size(), b0 + (size_t)S.walker_batch);
               int maxnb = 0;
               for (size_t q = b0; q < b1; ++q) maxnb = std::max(maxnb, ceil_div(S.sn[bigs[q]].w, kTile));
               for (int J = 0; J < maxnb; ++J)

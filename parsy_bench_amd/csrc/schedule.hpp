@@ -108,6 +108,7 @@ constexpr int kSplitChunks = 192;        // early wave streams longer than this 
 constexpr int kSplitTarget = 128;        // ... into parts of about this length (at most kSplitMaxParts)
 constexpr int kSplitMaxParts = 4;
 constexpr int kWalkerBatch = 64;          // CHAIN: supernodes whose tiles are interleaved block column by block column
+                                         // (upper bound; Schedule::walker_batch follows the device's CU count)
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
@@ -119,6 +120,8 @@ struct Schedule {
     int64_t n_dslots = 0;          // block columns of the tiled supernodes (64*64 doubles of scratch each)
     int64_t n_tflags = 0;          // tiles of the tiled supernodes (one publication flag each)
     int n_chain_launches = 0;      // CHAIN launches (one ticket counter each)
+    int walker_batch = kWalkerBatch;  // walkers interleaved per batch: at most a quarter of the resident workgroups
+                                      // (2 per CU), so that a small partition of the GPU cannot fill up with walkers
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;
     double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)
     double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (CHAIN launches)
@@ -166,7 +169,7 @@ struct Schedule {
 // the LAUNCHES to a subset of supernodes (multi-GPU shards); descriptors always
 // cover the whole pattern.
 void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
-                    const uint8_t* active, Schedule& out);
+                    const uint8_t* active, Schedule& out, int compute_units = 0);
 // Recompute only the launch lists for a new active set.
 void build_launches(Schedule& S, const uint8_t* active);
 // Dry run of the CHAIN launches' hand-off protocol with `slots` resident workgroups (tickets in start
