@@ -128,7 +128,14 @@ typedef struct parsy_plan_info {
     double update_flops;           /* flops in the SYRK/GEMM update kernels */
     double reread_bytes;           /* left-looking re-read traffic 8*sum K*nSupRs */
     double inner_flops;            /* in-supernode SYRK/GEMM flops of the tiled path */
-    double tile_update_flops;      /* external-update flops applied by the tile kernel */
+    double tile_update_flops;      /* external-update flops applied by the tile kernel's wave streams */
+    double big_flops;              /* update flops applied by the BIG (LDS-staged GEMM) launches */
+    int64_t big_entries;           /* (tile, source) pairs of the BIG launches */
+    int32_t big_tasks;             /* workgroups of the BIG launches per factorization */
+    int32_t n_pieces;              /* supernodes of the Cholesky view (very wide ones cut into pieces) */
+    int32_t chol_levels;           /* levels of the Cholesky view's (chain-extended) etree */
+    int32_t piece_width, big_min_k;
+    int32_t pad_;
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

@@ -49,6 +49,9 @@ class PlanInfo(C.Structure):
         ("n_updates", C.c_int64), ("relpos_len", C.c_int64), ("device_bytes", C.c_int64),
         ("flops_stored", C.c_double), ("update_flops", C.c_double), ("reread_bytes", C.c_double),
         ("inner_flops", C.c_double), ("tile_update_flops", C.c_double),
+        ("big_flops", C.c_double), ("big_entries", C.c_int64), ("big_tasks", C.c_int32),
+        ("n_pieces", C.c_int32), ("chol_levels", C.c_int32), ("piece_width", C.c_int32),
+        ("big_min_k", C.c_int32), ("pad_", C.c_int32),
     ]
 
     def as_dict(self):

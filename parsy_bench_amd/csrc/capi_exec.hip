@@ -293,6 +293,13 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->reread_bytes = S.reread_bytes;
     o->inner_flops = S.inner_flops;
     o->tile_update_flops = S.tile_update_flops;
+    o->big_flops = S.big_flops;
+    o->big_entries = (int64_t)S.big_entries.size();
+    o->big_tasks = (int32_t)S.big_tasks.size();
+    o->n_pieces = (int32_t)S.csn.size();
+    o->chol_levels = S.cnlevels;
+    o->piece_width = S.piece_width;
+    o->big_min_k = S.big_min_k;
     return 0;
 }
 

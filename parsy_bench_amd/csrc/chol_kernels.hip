@@ -444,7 +444,7 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
     stage_cap = min(max(stage_cap, 2), kSmallStage);
     const size_t lds = (size_t)((lds_bytes + 15) & ~15) + 2 * (size_t)stage_cap * sizeof(double) +
                        4 * kSmallRelCap * sizeof(int32_t) + (kPotrfScratch + kTile) * sizeof(double);
-    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.sn,
+    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.csn,
                        P.upd, P.relpos, P.small_list + first, L, P.info, stage_cap);
 }
 
@@ -613,7 +613,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileDesc td = tiles[task];
     const SnDesc D = sn[td.sn];
-    const int r = D.r, w = D.w;
+    const int r = D.r, w = D.w, ld = D.ld;  // ld > r: a piece of a split supernode (window of its panel)
     double* __restrict__ G = L + D.px;
     const int tI = td.row0 / kTile, tJ = td.col0 / kTile, nbc = (w + kTile - 1) / kTile;
     const bool diag_tile = td.row0 == td.col0;
@@ -648,7 +648,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             const int e = q * 64 + lane;
             const int cc = e >> 5, rr = e & 31;
             const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
-            tv[q] = (in && split_part == 0) ? G[(int64_t)(subcol0 + cc) * r + subrow0 + rr] : 0.0;
+            tv[q] = (in && split_part == 0) ? G[(int64_t)(subcol0 + cc) * ld + subrow0 + rr] : 0.0;
         }
         if (CHAIN && split_n > 1) {
             for (int part = 1; part < split_n; ++part) {
@@ -757,9 +757,9 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                 ++le;
             } else {
                 // block column l_kint of the tile's own supernode, identity row map
-                E.src = D.px + (int64_t)l_kint * kTile * r;
+                E.src = D.px + (int64_t)l_kint * kTile * ld;
                 E.rel = 0;
-                E.ld = r;
+                E.ld = ld;
                 E.K = kTile;
                 E.ia = subrow0;
                 E.ja = subcol0;
@@ -865,7 +865,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                 // sub-tile column of source row `lane - 32` of the column window (-1: outside).
                 const bool ident = (c.mn >> 16) != 0;
                 const int relv = (l31 < (lane < 32 ? mi : nj))
-                                     ? (ident ? l31 : c.rel - (lane < 32 ? subrow0 : subcol0)) : -1;
+                                     ? (ident ? l31 : c.rel - D.rbias - (lane < 32 ? subrow0 : subcol0)) : -1;
                 const int C0 = __builtin_amdgcn_ds_bpermute((32 + l15) * 4, relv);
                 const int C1 = __builtin_amdgcn_ds_bpermute((48 + l15) * 4, relv);
                 // Cells outside the update (padding of the 16x16 fragments, the strict upper triangle
@@ -954,7 +954,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         for (int e = lane; e < kSub * kSub; e += 64) {
             const int cc = e >> 5, rr = e & 31;
             if (rr < nr && cc < nc && (sr + rr >= sc + cc) && kSub * wa + rr >= min_row) {
-                double* dst = &G[(int64_t)(sc + cc) * r + sr + rr];
+                double* dst = &G[(int64_t)(sc + cc) * ld + sr + rr];
                 if (CHAIN) st_sc1(dst, Q[cc * kLdSub + rr]);
                 else *dst = Q[cc * kLdSub + rr];
             }
@@ -1021,20 +1021,20 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             return;
         }
         {
-            const double* DB = G + (int64_t)td.col0 * r + td.col0;  // factored diagonal block, ld r
+            const double* DB = G + (int64_t)td.col0 * ld + td.col0;  // factored diagonal block
             double dtmp[kTile * kTile / kThreads];
 #pragma unroll
             for (int q = 0; q < kTile * kTile / kThreads; ++q) {
                 const int e = q * kThreads + tid;
                 const int c = e >> 6, i = e & 63;
-                dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * r + i]) : 0.0;
+                dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * ld + i]) : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < kTile * kTile / kThreads; ++q) {
                 const int e = q * kThreads + tid;
                 dgbuf[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
             }
-            if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * r + tid]) : 1.0;
+            if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * ld + tid]) : 1.0;
         }
         __syncthreads();
         invert_and_trsm((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, nb);
@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                 for (int q = 0; q < kSub * kSub / 64; ++q) {
                     const int e = q * 64 + lane;
                     const int cc = e >> 5, rr = e & 31;
-                    bv[q] = (rr < nr) ? ld_sc1(&G[(int64_t)(scb + cc) * r + sr + rr]) : 0.0;
+                    bv[q] = (rr < nr) ? ld_sc1(&G[(int64_t)(scb + cc) * ld + sr + rr]) : 0.0;
                 }
             };
             auto load_c = [&]() {  // diagonal tile (J+1,J+1), lower part
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                     const int e = q * 64 + lane;
                     const int cc = e >> 5, rr = e & 31;
                     const bool inc = rr < nr && cc < ncc && (sr + rr >= scc + cc);
-                    cpart[q] = inc ? ld_sc1(&G[(int64_t)(scc + cc) * r + sr + rr]) : 0.0;
+                    cpart[q] = inc ? ld_sc1(&G[(int64_t)(scc + cc) * ld + sr + rr]) : 0.0;
                 }
             };
             if (tid == 0) {
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
                     const int i = 4 * ti + ri, c = 4 * tj + ci;
-                    if (c < nb && i < nb && i >= c) st_sc1(&G[(int64_t)(col0 + c) * r + col0 + i], a[ri][ci]);
+                    if (c < nb && i < nb && i >= c) st_sc1(&G[(int64_t)(col0 + c) * ld + col0 + i], a[ri][ci]);
                 }
             if (!has_next && !tail_rows) {
                 publish(f_diag);
@@ -1276,6 +1276,199 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
                     epoch);
 }
 
+// ---------------------------------------------------------------------------
+// BIG: the updates from wide descendants (reference DSYRK + DGEMM at
+// parallel_PB_Cholesky_05.h:160,173 with K in the hundreds or thousands), and the updates
+// between the pieces of a split supernode.  One workgroup per 128x128 tile of the target's
+// panel; per source the rows of the descendant that fall into the tile's row window (R, <= 128
+// consecutive rows of its column-major panel) and into its column window (C) are staged through
+// LDS in 16-wide k chunks (double-buffered, next chunk prefetched into registers across entry
+// boundaries), shared by the four waves (2x2, 64x64 outputs each: 16 accumulators of
+// v_mfma_f64_16x16x4_f64); 16 flop per byte fetched against 4 for the per-wave streams.  The
+// product is formed as C x R' (lanes along the target's ROWS: 128-B segments), and at the end of a
+// source it is subtracted from the tile in the panel through the relative indices -- the tile
+// belongs to this workgroup alone within the launch, sources in list order: fixed summation order.
+// ---------------------------------------------------------------------------
+static constexpr int kBK = 16;                 // k extent of a staged chunk
+static constexpr int kBLd = kBigTile + 16;     // k stride of a staged chunk in LDS: lanes 16..31 (k + 1) of an
+                                               // operand read hit the other half of the banks
+struct BigLds {
+    double R[2][kBK * kBLd];
+    double C[2][kBK * kBLd];
+};
+
+__global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restrict__ sn,
+                                                          const int32_t* __restrict__ relpos,
+                                                          const WaveEntry* __restrict__ ents,
+                                                          const TileDesc* __restrict__ tasks,
+                                                          double* __restrict__ L) {
+    __shared__ BigLds S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, kq = lane >> 4;
+    const TileDesc td = tasks[blockIdx.x];
+    const SnDesc D = sn[td.sn];
+    double* __restrict__ G = L + D.px;
+    const int ld = D.ld;
+    const bool diag = td.row0 == td.col0;
+    const int64_t e_begin = td.wp, e_end = td.sp;
+    if (e_begin >= e_end) return;
+
+    // ---- loader: thread (row = tid & 127, k = (tid >> 7) + 2 q) of both staged blocks
+    const int lrow = tid & (kBigTile - 1), lkh = tid >> 7;
+    int64_t le = e_begin;
+    int lk = 0;                       // k position inside entry le
+    WaveEntry LE = ents[le];
+    double vR[8], vC[8];
+    int v_kend = 0;                   // valid k of the chunk held in vR / vC
+    auto fetch = [&]() {
+        if (le >= e_end) {
+            v_kend = -1;
+            return;
+        }
+        const int mi = LE.mn & 255, nj = (LE.mn >> 8) & 255;
+        const int kend = min(kBK, LE.K - lk);
+        const double* __restrict__ pr = L + LE.src + LE.ia + min(lrow, mi - 1) + (int64_t)lk * LE.ld;
+        const double* __restrict__ pc = L + LE.src + LE.ja + min(lrow, nj - 1) + (int64_t)lk * LE.ld;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t ko = (int64_t)min(lkh + 2 * q, kend - 1) * LE.ld;
+            vR[q] = pr[ko];
+            vC[q] = pc[ko];
+        }
+        v_kend = kend;
+        lk += kBK;
+        if (lk >= LE.K) {
+            lk = 0;
+            ++le;
+            if (le < e_end) LE = ents[le];
+        }
+    };
+    auto stage = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = lkh + 2 * q;
+            S.R[b][k * kBLd + lrow] = k < v_kend ? vR[q] : 0.0;
+            S.C[b][k * kBLd + lrow] = k < v_kend ? vC[q] : 0.0;
+        }
+    };
+
+    // ---- consumer state: entry ce, progress ck
+    int64_t ce = e_begin;
+    int ck = 0;
+    WaveEntry CE = LE;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
+
+    auto frags = [&](const WaveEntry& E, int& nfr, int& nfc) {
+        const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+        nfr = min(4, max(0, (mi - 64 * wr + 15) >> 4));
+        nfc = min(4, max(0, (nj - 64 * wc + 15) >> 4));
+        if (diag && wr < wc) nfr = 0;  // strictly upper quadrant of a diagonal tile
+        if (nfr == 0 || nfc == 0) nfr = nfc = 0;
+    };
+    auto compute = [&](int b, int nfr, int nfc) {
+        const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
+        const double* __restrict__ Cb = &S.C[b][64 * wc + l15];
+        if (nfr == 0) return;
+#pragma unroll
+        for (int ks = 0; ks < kBK / 4; ++ks) {
+            double rv[4], cv[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                rv[f] = Rb[(4 * ks + kq) * kBLd + 16 * f];
+                cv[f] = Cb[(4 * ks + kq) * kBLd + 16 * f];
+            }
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc) {
+                if (fc < nfc) {
+#pragma unroll
+                    for (int fr = 0; fr < 4; ++fr)
+                        if (fr < nfr)
+                            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
+    // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C)
+    auto epilogue = [&](const WaveEntry& E, int nfr, int nfc) {
+        if (nfr == 0) return;
+        const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+        const bool ident = (E.mn >> 16) != 0;
+        int prow[4];
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr) {
+            const int i = 64 * wr + 16 * fr + l15;
+            prow[fr] = -1;
+            if (i < mi) prow[fr] = ident ? E.ia + i : relpos[(int64_t)E.rel + E.ia + i] - D.rbias;
+        }
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) {
+            if (fc < nfc) {
+                int pcol[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = 64 * wc + 16 * fc + kq + 4 * v;
+                    pcol[v] = -1;
+                    if (j < nj) pcol[v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
+                }
+#pragma unroll
+                for (int fr = 0; fr < 4; ++fr) {
+                    if (fr < nfr) {
+                        double old[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
+                            old[v] = ok ? G[(int64_t)pcol[v] * ld + prow[fr]] : 0.0;
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
+                            if (ok) G[(int64_t)pcol[v] * ld + prow[fr]] = old[v] - acc[fc][fr][v];
+                        }
+                        asm volatile("" ::: "memory");  // one group of loads in flight (registers)
+                    }
+                }
+            }
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) acc[fc][fr] = double4_t{0, 0, 0, 0};
+        }
+    };
+
+    // ---- pipeline: chunk n is multiplied from LDS buffer n & 1 while chunk n + 1 moves from
+    // registers to the other buffer and chunk n + 2 is on its way from the panel
+    fetch();
+    stage(0);
+    fetch();
+    __syncthreads();
+    int nfr, nfc;
+    frags(CE, nfr, nfc);
+    for (int n = 0;; ++n) {
+        const bool have_next = v_kend >= 0;
+        if (have_next) {
+            stage((n + 1) & 1);
+            fetch();
+        }
+        compute(n & 1, nfr, nfc);
+        ck += kBK;
+        if (ck >= CE.K) {
+            epilogue(CE, nfr, nfc);
+            ck = 0;
+            ++ce;
+            if (ce < e_end) {
+                CE = ents[ce];
+                frags(CE, nfr, nfc);
+            }
+        }
+        if (!have_next) break;
+        __syncthreads();
+    }
+}
+
 #ifdef PARSY_STAMPS
 extern "C" void parsy_debug_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
@@ -1288,16 +1481,22 @@ extern "C" void parsy_debug_trace(unsigned long long* out) {
 }
 #endif
 
+void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_chol_big, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.big_entries,
+                       P.big_tasks + first, L);
+}
+
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_tiles, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos, P.wave_entries,
+    hipLaunchKernelGGL(k_chol_tiles, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.wave_entries,
                        P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L);
 }
 
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_chain, dim3(count), dim3(kThreads), 0, stream, P.sn, P.relpos, P.wave_entries,
+    hipLaunchKernelGGL(k_chol_chain, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.wave_entries,
                        P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L, P.info, P.tflags,
                        P.n_tflags, P.tickets + ticket, epoch);
 }

@@ -40,6 +40,7 @@ int plan_upload_launches(parsy_plan* pl) {
     const Schedule& S = pl->S;
     if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
     if (upload(pl, S.tiles, pl->dp.tiles, true)) return -1;
+    if (upload(pl, S.big_tasks, pl->dp.big_tasks, true)) return -1;
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
@@ -62,6 +63,8 @@ static int plan_upload(parsy_plan* pl) {
     PARSY_HIP(hipSetDevice(pl->device));
     const Schedule& S = pl->S;
     if (upload(pl, S.sn, pl->dp.sn, false)) return -1;
+    if (upload(pl, S.csn, pl->dp.csn, false)) return -1;
+    if (upload(pl, S.big_entries, pl->dp.big_entries, false)) return -1;
     if (upload(pl, S.upd, pl->dp.upd, false)) return -1;
     if (upload(pl, S.relpos, pl->dp.relpos, false)) return -1;
     if (upload(pl, S.a_dst, pl->dp.a_dst, false)) return -1;
@@ -103,8 +106,8 @@ static int plan_upload(parsy_plan* pl) {
         PARSY_HIP(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, prio_least));
     }
     PARSY_HIP(hipEventCreateWithFlags(&pl->ev_init, hipEventDisableTiming));
-    pl->ev_level_done.resize(S.nlevels + 1);
-    pl->ev_early_done.resize(S.nlevels + 1);
+    pl->ev_level_done.resize(std::max(S.nlevels, S.cnlevels) + 1);
+    pl->ev_early_done.resize(std::max(S.nlevels, S.cnlevels) + 1);
     for (auto& e : pl->ev_level_done) PARSY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : pl->ev_early_done) PARSY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     {
@@ -195,21 +198,25 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         const bool on_side = overlap && l.side;
         if (!on_side) {
             // everything enqueued so far on the main stream belongs to levels < l.level
-            if (overlap && l.kind <= kLaunchChain) record_levels_below(l.level);
-            if (overlap && l.kind == kLaunchChain && early_seen[l.level])
+            if (overlap && l.kind <= kLaunchBig) record_levels_below(l.level);
+            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig) && early_seen[l.level])
                 (void)hipStreamWaitEvent(stream, pl->ev_early_done[l.level], 0);
         }
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, L, stream); break;
             case kLaunchTiles:
+            case kLaunchBig:
                 if (on_side) {
                     record_levels_below(l.wait_level + 1);
                     (void)hipStreamWaitEvent(pl->side_stream,
                                              l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
-                    launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
+                    if (l.kind == kLaunchBig) launch_chol_big(pl->dp, l.first, l.count, L, pl->side_stream);
+                    else launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
                     (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
                     early_seen[l.level] = 1;
+                } else if (l.kind == kLaunchBig) {
+                    launch_chol_big(pl->dp, l.first, l.count, L, stream);
                 } else {
                     launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }

@@ -10,7 +10,8 @@
 namespace parsy {
 
 struct DevicePattern {           // device copies of Schedule arrays
-    const SnDesc* sn = nullptr;
+    const SnDesc* sn = nullptr;           // the supernodes (solve kernels)
+    const SnDesc* csn = nullptr;          // Cholesky view (pieces of the very wide ones): Cholesky kernels
     const UpdDesc* upd = nullptr;
     const int32_t* relpos = nullptr;
     const int64_t* a_dst = nullptr;
@@ -21,6 +22,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     double* tile_scratch = nullptr;            // partial tiles of the split streams
     const int32_t* small_list = nullptr;
     const TileDesc* tiles = nullptr;
+    const WaveEntry* big_entries = nullptr;   // BIG launches: (source, row window, column window) per task
+    const TileDesc* big_tasks = nullptr;
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
@@ -39,6 +42,7 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
                       hipStream_t stream);
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
                        hipStream_t stream);
+void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream);

@@ -12,6 +12,12 @@ namespace parsy {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return std::atoi(v);
+}
+
 void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
                     const uint8_t* active, Schedule& S, int compute_units) {
     S = Schedule();
@@ -25,6 +31,11 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     S.rows.assign(P.s, P.s + P.i_ptr[n]);
     S.ssize = (int64_t)P.i_ptr[n];
     S.xsize = (int64_t)lC[n];
+    // diagnostics: PARSY_BIG_MINK (a huge value switches the BIG launches off), PARSY_PIECE_WIDTH (0: no pieces)
+    S.big_min_k = std::max(16, env_int("PARSY_BIG_MINK", kBigMinK));
+    S.piece_width = env_int("PARSY_PIECE_WIDTH", kPieceWidth);
+    if (S.piece_width > 0) S.piece_width = ceil_div(std::max(S.piece_width, kBigTile), kBigTile) * kBigTile;
+    if (S.piece_width < S.big_min_k) S.piece_width = 0;  // the pieces update each other through the BIG launches
 
     // --- supernode descriptors ------------------------------------------------
     S.sn.resize(ns);
@@ -33,6 +44,8 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         d.c0 = P.super[t];
         d.w = P.super[t + 1] - P.super[t];
         d.r = (int)(P.i_ptr[P.super[t + 1]] - P.i_ptr[P.super[t]]);
+        d.ld = d.r;
+        d.rbias = 0;
         d.px = (int64_t)lC[d.c0];
         d.pi = (int64_t)P.i_ptr[d.c0];
         d.a0 = A2p ? A2p[d.c0] : 0;
@@ -54,17 +67,22 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         for (int k = 0; k < d.w; ++k)
             if (S.rows[d.pi + k] != d.c0 + k)
                 throw std::runtime_error("schedule: supernode rows do not start with its own columns");
+        // solve: one scratch slot (inverse diagonal block) per block column of the wide supernodes
+        if (d.w > kTile) {
+            d.dslot = (int32_t)S.n_dslots;
+            S.n_dslots += ceil_div(d.w, kTile);
+        }
     }
 
-    // --- update lists, relative indices, A scatter map ---------------------------
+    // --- update lists of the supernodes, relative indices, A scatter map -----------
     std::vector<int64_t> uptr(ns + 1, 0);
     std::vector<int> usn, ulb, uub;
     if (!S.solve_only) build_update_lists(P, uptr, usn, ulb, uub);
-    S.upd.resize(usn.size());
+    std::vector<int64_t> urel(usn.size(), 0);  // per (target, descendant): offset into relpos of row lb
     S.a_dst.assign((size_t)S.nnzA, 0);
     std::vector<int> map(n, -1), stamp(n, -1);
     for (int t = 0; t < ns; ++t) {
-        SnDesc& T = S.sn[t];
+        const SnDesc& T = S.sn[t];
         for (int k = 0; k < T.r; ++k) {
             const int row = S.rows[T.pi + k];
             map[row] = k;
@@ -76,56 +94,133 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                 if (stamp[row] != t) throw std::runtime_error("schedule: A entry outside the pattern of L");
                 S.a_dst[q] = (int64_t)lC[col] + map[row];
             }
-        T.upd0 = uptr[t];
-        T.nupd = (int)(uptr[t + 1] - uptr[t]);
         for (int64_t u = uptr[t]; u < uptr[t + 1]; ++u) {
             const SnDesc& D = S.sn[usn[u]];
-            UpdDesc& U = S.upd[u];
-            U.src = D.px + ulb[u];
-            U.ld = D.r;
-            U.K = D.w;
-            U.m = D.r - ulb[u];
-            U.n1 = uub[u] - ulb[u] + 1;
-            U.rel = (int64_t)S.relpos.size();
+            urel[u] = (int64_t)S.relpos.size();
             for (int k = ulb[u]; k < D.r; ++k) {
                 const int row = S.rows[D.pi + k];
                 if (stamp[row] != t)
                     throw std::runtime_error("schedule: descendant row missing from the target's pattern");
                 S.relpos.push_back(map[row]);
             }
-            S.update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
-            S.reread_bytes += 8.0 * (double)U.K * U.m;
+            const double K = D.w, m = D.r - ulb[u], n1 = uub[u] - ulb[u] + 1;
+            S.update_flops += K * n1 * (n1 + 1) + 2.0 * K * (m - n1) * n1;
+            S.reread_bytes += 8.0 * K * m;
         }
     }
-
     if (S.relpos.size() > 0x7fffffffULL) throw std::runtime_error("schedule: relative index array exceeds int32");
+
     std::vector<int> tree(P.sparent, P.sparent + ns);
     level_sets(tree, S.levelPtr, S.levelSet);
     S.nlevels = (int)S.levelPtr.size() - 1;
-    S.level_of.assign(ns, 0);
-    for (int l = 0; l < S.nlevels; ++l)
-        for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) S.level_of[S.levelSet[q]] = l;
+
+    // --- Cholesky view: pieces of the very wide supernodes -------------------------------
+    S.piece0.assign(ns + 1, 0);
+    for (int t = 0; t < ns; ++t) {
+        const SnDesc& T = S.sn[t];
+        S.piece0[t] = (int32_t)S.csn.size();
+        int np = 1;
+        const int pw = S.piece_width;
+        if (!S.solve_only && pw > 0 && T.w > pw + pw / 2) {
+            np = ceil_div(T.w, pw);
+            if (T.w - (np - 1) * pw < pw / 2) --np;  // a short remainder stays with the last piece
+        }
+        for (int j = 0; j < np; ++j) {
+            const int off = j * pw;
+            SnDesc c = T;
+            c.c0 = T.c0 + off;
+            c.w = (j == np - 1) ? T.w - off : pw;
+            c.r = T.r - off;
+            c.ld = T.r;
+            c.rbias = off;
+            c.px = T.px + (int64_t)off * T.r + off;
+            c.pi = T.pi + off;
+            c.dslot = -1;
+            S.csn.push_back(c);
+            S.csn_real.push_back(t);
+        }
+    }
+    const int nc = (int)S.csn.size();
+    S.piece0[ns] = nc;
+    {
+        std::vector<int> ctree(nc, -1);
+        for (int t = 0; t < ns; ++t)
+            for (int p = S.piece0[t]; p < S.piece0[t + 1]; ++p)
+                ctree[p] = (p + 1 < S.piece0[t + 1]) ? p + 1 : (tree[t] >= 0 ? S.piece0[tree[t]] : -1);
+        level_sets(ctree, S.clevelPtr, S.clevelSet);
+    }
+    S.cnlevels = (int)S.clevelPtr.size() - 1;
+    S.level_of.assign(nc, 0);
+    for (int l = 0; l < S.cnlevels; ++l)
+        for (int q = S.clevelPtr[l]; q < S.clevelPtr[l + 1]; ++q) S.level_of[S.clevelSet[q]] = l;
+
+    // --- update descriptors per piece: the supernode's descendants restricted to the piece's columns
+    // (reference order), then the pieces to its left (identity row map) ------------------------
+    for (int t = 0; t < ns && !S.solve_only; ++t) {
+        const SnDesc& T = S.sn[t];
+        for (int p = S.piece0[t]; p < S.piece0[t + 1]; ++p) {
+            SnDesc& C = S.csn[p];
+            C.upd0 = (int64_t)S.upd.size();
+            const int col_lo = C.c0, col_hi = C.c0 + C.w;
+            for (int64_t u = uptr[t]; u < uptr[t + 1]; ++u) {
+                const SnDesc& D = S.sn[usn[u]];
+                int lb = ulb[u], ub = uub[u];
+                if (S.piece0[t + 1] - S.piece0[t] > 1) {
+                    while (lb <= ub && S.rows[D.pi + lb] < col_lo) ++lb;
+                    while (ub >= lb && S.rows[D.pi + ub] >= col_hi) --ub;
+                    if (lb > ub) continue;
+                }
+                UpdDesc U;
+                U.src = D.px + lb;
+                U.ld = D.r;
+                U.K = D.w;
+                U.m = D.r - lb;
+                U.n1 = ub - lb + 1;
+                U.rel = urel[u] + (lb - ulb[u]);
+                S.upd.push_back(U);
+                S.upd_src.push_back(S.piece0[usn[u] + 1] - 1);
+            }
+            for (int q = S.piece0[t]; q < p; ++q) {
+                const SnDesc& Q = S.csn[q];
+                UpdDesc U;
+                U.src = T.px + (int64_t)Q.rbias * T.r + C.rbias;
+                U.ld = T.r;
+                U.K = Q.w;
+                U.m = C.r;
+                U.n1 = C.w;
+                U.rel = -1;
+                S.upd.push_back(U);
+                S.upd_src.push_back(q);
+            }
+            C.nupd = (int)((int64_t)S.upd.size() - C.upd0);
+        }
+    }
+    auto is_big = [&](const UpdDesc& U) { return U.rel < 0 || U.K >= S.big_min_k; };
 
     // --- tiled supernodes: scratch slots and the per-wave update streams ---------------
     // Every (target, descendant) update is cut along the 32-row windows of the target's tiles:
     // the descendant rows that fall into row window I32 times those (among its first n1 rows)
     // that fall into column window J32 are one WaveEntry of sub-tile (I32, J32), I32 >= J32.
     // Lists keep the reference's update order, so the sum order per entry of L is fixed.
-    S.sn_wp0.assign(ns, -1);
-    S.sn_tw0.assign(ns, -1);
+    // Updates from wide descendants (is_big) do not enter these lists: BIG launches below.
+    S.sn_wp0.assign(nc, -1);
+    S.sn_tw0.assign(nc, -1);
     struct Group { int32_t win, first, len; };
     std::vector<Group> groups;
     std::vector<int64_t> cursor;
-    for (int t = 0; t < ns; ++t) {
-        SnDesc& T = S.sn[t];
+    struct BigKeyed { int64_t launch_tile; WaveEntry e; };  // launch id << 40 | global tile index
+    std::vector<BigKeyed> bigk;
+    std::vector<int64_t> big_tile0(nc + 1, 0);  // first 128x128 tile index of every tiled piece
+    for (int t = 0; t < nc; ++t) {
+        SnDesc& T = S.csn[t];
+        big_tile0[t + 1] = big_tile0[t];
+        if (S.solve_only) continue;
         if (is_small(T)) {
             S.n_small++;
             continue;
         }
         S.n_big++;
         const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
-        T.dslot = (int32_t)S.n_dslots;
-        S.n_dslots += nbc;
         if (S.n_tflags + (int64_t)nbc * nbr > 0x7fffffffLL) throw std::runtime_error("schedule: too many tiles");
         T.tflag0 = (int32_t)S.n_tflags;
         S.n_tflags += (int64_t)nbc * nbr;
@@ -133,19 +228,21 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const double K = (double)jb * kTile, wb = std::min(kTile, T.w - jb * kTile);
             S.inner_flops += K * wb * (wb + 1) + 2.0 * K * (double)(T.r - jb * kTile - wb) * wb;
         }
+        const int lev_t = S.level_of[t];
+        auto rel_at = [&](const UpdDesc& U, int k) { return U.rel < 0 ? k : S.relpos[(size_t)U.rel + k] - T.rbias; };
         // key of a list: ((J * nbr + I) * 2 + phase) * 4 + wave
         const size_t nkeys = (size_t)nbc * nbr * 8;
         auto for_each_entry = [&](auto&& fn) {
             for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
                 const UpdDesc& U = S.upd[u];
+                if (is_big(U)) continue;
                 // early: the descendant is complete before the level below the target even starts
-                const int phase = (S.level_of[usn[u]] <= S.level_of[t] - 2) ? 0 : 1;
-                const int32_t* rel = &S.relpos[U.rel];
+                const int phase = (S.level_of[S.upd_src[u]] <= lev_t - 2) ? 0 : 1;
                 groups.clear();
                 for (int k = 0; k < U.m;) {
-                    const int win = rel[k] / kSub;
+                    const int win = rel_at(U, k) / kSub;
                     int k1 = k + 1;
-                    while (k1 < U.m && rel[k1] / kSub == win) ++k1;
+                    while (k1 < U.m && rel_at(U, k1) / kSub == win) ++k1;
                     groups.push_back(Group{win, k, k1 - k});
                     k = k1;
                 }
@@ -172,9 +269,40 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.wave_entries[(size_t)(base + cursor[key]++)] =
                 WaveEntry{U.src, (int32_t)U.rel, U.ld, U.K, ia, ja, mi | (nj << 8)};
         });
+        // ---- BIG: the wide descendants, cut along the 128-row windows of the target's panel
+        const int nbr128 = ceil_div(T.r, kBigTile), nbc128 = ceil_div(T.w, kBigTile);
+        big_tile0[t + 1] = big_tile0[t] + (int64_t)nbr128 * nbc128;
         for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
             const UpdDesc& U = S.upd[u];
-            S.tile_update_flops += (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
+            const double f = (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
+            if (!is_big(U)) {
+                S.tile_update_flops += f;
+                continue;
+            }
+            S.big_flops += f;
+            const int lev_s = S.level_of[S.upd_src[u]];
+            if (lev_s >= lev_t) throw std::runtime_error("schedule: an update source is not below its target");
+            const int64_t launch = (int64_t)lev_s * 2 + (lev_s == lev_t - 1 ? 0 : 1);
+            groups.clear();
+            for (int k = 0; k < U.m;) {
+                const int win = rel_at(U, k) / kBigTile;
+                int k1 = k + 1;
+                if (U.rel < 0) k1 = std::min(U.m, (win + 1) * kBigTile);
+                else while (k1 < U.m && rel_at(U, k1) / kBigTile == win) ++k1;
+                groups.push_back(Group{win, k, k1 - k});
+                k = k1;
+            }
+            for (const Group& gc : groups) {
+                if (gc.first >= U.n1) break;
+                const int nj = std::min(gc.len, U.n1 - gc.first);
+                for (const Group& gr : groups) {
+                    if (gr.win < gc.win) continue;
+                    const int64_t tile = big_tile0[t] + (int64_t)gc.win * nbr128 + gr.win;
+                    bigk.push_back(BigKeyed{(launch << 40) | tile,
+                                            WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, gr.first,
+                                                      gc.first, gr.len | (nj << 8) | ((U.rel < 0) << 16)}});
+                }
+            }
         }
         // weight of every tile = 16-wide k chunks of its longest wave stream
         S.sn_tw0[t] = (int64_t)S.tile_w.size();
@@ -216,6 +344,35 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             }
         }
     }
+    // ---- BIG tasks: one per (launch, tile), entries in update order (stable sort)
+    if (!bigk.empty()) {
+        std::stable_sort(bigk.begin(), bigk.end(),
+                         [](const BigKeyed& a, const BigKeyed& b) { return a.launch_tile < b.launch_tile; });
+        S.big_entries.resize(bigk.size());
+        int t = 0;
+        for (size_t i = 0; i < bigk.size();) {
+            size_t j = i;
+            int64_t weight = 0;
+            while (j < bigk.size() && bigk[j].launch_tile == bigk[i].launch_tile) {
+                S.big_entries[j] = bigk[j].e;
+                weight += ceil_div(bigk[j].e.K, 16) + 4;
+                ++j;
+            }
+            const int64_t launch = bigk[i].launch_tile >> 40, tile = bigk[i].launch_tile & ((1LL << 40) - 1);
+            while (t + 1 < nc && big_tile0[t + 1] <= tile) ++t;   // tiles ascend within a launch ...
+            if (tile < big_tile0[t]) {                             // ... and start over with the next one
+                t = 0;
+                while (big_tile0[t + 1] <= tile) ++t;
+            }
+            const int nbr128 = ceil_div(S.csn[t].r, kBigTile);
+            const int64_t local = tile - big_tile0[t];
+            S.big_all.push_back(Schedule::BigTask{t, (int32_t)(local % nbr128) * kBigTile,
+                                                  (int32_t)(local / nbr128) * kBigTile,
+                                                  (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
+                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0)});
+            i = j;
+        }
+    }
 
     build_launches(S, active);
 }
@@ -241,22 +398,38 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve.clear();
     S.n_solve_wide = 0;
 
-    // TILES_EARLY(lev) is enqueued right before level lev-1's launches, so that it runs on the side
-    // stream while the main stream works through that level's block-column chain.
+    // Side-stream launches -- TILES(lev): the early wave streams of level lev's tiles, PUSH(s): the BIG
+    // updates from level s's supernodes into targets at levels >= s + 2 -- are enqueued right before the
+    // main-stream launches of the level in between (lev - 1 = s + 1), so that they run while the main
+    // stream works through that level's chain; Launch::level = lev = s + 2 is the level whose main-stream
+    // launches wait for them.
+    S.big_tasks.clear();
     std::vector<Launch> early_launches;
     std::vector<size_t> level_begin;  // index in S.chol where each level's launches start
     std::vector<int> bigs, sbigs;
-    for (int lev = 0; lev < S.nlevels; ++lev) {
+    // BIG tasks of every (source level, kind), active targets only, heaviest first
+    std::vector<std::vector<const Schedule::BigTask*>> big_next(S.cnlevels), big_push(S.cnlevels);
+    for (const Schedule::BigTask& b : S.big_all)
+        if (S.active[S.csn_real[b.sn]]) (b.next ? big_next : big_push)[b.src_level].push_back(&b);
+    auto emit_big = [&](std::vector<const Schedule::BigTask*>& v, Launch L) {
+        if (v.empty()) return L;
+        std::stable_sort(v.begin(), v.end(),
+                         [](const Schedule::BigTask* a, const Schedule::BigTask* b) { return a->weight > b->weight; });
+        L.first = (int32_t)S.big_tasks.size();
+        for (const Schedule::BigTask* b : v) S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
+        L.count = (int32_t)v.size();
+        return L;
+    };
+    for (int lev = 0; lev < S.cnlevels && !S.solve_only; ++lev) {
         level_begin.push_back(S.chol.size());
         bigs.clear();
-        sbigs.clear();
         // ---- Cholesky -------------------------------------------------------------
-        if (!S.solve_only) {
+        {
             Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
-            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
-                const int t = S.levelSet[q];
-                if (!S.active[t]) continue;
-                const SnDesc& T = S.sn[t];
+            for (int q = S.clevelPtr[lev]; q < S.clevelPtr[lev + 1]; ++q) {
+                const int t = S.clevelSet[q];
+                if (!S.active[S.csn_real[t]]) continue;
+                const SnDesc& T = S.csn[t];
                 if (is_small(T)) {
                     S.small_list.push_back(t);
                     L.lds_bytes = std::max<int32_t>(L.lds_bytes, T.w * T.r * (int)sizeof(double));
@@ -271,13 +444,23 @@ void build_launches(Schedule& S, const uint8_t* active) {
             L.count = (int32_t)S.small_list.size() - L.first;
             if (L.count > 0) S.chol.push_back(L);
         }
-        if (!S.solve_only && !bigs.empty()) {
+        // ---- PUSH(lev): this level's wide supernodes update everything at least two levels up (side
+        // stream, once the level is complete); NEXT(lev - 1): the level below updates this level's tiles
+        if (lev + 2 < S.cnlevels) {
+            Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1});
+            if (Lp.count > 0) early_launches.push_back(Lp);
+        }
+        if (lev > 0) {
+            Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0});
+            if (Ln.count > 0) S.chol.push_back(Ln);
+        }
+        if (!bigs.empty()) {
             // ---- TILES: the early part of the external updates, longest streams first ------
             {
                 Launch Lt{kLaunchTiles, (int32_t)S.tiles.size(), 0, lev, 0, 0, 0, 1, lev - 2, 1};
                 std::vector<std::pair<int32_t, TileDesc>> wt;  // (weight, tile)
                 for (int t : bigs) {
-                    const SnDesc& T = S.sn[t];
+                    const SnDesc& T = S.csn[t];
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     const int32_t* tw = &S.tile_w[S.sn_tw0[t]];
                     for (int J = 0; J < nbc; ++J)
@@ -315,11 +498,11 @@ void build_launches(Schedule& S, const uint8_t* active) {
             for (size_t b0 = 0; b0 < bigs.size(); b0 += (size_t)S.walker_batch) {
               const size_t b1 = std::min(bigs.size(), b0 + (size_t)S.walker_batch);
               int maxnb = 0;
-              for (size_t q = b0; q < b1; ++q) maxnb = std::max(maxnb, ceil_div(S.sn[bigs[q]].w, kTile));
+              for (size_t q = b0; q < b1; ++q) maxnb = std::max(maxnb, ceil_div(S.csn[bigs[q]].w, kTile));
               for (int J = 0; J < maxnb; ++J)
                 for (size_t q = b0; q < b1; ++q) {
                     const int t = bigs[q];
-                    const SnDesc& T = S.sn[t];
+                    const SnDesc& T = S.csn[t];
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     if (J >= nbc) continue;
                     auto push = [&](int I, int Jc) {
@@ -341,6 +524,23 @@ void build_launches(Schedule& S, const uint8_t* active) {
             Lc.count = (int32_t)S.tiles.size() - Lc.first;
             S.chol.push_back(Lc);
         }
+    }
+    // splice the side launches in front of the level before the one that waits for them (stable: PUSH
+    // before TILES of the same level)
+    if (!early_launches.empty()) {
+        std::vector<Launch> merged;
+        size_t e = 0;
+        std::stable_sort(early_launches.begin(), early_launches.end(),
+                         [](const Launch& a, const Launch& b) { return a.level < b.level; });
+        for (int lev = 0; lev < S.cnlevels; ++lev) {
+            while (e < early_launches.size() && early_launches[e].level - 1 <= lev) merged.push_back(early_launches[e++]);
+            const size_t b0 = level_begin[lev], b1 = lev + 1 < S.cnlevels ? level_begin[lev + 1] : S.chol.size();
+            merged.insert(merged.end(), S.chol.begin() + b0, S.chol.begin() + b1);
+        }
+        S.chol.swap(merged);
+    }
+    for (int lev = 0; lev < S.nlevels; ++lev) {
+        sbigs.clear();
         // ---- forward solve ----------------------------------------------------------
         {
             Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
@@ -388,19 +588,6 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 S.solve_fix_list.insert(S.solve_fix_list.end(), sbigs.begin(), sbigs.end());
             }
         }
-    }
-    // splice the early launches in front of the level before their target level
-    if (!early_launches.empty()) {
-        std::vector<Launch> merged;
-        size_t e = 0;
-        std::sort(early_launches.begin(), early_launches.end(),
-                  [](const Launch& a, const Launch& b) { return a.level < b.level; });
-        for (int lev = 0; lev < S.nlevels; ++lev) {
-            while (e < early_launches.size() && early_launches[e].level - 1 <= lev) merged.push_back(early_launches[e++]);
-            const size_t b0 = level_begin[lev], b1 = lev + 1 < S.nlevels ? level_begin[lev + 1] : S.chol.size();
-            merged.insert(merged.end(), S.chol.begin() + b0, S.chol.begin() + b1);
-        }
-        S.chol.swap(merged);
     }
     // ---- backward solve: root level first.  Per level one chain launch for the block columns of
     // the wide supernodes (last block column first: block jb waits for the published x of blocks
@@ -469,7 +656,7 @@ int64_t simulate_chain(const Schedule& S, int slots) {
             progress = false;
             while ((int)resident.size() < slots && next < count) {
                 const TileDesc& td = S.tiles[(size_t)L.first + (size_t)next++];
-                const SnDesc& D = S.sn[td.sn];
+                const SnDesc& D = S.csn[td.sn];
                 const int nbc = ceil_div(D.w, kTile);
                 Task t{td.sn, td.row0 / kTile, td.col0 / kTile, 3, 0};
                 if (t.I == 0 && t.J == 0) t.role = 0;
@@ -480,7 +667,7 @@ int64_t simulate_chain(const Schedule& S, int slots) {
             }
             for (size_t q = 0; q < resident.size();) {
                 Task& t = resident[q];
-                const SnDesc& D = S.sn[t.sn];
+                const SnDesc& D = S.csn[t.sn];
                 const int nbc = ceil_div(D.w, kTile);
                 auto flag = [&](int I, int J) { return (size_t)D.tflag0 + (size_t)I * nbc + J; };
                 bool done = false;

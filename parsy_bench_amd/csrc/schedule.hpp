@@ -48,12 +48,18 @@ struct SnDesc {       // one per supernode
     int32_t a0, a1;   // entries [a0,a1) of A2 belong to this supernode's columns
     int32_t dslot;    // first 64x64 slot of the per-block-column scratch (solve: inverse blocks; -1: SMALL)
     int32_t tflag0;   // first tile flag of a tiled supernode: tile (I,J) has flag tflag0 + I*ceil(w/64) + J
+    int32_t ld;       // leading dimension of the panel: r, except for a piece of a split supernode
+                      // (rows of the whole supernode; the piece is a window of its panel)
+    int32_t rbias;    // piece of a split supernode: offset of its first column inside the supernode
+                      // (relpos values count from the supernode's first row; panel row = relpos - rbias)
 };
 
 struct UpdDesc {      // one per (target, descendant) pair, in the reference's update order
     int64_t src;      // offset in lValues of row lb of the descendant's panel
     int64_t rel;      // offset into relpos: position in the target's row list of
-                      // descendant rows lb, lb+1, ...  (the reference's map[lR[..]])
+                      // descendant rows lb, lb+1, ...  (the reference's map[lR[..]]);
+                      // -1: identity (row lb + k of the source is row k of the target's panel:
+                      // the earlier pieces of a split supernode)
     int32_t ld;       // rows of the descendant (leading dimension)
     int32_t K;        // width of the descendant
     int32_t m;        // nSupRs: descendant rows from lb to the end
@@ -88,14 +94,14 @@ struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
 };
 
 enum LaunchKind : int32_t {
-    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2,  // 3, 4: retired (PANEL, FIXUP)
+    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,  // 4: retired (FIXUP)
     kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
 };
 
 struct Launch {
     int32_t kind;
     int32_t first, count;  // range in the kind's descriptor array
-    int32_t level;
+    int32_t level;         // etree level of the targets; side launches: level whose main-stream launches wait for it
     int32_t jb;            // SMALL: stage size; CHAIN: index of its ticket counter; SOLVE_PANEL / BACK: block column
     int32_t lds_bytes;     // dynamic LDS (SMALL)
     int32_t fused;         // SOLVE_PANEL: 1 = chain launch of the whole level
@@ -109,6 +115,10 @@ constexpr int kSplitTarget = 128;        // ... into parts of about this length 
 constexpr int kSplitMaxParts = 4;
 constexpr int kWalkerBatch = 64;          // CHAIN: supernodes whose tiles are interleaved block column by block column
                                          // (upper bound; Schedule::walker_batch follows the device's CU count)
+constexpr int kBigTile = 128;             // tile edge of the BIG (LDS-staged GEMM) update kernel
+constexpr int kBigMinK = 128;             // updates from descendants at least this wide go through it (PARSY_BIG_MINK)
+constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this are factored as a chain of pieces
+                                          // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
@@ -126,8 +136,19 @@ struct Schedule {
     double tile_update_flops = 0;  // external-update flops of the tiled supernodes (TILES launches)
     double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (CHAIN launches)
 
-    std::vector<SnDesc> sn;
-    std::vector<UpdDesc> upd;
+    std::vector<SnDesc> sn;          // the supernodes of the pattern (solve launches)
+    // Cholesky view: the same supernodes, the very wide ones cut into pieces (column ranges) that are
+    // factored one after the other like a chain of supernodes -- a piece's panel is a window of the
+    // supernode's panel (ld, rbias), the pieces to its left update it like descendants (identity row
+    // map).  Levels, update lists, tiles and launches of the factorization are built on this view.
+    std::vector<SnDesc> csn;
+    std::vector<int32_t> piece0;     // per supernode: its first piece in csn (nsuper + 1 entries)
+    std::vector<int32_t> csn_real;   // per piece: its supernode
+    std::vector<int> clevelPtr, clevelSet;  // level sets of the chain-extended etree
+    int cnlevels = 0;
+    int big_min_k = kBigMinK, piece_width = kPieceWidth;
+    std::vector<UpdDesc> upd;        // update descriptors of the Cholesky view (per piece)
+    std::vector<int32_t> upd_src;    // ... and the piece that completes each one's source (its last piece)
     std::vector<int32_t> relpos;
     std::vector<int64_t> a_dst;     // destination in lValues of every A2 entry
     std::vector<int32_t> rows;      // lR
@@ -137,6 +158,14 @@ struct Schedule {
     // Cholesky launch data
     std::vector<int32_t> small_list;
     std::vector<TileDesc> tiles;       // TILES and CHAIN descriptors
+    // BIG: updates from wide descendants (K >= big_min_k), one workgroup per 128x128 tile of the target
+    // and launch; launches go by the level of the SOURCE: NEXT(s) = targets one level up (main stream,
+    // before their chain), PUSH(s) = targets further up (side stream, as soon as level s is complete).
+    std::vector<WaveEntry> big_entries;   // per task: (source, row window, column window), sources in update order
+    struct BigTask { int32_t sn, row0, col0, weight; int64_t e0, e1; int32_t src_level, next; };
+    std::vector<BigTask> big_all;         // every task, grouped by (src_level, next)
+    std::vector<TileDesc> big_tasks;      // tasks of the launches (active targets): wp = e0, sp = e1
+    double big_flops = 0;                 // flops of the BIG launches
     std::vector<Launch> chol;
 
     // solve launch data

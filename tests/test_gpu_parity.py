@@ -486,3 +486,39 @@ def test_end_to_end_solve_residual(api, oracle, name):
     assert np.abs(R).max() <= RESID_TOL * (np.abs(As).max() * np.abs(X).max() + np.abs(B).max())
     xs, _ = plan.solve_spd(lv, As @ np.ones(sym.n))
     assert np.abs(xs - 1.0).max() <= 1e-9
+
+
+# ---------------------------------------------------------------------------
+# BIG launches (LDS-staged GEMM updates from wide descendants) and the pieces of split
+# supernodes: forced onto small inputs with the diagnostic knobs of the schedule
+# (PARSY_PIECE_WIDTH / PARSY_BIG_MINK are read when a plan is built)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,piece,mink", [("small3d", 128, 16), ("mid3d", 128, 16), ("mid3d", 128, 48),
+                                             ("lap30", 128, 32), ("lap30", 256, 64), ("ex15", 128, 16),
+                                             ("mid3d", 0, 32), ("lap30", 512, 128)])
+def test_factor_with_pieces_and_big_launches(api, oracle, monkeypatch, name, piece, mink):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    assert info["piece_width"] == piece and info["big_min_k"] == mink
+    if piece and sym.maxSupWid > piece * 3 // 2:
+        assert info["n_pieces"] > sym.nsuper and info["chol_levels"] > sym.nlevels
+    assert info["big_tasks"] > 0 and info["big_flops"] > 0
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok
+    err = np.abs(lv - lo).max() / np.abs(lo).max()
+    assert err <= FACTOR_TOL, f"{name} piece={piece} mink={mink}: {err:.3e}"
+    lv2, _ = plan.factor(sym.A2x)
+    assert np.array_equal(lv, lv2)  # fixed summation order: bitwise reproducible
+    # the schedule is a rearrangement of the same work: flop counts add up
+    monkeypatch.delenv("PARSY_PIECE_WIDTH")
+    monkeypatch.delenv("PARSY_BIG_MINK")
+    ref = api.Plan(sym, 0).info
+    tot = info["big_flops"] + info["tile_update_flops"] + info["inner_flops"]
+    tot_ref = ref["big_flops"] + ref["tile_update_flops"] + ref["inner_flops"]
+    assert tot <= tot_ref * (1 + 1e-12) + 1 and info["update_flops"] == ref["update_flops"]
