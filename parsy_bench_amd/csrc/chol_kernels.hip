@@ -1292,20 +1292,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
 static constexpr int kBK = 16;                 // k extent of a staged chunk
 static constexpr int kBLd = kBigTile + 16;     // k stride of a staged chunk in LDS: lanes 16..31 (k + 1) of an
                                                // operand read hit the other half of the banks
+static constexpr int kBigThreads = 512;        // 8 waves: 2 (rows) x 4 (columns), 64 x 32 outputs each; two
+                                               // workgroups per CU = 4 waves per SIMD, so that the epilogue and
+                                               // the start of one task hide behind the multiplies of the others
 struct BigLds {
     double R[2][kBK * kBLd];
     double C[2][kBK * kBLd];
 };
 
-__global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restrict__ sn,
-                                                          const int32_t* __restrict__ relpos,
-                                                          const WaveEntry* __restrict__ ents,
-                                                          const TileDesc* __restrict__ tasks,
-                                                          double* __restrict__ L) {
+__global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __restrict__ sn,
+                                                             const int32_t* __restrict__ relpos,
+                                                             const WaveEntry* __restrict__ ents,
+                                                             const TileDesc* __restrict__ tasks,
+                                                             double* __restrict__ L) {
     __shared__ BigLds S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
     const TileDesc td = tasks[blockIdx.x];
     const SnDesc D = sn[td.sn];
     double* __restrict__ G = L + D.px;
@@ -1314,13 +1317,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
 
-    // ---- loader: thread (row = tid & 127, k = (tid >> 7) + 2 q) of both staged blocks
+    // ---- loader: thread (row = tid & 127, k = (tid >> 7) + 4 q) of both staged blocks
+    constexpr int kLq = kBK * kBigTile / kBigThreads;  // values per thread, block and chunk (4)
+    constexpr int kLs = kBigThreads / kBigTile;        // k stride between them (4)
     const int lrow = tid & (kBigTile - 1), lkh = tid >> 7;
     int64_t le = e_begin;
     int lk = 0;                       // k position inside entry le
     WaveEntry LE = ents[le];
-    double vR[8], vC[8];
-    int v_kend = 0;                   // valid k of the chunk held in vR / vC
+    double vR[kLq], vC[kLq];
+    int v_kend = 0;                   // valid k of the chunk held in vR / vC (-1: no chunk)
     auto fetch = [&]() {
         if (le >= e_end) {
             v_kend = -1;
@@ -1331,8 +1336,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
         const double* __restrict__ pr = L + LE.src + LE.ia + min(lrow, mi - 1) + (int64_t)lk * LE.ld;
         const double* __restrict__ pc = L + LE.src + LE.ja + min(lrow, nj - 1) + (int64_t)lk * LE.ld;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t ko = (int64_t)min(lkh + 2 * q, kend - 1) * LE.ld;
+        for (int q = 0; q < kLq; ++q) {
+            const int64_t ko = (int64_t)min(lkh + kLs * q, kend - 1) * LE.ld;
             vR[q] = pr[ko];
             vC[q] = pc[ko];
         }
@@ -1346,8 +1351,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
     };
     auto stage = [&](int b) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = lkh + 2 * q;
+        for (int q = 0; q < kLq; ++q) {
+            const int k = lkh + kLs * q;
             S.R[b][k * kBLd + lrow] = k < v_kend ? vR[q] : 0.0;
             S.C[b][k * kBLd + lrow] = k < v_kend ? vC[q] : 0.0;
         }
@@ -1357,33 +1362,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
     int64_t ce = e_begin;
     int ck = 0;
     WaveEntry CE = LE;
-    double4_t acc[4][4];
+    double4_t acc[2][4];  // [16-row fragment of the column window][... of the row window]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
 
     auto frags = [&](const WaveEntry& E, int& nfr, int& nfc) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         nfr = min(4, max(0, (mi - 64 * wr + 15) >> 4));
-        nfc = min(4, max(0, (nj - 64 * wc + 15) >> 4));
-        if (diag && wr < wc) nfr = 0;  // strictly upper quadrant of a diagonal tile
+        nfc = min(2, max(0, (nj - 32 * wc + 15) >> 4));
+        if (diag && 64 * wr + 63 < 32 * wc) nfr = 0;  // block strictly above the diagonal of a diagonal tile
         if (nfr == 0 || nfc == 0) nfr = nfc = 0;
     };
     auto compute = [&](int b, int nfr, int nfc) {
-        const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
-        const double* __restrict__ Cb = &S.C[b][64 * wc + l15];
         if (nfr == 0) return;
+        const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
+        const double* __restrict__ Cb = &S.C[b][32 * wc + l15];
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
-            double rv[4], cv[4];
+            double rv[4], cv[2];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                rv[f] = Rb[(4 * ks + kq) * kBLd + 16 * f];
-                cv[f] = Cb[(4 * ks + kq) * kBLd + 16 * f];
-            }
+            for (int f = 0; f < 4; ++f) rv[f] = Rb[(4 * ks + kq) * kBLd + 16 * f];
 #pragma unroll
-            for (int fc = 0; fc < 4; ++fc) {
+            for (int f = 0; f < 2; ++f) cv[f] = Cb[(4 * ks + kq) * kBLd + 16 * f];
+#pragma unroll
+            for (int fc = 0; fc < 2; ++fc) {
                 if (fc < nfc) {
 #pragma unroll
                     for (int fr = 0; fr < 4; ++fr)
@@ -1394,7 +1398,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
         }
     };
     // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
-    // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C)
+    // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C), 8 loads of a lane at a time
     auto epilogue = [&](const WaveEntry& E, int nfr, int nfc) {
         if (nfr == 0) return;
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
@@ -1407,31 +1411,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_big(const SnDesc* __restri
             if (i < mi) prow[fr] = ident ? E.ia + i : relpos[(int64_t)E.rel + E.ia + i] - D.rbias;
         }
 #pragma unroll
-        for (int fc = 0; fc < 4; ++fc) {
+        for (int fc = 0; fc < 2; ++fc) {
             if (fc < nfc) {
                 int pcol[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int j = 64 * wc + 16 * fc + kq + 4 * v;
+                    const int j = 32 * wc + 16 * fc + kq + 4 * v;
                     pcol[v] = -1;
                     if (j < nj) pcol[v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
                 }
 #pragma unroll
-                for (int fr = 0; fr < 4; ++fr) {
-                    if (fr < nfr) {
-                        double old[4];
+                for (int fh = 0; fh < 4; fh += 2) {
+                    double old[2][4];
+#pragma unroll
+                    for (int fr = fh; fr < fh + 2; ++fr)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
-                            old[v] = ok ? G[(int64_t)pcol[v] * ld + prow[fr]] : 0.0;
+                            old[fr - fh][v] = ok ? G[(int64_t)pcol[v] * ld + prow[fr]] : 0.0;
                         }
+#pragma unroll
+                    for (int fr = fh; fr < fh + 2; ++fr)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
-                            if (ok) G[(int64_t)pcol[v] * ld + prow[fr]] = old[v] - acc[fc][fr][v];
+                            if (ok) G[(int64_t)pcol[v] * ld + prow[fr]] = old[fr - fh][v] - acc[fc][fr][v];
                         }
-                        asm volatile("" ::: "memory");  // one group of loads in flight (registers)
-                    }
+                    asm volatile("" ::: "memory");  // 8 loads of a lane in flight (registers)
                 }
             }
 #pragma unroll
@@ -1483,7 +1489,7 @@ extern "C" void parsy_debug_trace(unsigned long long* out) {
 
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_big, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.big_entries,
+    hipLaunchKernelGGL(k_chol_big, dim3(count), dim3(kBigThreads), 0, stream, P.csn, P.relpos, P.big_entries,
                        P.big_tasks + first, L);
 }
 
