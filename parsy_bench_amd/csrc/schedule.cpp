@@ -36,6 +36,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     S.piece_width = env_int("PARSY_PIECE_WIDTH", kPieceWidth);
     if (S.piece_width > 0) S.piece_width = ceil_div(std::max(S.piece_width, kBigTile), kBigTile) * kBigTile;
     if (S.piece_width < S.big_min_k) S.piece_width = 0;  // the pieces update each other through the BIG launches
+    S.push_group = std::max(1, env_int("PARSY_PUSH_GROUP", kPushGroup));
 
     // --- supernode descriptors ------------------------------------------------
     S.sn.resize(ns);
@@ -180,22 +181,37 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                 S.upd.push_back(U);
                 S.upd_src.push_back(S.piece0[usn[u] + 1] - 1);
             }
-            for (int q = S.piece0[t]; q < p; ++q) {
-                const SnDesc& Q = S.csn[q];
+            // the pieces to the left: the one right before this piece by itself (it is applied by the NEXT
+            // launch of its level), the earlier ones in aligned groups of push_group pieces -- adjacent
+            // columns of the same panel, one update with the summed width, due when the group's last
+            // piece is complete (a group is cut short where this piece's turn comes first)
+            const int j = p - S.piece0[t];
+            for (int g0 = 0; g0 < j; ) {
+                int g1 = (g0 == j - 1) ? j : std::min(j - 1, (g0 / S.push_group + 1) * S.push_group);
+                const SnDesc& Q0 = S.csn[S.piece0[t] + g0];
+                int K = 0;
+                for (int q = g0; q < g1; ++q) K += S.csn[S.piece0[t] + q].w;
                 UpdDesc U;
-                U.src = T.px + (int64_t)Q.rbias * T.r + C.rbias;
+                U.src = T.px + (int64_t)Q0.rbias * T.r + C.rbias;
                 U.ld = T.r;
-                U.K = Q.w;
+                U.K = K;
                 U.m = C.r;
                 U.n1 = C.w;
                 U.rel = -1;
                 S.upd.push_back(U);
-                S.upd_src.push_back(q);
+                S.upd_src.push_back(S.piece0[t] + g1 - 1);
+                g0 = g1;
             }
             C.nupd = (int)((int64_t)S.upd.size() - C.upd0);
         }
     }
-    auto is_big = [&](const UpdDesc& U) { return U.rel < 0 || U.K >= S.big_min_k; };
+    // Updates that go through the BIG launches: wide descendants, and EVERY update of a split supernode's
+    // pieces (what little reaches those from narrow descendants would otherwise be a TILES launch per
+    // piece, in between the PUSH launches of the side stream).
+    auto is_big = [&](const UpdDesc& U, int target_piece) {
+        const int real = S.csn_real[target_piece];
+        return U.rel < 0 || U.K >= S.big_min_k || S.piece0[real + 1] - S.piece0[real] > 1;
+    };
 
     // --- tiled supernodes: scratch slots and the per-wave update streams ---------------
     // Every (target, descendant) update is cut along the 32-row windows of the target's tiles:
@@ -235,7 +251,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         auto for_each_entry = [&](auto&& fn) {
             for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
                 const UpdDesc& U = S.upd[u];
-                if (is_big(U)) continue;
+                if (is_big(U, t)) continue;
                 // early: the descendant is complete before the level below the target even starts
                 const int phase = (S.level_of[S.upd_src[u]] <= lev_t - 2) ? 0 : 1;
                 groups.clear();
@@ -275,7 +291,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
             const UpdDesc& U = S.upd[u];
             const double f = (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
-            if (!is_big(U)) {
+            if (!is_big(U, t)) {
                 S.tile_update_flops += f;
                 continue;
             }

@@ -119,6 +119,7 @@ constexpr int kBigTile = 128;             // tile edge of the BIG (LDS-staged GE
 constexpr int kBigMinK = 128;             // updates from descendants at least this wide go through it (PARSY_BIG_MINK)
 constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this are factored as a chain of pieces
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
+constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
@@ -146,7 +147,7 @@ struct Schedule {
     std::vector<int32_t> csn_real;   // per piece: its supernode
     std::vector<int> clevelPtr, clevelSet;  // level sets of the chain-extended etree
     int cnlevels = 0;
-    int big_min_k = kBigMinK, piece_width = kPieceWidth;
+    int big_min_k = kBigMinK, piece_width = kPieceWidth, push_group = kPushGroup;
     std::vector<UpdDesc> upd;        // update descriptors of the Cholesky view (per piece)
     std::vector<int32_t> upd_src;    // ... and the piece that completes each one's source (its last piece)
     std::vector<int32_t> relpos;
