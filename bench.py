@@ -2,7 +2,7 @@
 """Benchmark of the hot path: supernodal Cholesky factorizations/s (+ BCSC forward
 solves/s) on a SuiteSparse-class SPD matrix, numeric phase only, inputs resident in HBM.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one numeric factorization of the workload matrix (pattern analysed and
@@ -10,11 +10,14 @@ uploaded once, outside the timed region -- the reference times only the executor
 too: examples/choleskyTest01.cpp:209-229).  After the K factorization steps, K forward
 solves are timed the same way and reported as `solves_per_sec`.
 
-N = 1 workload: the nd24k-class stand-in (BASELINE.json configs[1]; the SuiteSparse
-file itself cannot be fetched offline): 3-D 27-point stencil 42^3, geometric nested
-dissection.  N > 1: the same matrix, etree subtrees sharded over the ranks, ONE
-exchange step (RCCL point-to-point gather of the subtree panels onto rank 0), root
-part on rank 0 -- strong scaling, as north_star describes it.
+N = 1 workload: the Flan_1565-class stand-in (BASELINE.json configs[2], the largest
+single-GPU configuration; the SuiteSparse file itself cannot be fetched offline): 3-D
+27-point stencil 116^3, geometric nested dissection, n = 1 560 896, 19.4 GB of lValues.
+The nd24k-class (configs[1]) and parabolic_fem-class (configs[3]: solves with 1 / 8 / 64
+right-hand sides) inputs are measured after it and reported as extra objects, never as
+`value`.  N > 1: the same matrix, etree subtrees sharded over the ranks, ONE exchange
+step (RCCL point-to-point gather of the subtree panels onto rank 0), root part on rank 0
+-- strong scaling, as north_star describes it.
 
 PyTorch is plumbing here: device buffers, the HIP stream, torch.distributed.  All
 numerics run in libparsy_amd.so through its C ABI.
@@ -22,6 +25,7 @@ numerics run in libparsy_amd.so through its C ABI.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,59 +39,129 @@ sys.path.insert(0, str(ROOT))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, datasheet (the microarch guide lists no f64 row)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+SOLVE_TOL = 1e-9               # max|x - 1| of the solve of L x = L 1 (reference testTriangular: 1e-3)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sym, threads_all: int, want_solve: bool = True):
-    """Time the CPU port (oracle/, test infrastructure) on this host: one factorization of
-    the same matrix at 1 thread and at all threads; the faster one is reported."""
+def kernel_source_hash() -> str:
+    """Identifies the kernels a committed PMC summary was measured on (profiles/*pmc*.json carry it)."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "parsy_bench_amd" / "csrc").glob("*")):
+        if p.suffix in (".hip", ".cpp", ".hpp"):
+            h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------
+# CPU baseline: the oracle (oracle/, test infrastructure: a plain-C restatement of the reference's
+# executors, -O3 -fopenmp, dense kernels bound to the image's MKL when present -- what the reference
+# links) timed on this host.  Only this leg of bench.py touches oracle/.
+# ---------------------------------------------------------------------------------------
+def _subtree_ranges(sym):
+    """first[s] = first supernode of the subtree rooted at s (supernodes are postordered: the subtree is
+    the contiguous range first[s]..s); cost[s] = flops on the stored structure of that subtree."""
+    ns = sym.nsuper
+    first = np.arange(ns)
+    par = np.asarray(sym.sParent)
+    for s in range(ns):
+        p = par[s]
+        if p >= 0 and first[s] < first[p]:
+            first[p] = first[s]
+    w = np.diff(sym.super).astype(np.float64)
+    r = np.diff(sym.i_ptr[sym.super].astype(np.int64)).astype(np.float64)
+    own = w * r * r - w * (w - 1) * r + w * (w - 1) * (2 * w - 1) / 6.0   # sum_t (r - t)^2
+    cum = np.concatenate([[0.0], np.cumsum(own)])
+    return first, cum[np.arange(ns) + 1] - cum[first], float(own.sum())
+
+
+def cpu_baseline(sym, threads: int, budget_s: float = 8.0):
+    """Time the CPU port on a BOUNDED sample of the same matrix: one etree subtree (a complete
+    factorization of its own columns, same mix of narrow and wide supernodes) sized from a calibration
+    run to about `budget_s` seconds, median of 3 runs after a warm-up; the whole matrix when it fits the
+    budget.  value = (executed flops of the sample / seconds) / executed flops of the whole job."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as O
-    from parsy_bench_amd import inspector as I
     O.lib()
     blas = O.bind_system_blas()
-    hl = I.trivial_hlevel(sym)
-    best = None
-    lo = None
-    for th in sorted({1, threads_all}):
-        t0 = time.perf_counter()
-        ok, lv, _ = O.cholesky_05(sym, sym.A2x, hl, threads=th)
-        dt = time.perf_counter() - t0
-        if not ok:
-            raise RuntimeError("CPU port reported a non-positive pivot")
-        lo = lv
-        if best is None or dt < best[0]:
-            best = (dt, th)
-        if dt > 40:
-            break
-    out = {"value": 1.0 / best[0], "unit": "factorizations/s", "cores": best[1], "kind": "port",
-           "sample": f"1 factorization of the same matrix per thread count (1 and {threads_all}), "
-                     f"best of the two; oracle/parsy_oracle.c -O3 -fopenmp, dense kernels: "
-                     f"{blas or 'built-in loops'}",
-           "seconds": best[0]}
-    if want_solve:
-        b = O.rhs_init_blocked(sym, lo)
-        t0 = time.perf_counter()
-        x = O.blocked_lsolve(sym, lo, b, "H1", threads=threads_all)
-        out["solves_per_sec"] = 1.0 / (time.perf_counter() - t0)
-        out["solve_max_abs_err"] = float(np.abs(x - 1.0).max())
+    first, sub, total = _subtree_ranges(sym)
+    ns = sym.nsuper
+
+    def run(root, reps):
+        ts = []
+        for _ in range(reps):
+            ok, dt = O.cholesky_wavefront_subtree(sym, sym.A2x, int(root), int(first[root]), threads=threads)
+            if not ok:
+                raise RuntimeError("CPU port reported a non-positive pivot")
+            ts.append(dt)
+        return float(np.median(ts))
+
+    def pick(limit):
+        ok = np.where(sub <= limit)[0]
+        return int(ok[np.argmax(sub[ok])])
+
+    # calibration (doubles as the warm-up of the BLAS threads and of the page cache)
+    cal = pick(max(total * 1e-3, min(total, 3e10)))
+    run(cal, 1)
+    rate = sub[cal] / run(cal, 1)
+    root = pick(max(sub[cal], rate * budget_s))
+    whole = sub[root] >= 0.999 * total
+    secs = run(root, 3)
+    sample = (f"{'the whole matrix' if whole else 'one etree subtree'}: supernodes {int(first[root])}..{root} of "
+              f"{ns} = {100.0 * sub[root] / total:.2f} % of the executed flops ({sub[root]:.3e} of {total:.3e}), "
+              f"median of 3 runs after a warm-up; oracle/parsy_oracle.c wavefront executor, -O3 -fopenmp, "
+              f"{threads} OpenMP threads over the supernodes of a level, dense kernels: "
+              f"{blas + ' (MKL_THREADING_LAYER=' + os.environ.get('MKL_THREADING_LAYER', '?') + ')' if blas else 'built-in loops'}"
+              f"{'' if whole else '; value = sample flop rate / flops of the whole job (the top separators, absent from the sample, run at a higher BLAS-3 rate on a CPU too: read it as a lower bound)'}")
+    out = {"value": (sub[root] / secs) / total, "unit": "factorizations/s", "cores": threads, "kind": "port",
+           "sample": sample, "sample_seconds": secs, "sample_gflops": sub[root] / secs / 1e9,
+           "host_cpus_visible": len(os.sched_getaffinity(0))}
     O.unbind_blas()
-    return out, lo
+    return out
 
 
+def cpu_baseline_ex15(threads: int = 1):
+    """configs[0]: the reference's own CPU-runnable case (ex15-class, 1 thread), as scripts/eval.sh times
+    it: 5 factorizations, the median; _05 executor with every supernode its own w-partition."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as O
+    from parsy_bench_amd import inspector as I, matrices as M
+    O.lib()
+    blas = O.bind_system_blas()
+    A, perm = M.workload("ex15")
+    sym = I.analyze(A, perm)
+    hl = I.trivial_hlevel(sym)
+    O.cholesky_05(sym, sym.A2x, hl, threads=threads)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ok, lo, _ = O.cholesky_05(sym, sym.A2x, hl, threads=threads)
+        ts.append(time.perf_counter() - t0)
+    b = O.rhs_init_blocked(sym, lo)
+    t0 = time.perf_counter()
+    x = O.blocked_lsolve(sym, lo, b, "serial")
+    ts_solve = time.perf_counter() - t0
+    O.unbind_blas()
+    return {"workload": "ex15-class stand-in (83x83 5-point grid, n = 6 889)", "threads": threads,
+            "factorizations_per_sec": 1.0 / float(np.median(ts)), "median_of": 5, "dense_kernels": blas or "built-in loops",
+            "solves_per_sec": 1.0 / ts_solve, "solve_max_abs_err": float(np.abs(x - 1.0).max())}
+
+
+# ---------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="nd24k")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="flan")
     ap.add_argument("--nrhs", type=int, default=1)
-    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--no-extras", action="store_true", help="skip the nd24k / parabolic_fem / ex15 extra objects")
+    ap.add_argument("--no-solve", action="store_true", help="factorizations only (profiling runs)")
+    ap.add_argument("--in-flight", type=int, default=1,
                     help="also time this many independent factorizations in flight (extra field; 1 = skip)")
     args = ap.parse_args()
 
@@ -117,21 +191,70 @@ def main():
 
     from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
 
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, warmup, steps, collective=True):
+        for _ in range(warmup):
+            fn()
+        fence() if collective else torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence() if collective else torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1 and collective:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def measure_solves(plan, sym, L, nrhs, warmup, steps):
+        """b = L 1 (the reference's rhsInitBlocked) repeated nrhs times; forward solves timed like the
+        factorizations; every column must come back as ones."""
+        b = torch.empty(sym.n, dtype=torch.float64, device=dev)
+        plan.rhs_ones_device(L.data_ptr(), b.data_ptr(), stream)
+        B = b.repeat(nrhs).contiguous()
+        X = torch.empty_like(B)
+
+        def solve_step():
+            X.copy_(B)
+            plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+
+        dt = timed(solve_step, warmup, steps, collective=False)
+        err = float((X - 1.0).abs().max().item())
+        if not (err <= SOLVE_TOL):
+            raise SystemExit(f"forward solve of L x = L 1 is off: max|x - 1| = {err:.3e} (nrhs = {nrhs})")
+
+        def bsolve_step():
+            X.copy_(B)
+            plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+
+        dt_b = timed(bsolve_step, warmup, steps, collective=False)
+        return dt, dt_b, err, (B, X)
+
+    # ---- the headline workload -----------------------------------------------------------
     t0 = time.perf_counter()
     A, perm = M.workload(args.workload)
     sym = I.analyze(A, perm)
     t_inspect = time.perf_counter() - t0
+    t0 = time.perf_counter()
     plan = api.Plan(sym, local_rank)
+    t_plan = time.perf_counter() - t0
     info = plan.info
     if rank == 0:
         log(f"[bench] workload={args.workload} n={sym.n} nnz(A)={sym.nnzA} nsuper={sym.nsuper} "
             f"nnz(L)={sym.nnzL} xsize={sym.xsize} F={sym.flops_colcount:.4e} "
-            f"executed={sym.flops_stored:.4e} levels={sym.nlevels} maxw={sym.maxSupWid} "
-            f"launches/factor={info['chol_launches']} inspect={t_inspect:.2f}s")
+            f"executed={sym.flops_stored:.4e} levels={sym.nlevels} (Cholesky view: {info['n_pieces']} pieces, "
+            f"{info['chol_levels']} levels) maxw={sym.maxSupWid} launches/factor={info['chol_launches']} "
+            f"inspect={t_inspect:.2f}s plan={t_plan:.2f}s")
 
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
     L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
 
     cut = None
     plan_root = None
@@ -152,36 +275,14 @@ def main():
             if rank == 0:
                 plan_root.factor_device(values.data_ptr(), L.data_ptr(), stream, init=False)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn, warmup, steps):
-        for _ in range(warmup):
-            fn()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
     # ---- factorizations ------------------------------------------------------------
     dt_f = timed(factor_step, args.warmup, args.steps)
     status = plan.status() if world == 1 else (plan_root.status() if rank == 0 else 0)
     if status != 0:
-        raise SystemExit(f"factorization reported a non-positive pivot at column {status}")
+        raise SystemExit(f"factorization failed: status {status} (> 0: non-positive pivot at that column; "
+                         f"< 0: a hand-off wait inside a launch timed out)")
 
     # ---- two independent factorizations in flight (reported beside `value`, never as `value`) -----
-    # The chain of the top separators leaves most CUs idle; a second plan (own flags, tickets, scratch,
-    # side stream) on a second stream, factoring into its own lValues, fills them.  Same matrix values:
-    # the two factors must be bitwise equal.
     pipelined = None
     if world == 1 and args.in_flight > 1 and int(sym.xsize) * 8 * args.in_flight < 64e9:
         plans2 = [plan] + [api.Plan(sym, local_rank) for _ in range(args.in_flight - 1)]
@@ -203,59 +304,20 @@ def main():
                              "streams; not the headline value (that is one factorization after the other)"}
         del plans2[1:], Ls2[1:]
 
-    # ---- forward solves (rank 0 holds the whole factor) --------------------------------
-    dt_s = None
+    # ---- forward / backward solves (rank 0 holds the whole factor) -------------------------
+    dt_s = dt_b = solve_err = None
     nrhs = args.nrhs
     solve_plan = None
-    if rank == 0:
+    BX = None
+    if rank == 0 and not args.no_solve:
         solve_plan = plan
         if world > 1:
             solve_plan = api.Plan(sym, local_rank)  # all supernodes active
-        ones = torch.ones(sym.n, dtype=torch.float64, device=dev)
-        # b = L * 1 on the stored structure (common/Util.h:277), built with torch plumbing only
-        rows = torch.from_numpy(sym.s.astype(np.int64)).to(dev)
-        w = np.diff(sym.super)
-        r = np.diff(sym.i_ptr[sym.super].astype(np.int64))
-        b = torch.zeros(sym.n, dtype=torch.float64, device=dev)
-        # per supernode: b[rows] += sum over columns of the panel
-        for sn in np.argsort(-w * r)[: sym.nsuper]:
-            c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
-            rs = slice(int(sym.i_ptr[c0]), int(sym.i_ptr[c0]) + int(r[sn]))
-            panel = L[int(sym.p[c0]): int(sym.p[c0]) + int(w[sn] * r[sn])].view(int(w[sn]), int(r[sn]))
-            b.index_add_(0, rows[rs], panel.sum(dim=0))
-        B = b.repeat(nrhs).contiguous()
-        X = torch.empty_like(B)
-
-        def solve_step():
-            X.copy_(B)
-            solve_plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
-
-        for _ in range(args.warmup):
-            solve_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            solve_step()
-        torch.cuda.synchronize()
-        dt_s = time.perf_counter() - t0
-        solve_err = float((X.view(nrhs, sym.n) - ones).abs().max().item())
-        # backward solve L' x = y (extension): timed the same way, reported beside
-        def bsolve_step():
-            X.copy_(B)
-            solve_plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
-
-        for _ in range(args.warmup):
-            bsolve_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            bsolve_step()
-        torch.cuda.synchronize()
-        dt_b = time.perf_counter() - t0
+        dt_s, dt_b, solve_err, BX = measure_solves(solve_plan, sym, L, nrhs, args.warmup, args.steps)
     if world > 1:
         dist.barrier()
 
-    # ---- per-kernel timing (hipEvents on the launch stream) for the roofline ---------
+    # ---- per-kernel timing (hipEvents on the launch stream, launches serialised) for the roofline ----
     prof = None
     if rank == 0 and world == 1 and args.profile_steps > 0:
         plan.profile(2)
@@ -264,13 +326,16 @@ def main():
             torch.cuda.synchronize()
             plan.profile_collect()
         prof_f = plan.profile_get()
-        plan.profile(2)
-        for _ in range(args.profile_steps):
-            X.copy_(B)
-            plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
-            torch.cuda.synchronize()
-            plan.profile_collect()
-        prof_s = plan.profile_get()
+        prof_s = None
+        if BX is not None:
+            B, X = BX
+            plan.profile(2)
+            for _ in range(args.profile_steps):
+                X.copy_(B)
+                plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+                torch.cuda.synchronize()
+                plan.profile_collect()
+            prof_s = plan.profile_get()
         plan.profile(0)
         prof = (prof_f, prof_s)
 
@@ -281,6 +346,7 @@ def main():
 
     ms_per_step = dt_f / args.steps * 1e3
     fact_per_s = args.steps / dt_f
+    grid = M.WORKLOADS.get(args.workload)
     out = {
         "metric": "Cholesky factorizations/sec (+ SpTRSV solves/sec), SuiteSparse SPD set",
         "value": fact_per_s,
@@ -290,16 +356,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if world > 1 else "n/a (one GPU)",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}-class stand-in: grid {M.WORKLOADS[args.workload][:3]} "
-                        f"{M.WORKLOADS[args.workload][3]}-point stencil, geometric nested dissection",
+            "workload": (f"{args.workload}-class stand-in (BASELINE.json configs[2] when flan: Flan_1565): grid "
+                         f"{grid[:3]} {grid[3]}-point stencil, geometric nested dissection" if grid else args.workload),
             "n": sym.n, "nnz_A_lower": int(sym.nnzA), "nsuper": sym.nsuper, "nnz_L": int(sym.nnzL),
             "xsize": int(sym.xsize), "flops_F": sym.flops_colcount, "flops_executed": sym.flops_stored,
-            "etree_levels": sym.nlevels, "launches_per_factorization": info["chol_launches"],
+            "etree_levels": sym.nlevels, "cholesky_view": {k: info[k] for k in (
+                "n_pieces", "chol_levels", "piece_width", "big_min_k", "big_tasks", "big_entries")},
+            "launches_per_factorization": info["chol_launches"],
             "parallelism": "1 GPU" if world == 1 else f"etree subtrees over {world} GPUs + root part on rank 0",
         },
         "gflops_F": sym.flops_colcount / (dt_f / args.steps) / 1e9,
@@ -307,65 +375,132 @@ def main():
         "solve_nrhs": nrhs,
         "solve_ms": (dt_s / args.steps * 1e3) if dt_s else None,
         "solve_max_abs_err_vs_ones": solve_err,
-        "backward_solve_ms": dt_b / args.steps * 1e3,
+        "backward_solve_ms": (dt_b / args.steps * 1e3) if dt_b else None,
         "throughput_in_flight": pipelined,
+        "inspect_seconds": t_inspect, "plan_seconds": t_plan,
     }
 
     if prof is not None:
         pf, ps = prof
         runs = pf["runs"]
-        tile_ms = (pf["ms"]["TILES"] + pf["ms"]["CHAIN"]) / runs
-        tile_launches = (pf["launches"]["TILES"] + pf["launches"]["CHAIN"]) // runs
+        kinds = {k: v / runs for k, v in pf["ms"].items() if v > 0}
+        launches = {k: v // runs for k, v in pf["launches"].items() if v > 0}
+        tile_ms = kinds.get("TILES", 0.0) + kinds.get("CHAIN", 0.0)
         tile_flops = info["tile_update_flops"] + info["inner_flops"]
-        achieved = tile_flops / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0
-        # HBM bytes per launch of the tile kernel from the PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-        # rocprofv3 runs, calibrated on known byte counts in the kernel's access shapes: tools/collect_pmc.sh);
-        # counters cannot be collected inside this run, so the committed summary of the same build is quoted
+        tiles = {"kernel": "tile_task<> (k_chol_tiles + k_chol_chain: per-wave update streams, POTRF/TRSM of the tiles)",
+                 "achieved": tile_flops / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0, "unit": "TFLOP/s",
+                 "algorithmic_flops_per_factorization": tile_flops, "kernel_ms_per_factorization_serialized": tile_ms}
+        tiles["frac"] = tiles["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        big_ms, big_n = kinds.get("BIG", 0.0), launches.get("BIG", 0)
+        if big_ms > 0 and info["big_flops"] >= tile_flops:
+            # dominant kernel: k_chol_big.  Algorithmic flops = the reference's DSYRK + DGEMM counts of the updates
+            # it applies: K n1 (n1 + 1) + 2 K (m - n1) n1 per (target, descendant) pair, exact from the schedule
+            name, dom_ms, dom_n, dom_flops = ("k_chol_big (LDS-staged 128x128 FP64-MFMA update tiles: the reference's "
+                                              "DSYRK/DGEMM of wide descendants and between the pieces of split "
+                                              "supernodes)"), big_ms, big_n, info["big_flops"]
+            key = "k_chol_big"
+        else:
+            name, dom_ms, dom_n, dom_flops, key = tiles["kernel"], tile_ms, launches.get("TILES", 0) + launches.get(
+                "CHAIN", 0), tile_flops, "k_chol_tiles"
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # HBM-side bytes per launch from the PMC passes of the same kernels (rocprofv3 --pmc FETCH_SIZE and
+        # WRITE_SIZE in separate runs, tools/collect_pmc.sh): counters cannot be collected inside this run, so the
+        # committed summary is quoted -- only while the kernel sources are the ones it was measured on
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-            if pmc.get("workload") == args.workload and "k_chol_tiles" in pmc.get("kernels", {}):
-                traffic = pmc["kernels"]["k_chol_tiles"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
+            pmc = json.load(open(ROOT / "profiles" / f"r02_{args.workload}_pmc_traffic.json"))
+            if pmc.get("kernel_source_hash") == kernel_source_hash() and key in pmc.get("kernels", {}):
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/r02_{args.workload}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                               f"separate passes, calibrated; same kernel sources)")
+            elif key in pmc.get("kernels", {}):
+                traffic_src = "profiles summary is from other kernel sources: not quoted"
         except (OSError, ValueError):
             pass
         out["roofline"] = {
-            "kernel": "k_chol_tiles (TILES + CHAIN launches: FP64-MFMA SYRK/GEMM updates, POTRF/TRSM of the tiles)",
-            "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
             "traffic_source": traffic_src,
-            "launches_per_factorization": int(tile_launches),
-            "algorithmic_flops_per_factorization": tile_flops,
-            "avg_launch_ms": tile_ms / max(tile_launches, 1),
-            "kernel_ms_per_factorization": tile_ms,
+            "launches_per_factorization": int(dom_n),
+            "algorithmic_flops_per_launch": dom_flops / max(dom_n, 1),
+            "algorithmic_flops_per_factorization": dom_flops,
+            "avg_launch_ms": dom_ms / max(dom_n, 1),
+            "kernel_ms_per_factorization_serialized": dom_ms,
+            "timing": "hipEvents around every launch on the launch stream, launches serialised on one stream "
+                      "(in the timed steps the side stream overlaps them: the sum over kinds exceeds ms_per_step)",
             "whole_job": {"flops_F": sym.flops_colcount, "achieved": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12,
                           "frac": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
-            "kind_ms_per_factorization": {k: v / runs for k, v in pf["ms"].items() if v > 0},
+            "kind_ms_per_factorization_serialized": kinds,
+            "tile_kernel": tiles,
         }
-        sruns = ps["runs"]
-        solve_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
-        s_ms = sum(ps["ms"].values()) / sruns
-        out["roofline_solve"] = {
-            "bound": "hbm", "achieved": solve_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (solve_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms > 0 else 0.0,
-            "algorithmic_bytes_per_solve": solve_bytes, "traffic": None,
-            "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
-        }
+        if ps is not None:
+            sruns = ps["runs"]
+            solve_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
+            s_ms = sum(ps["ms"].values()) / sruns
+            out["roofline_solve"] = {
+                "bound": "hbm", "achieved": solve_bytes / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (solve_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms > 0 else 0.0,
+                "algorithmic_bytes_per_solve": solve_bytes, "traffic": None,
+                "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
+            }
+
+    # ---- extra objects: the other single-GPU configurations of BASELINE.json (never `value`) ----
+    del plan, solve_plan, BX
+    if world == 1 and not args.no_extras and args.workload == "flan":
+        L_big = L
+        try:
+            extras = {}
+            # configs[1] nd24k-class: factorizations/s + solves/s
+            A1, p1 = M.workload("nd24k")
+            s1 = I.analyze(A1, p1)
+            pl1 = api.Plan(s1, local_rank)
+            v1 = torch.from_numpy(np.ascontiguousarray(s1.A2x)).to(dev)
+            L1 = L_big[: int(s1.xsize)]
+            d1 = timed(lambda: pl1.factor_device(v1.data_ptr(), L1.data_ptr(), stream), 3, 20, collective=False)
+            if pl1.status() != 0:
+                raise RuntimeError(f"nd24k factorization status {pl1.status()}")
+            ds1, db1, e1, _ = measure_solves(pl1, s1, L1, 1, 3, 20)
+            extras["nd24k"] = {"workload": "nd24k-class stand-in (configs[1]): grid (42, 42, 42) 27-point stencil",
+                               "n": s1.n, "flops_F": s1.flops_colcount, "factorizations_per_sec": 20 / d1,
+                               "ms_per_factorization": d1 / 20 * 1e3, "gflops_F": s1.flops_colcount / (d1 / 20) / 1e9,
+                               "solves_per_sec": 20 / ds1, "solve_ms": ds1 / 20 * 1e3,
+                               "backward_solve_ms": db1 / 20 * 1e3, "solve_max_abs_err_vs_ones": e1}
+            del pl1
+            # configs[3] parabolic_fem-class: BCSC lower-triangular solve only, many right-hand sides
+            A3, p3 = M.workload("parabolic_fem")
+            s3 = I.analyze(A3, p3)
+            pl3 = api.Plan(s3, local_rank)
+            v3 = torch.from_numpy(np.ascontiguousarray(s3.A2x)).to(dev)
+            L3 = L_big[: int(s3.xsize)]
+            pl3.factor_device(v3.data_ptr(), L3.data_ptr(), stream)
+            torch.cuda.synchronize()
+            if pl3.status() != 0:
+                raise RuntimeError(f"parabolic_fem factorization status {pl3.status()}")
+            pf3 = {"workload": "parabolic_fem-class stand-in (configs[3]): grid (725, 725) 5-point stencil, solve only",
+                   "n": s3.n, "xsize": int(s3.xsize), "nrhs": {}}
+            for q in (1, 8, 64):
+                dsq, dbq, eq, _ = measure_solves(pl3, s3, L3, q, 2, 10)
+                bytes_q = 8.0 * s3.xsize + 4.0 * s3.ssize + 16.0 * s3.n * q
+                pf3["nrhs"][str(q)] = {"solves_per_sec": 10 * q / dsq, "ms_per_block_solve": dsq / 10 * 1e3,
+                                       "algorithmic_GBps": bytes_q / (dsq / 10) / 1e9,
+                                       "frac_of_hbm_peak": bytes_q / (dsq / 10) / 1e9 / HBM_PEAK_GBS,
+                                       "backward_ms_per_block_solve": dbq / 10 * 1e3, "max_abs_err_vs_ones": eq}
+            extras["parabolic_fem"] = pf3
+            del pl3
+            out["other_configs"] = extras
+        except Exception as e:  # extras never cost the headline
+            out["other_configs"] = {"failed": repr(e)}
 
     if not args.no_cpu_baseline and world == 1:
         try:
             # the GPU box gives one GPU a 16-CPU share (os.cpu_count() reports the whole host)
             share = min(len(os.sched_getaffinity(0)), 16)
-            cb, lo = cpu_baseline(sym, share)
-            out["cpu_baseline"] = cb
-            plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
-            torch.cuda.synchronize()
-            lv = L.cpu().numpy()
-            out["parity"] = {"max_abs_diff_vs_cpu_port_rel": float(np.abs(lv - lo).max() / np.abs(lo).max())}
+            out["cpu_baseline"] = cpu_baseline(sym, share)
+            out["cpu_baseline"]["ex15_1_thread"] = cpu_baseline_ex15(1)
         except Exception as e:  # the baseline is reporting only; never lose the GPU numbers to it
             out["cpu_baseline"] = {"value": None, "unit": "factorizations/s", "cores": 0, "kind": "port",
-                                   "sample": f"failed: {e}"}
+                                   "sample": f"failed: {e!r}"}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

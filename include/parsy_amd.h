@@ -186,6 +186,9 @@ int parsy_solve_device(parsy_plan* plan, const double* d_lValues, double* d_x, i
  * for the permuted system, x = P' L'^-1 L^-1 P b. Asynchronous on `stream`. */
 int parsy_backsolve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs, int ldx,
                            void* stream);
+/* d_b = L * 1 on the stored structure (device pointers, n doubles, overwritten): the right-hand side the
+ * reference's triangularTest solves (rhsInitBlocked, common/Util.h:277-288), so that L x = b has x = 1. */
+int parsy_rhs_ones_device(parsy_plan* plan, const double* d_lValues, double* d_b, void* stream);
 /* Host convenience: forward (if `forward` != 0) then backward solve on host buffers. */
 int parsy_solve2_host(parsy_plan* plan, const double* lValues, double* x, int nrhs, int ldx,
                       int forward, double* seconds);
@@ -206,9 +209,10 @@ double parsy_last_solve_ms(parsy_plan* plan);
  *   parsy_plan_profile(plan, 1) on, (plan, 0) off, (plan, 2) on + reset accumulators.
  *   parsy_plan_profile_collect(plan): after the stream is synchronised, add the
  *     elapsed time of every launch of the last factor/solve to its kernel kind.
- *   parsy_plan_profile_get: accumulated ms and launch counts per kind (8 entries:
- *     0 SMALL, 1 TILES, 2 CHAIN, 3 and 4 unused, 5 SOLVE_SMALL, 6 SOLVE_PANEL,
- *     7 SOLVE_FIXUP; the arrays passed must hold 8 entries) and the number of collected runs. */
+ *   parsy_plan_profile_get: accumulated ms and launch counts per kind (PARSY_PROFILE_KINDS = 10 entries:
+ *     0 SMALL, 1 TILES, 2 CHAIN, 3 BIG, 4 unused, 5 SOLVE_SMALL, 6 SOLVE_PANEL, 7 SOLVE_FIXUP,
+ *     8 BACK_BLOCK, 9 unused; the arrays passed must hold 10 entries) and the number of collected runs. */
+#define PARSY_PROFILE_KINDS 10
 int parsy_plan_profile(parsy_plan* plan, int enable);
 int parsy_plan_profile_collect(parsy_plan* plan);
 int parsy_plan_profile_get(parsy_plan* plan, double* kind_ms, int* kind_launches, int* runs);

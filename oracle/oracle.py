@@ -148,6 +148,37 @@ def cholesky_wavefront(sym, values, threads: int = 1):
     return bool(ok), lValues, timing
 
 
+def cholesky_wavefront_subtree(sym, values, root: int, first: int, threads: int = 1):
+    """The oracle's wavefront executor on ONE etree subtree: supernodes first..root (contiguous, the
+    supernodes are postordered), with level sets restricted to them.  A subtree is a complete
+    factorization of its own columns (a target only reads its descendants, common/Reach.h:122-135), so
+    this is a bounded sample of the whole job with the same mix of small and wide supernodes (bench.py's
+    CPU baseline on inputs whose full CPU factorization takes minutes).  Returns (ok, seconds)."""
+    import time
+    sub = np.arange(first, root + 1)
+    lev = np.zeros(sym.nsuper, dtype=np.int64)
+    for l in range(sym.nlevels):
+        lev[sym.levelSet[sym.levelPtr[l]:sym.levelPtr[l + 1]]] = l
+    order = sub[np.argsort(lev[sub], kind="stable")]
+    nl = int(lev[sub].max()) + 1
+    levelPtr = np.zeros(nl + 1, dtype=np.int32)
+    np.cumsum(np.bincount(lev[sub], minlength=nl), out=levelPtr[1:])
+    w = np.diff(sym.super)[sub]
+    r = np.diff(sym.i_ptr[sym.super].astype(np.int64))[sub]
+    lValues = np.zeros(int(sym.xsize), dtype=np.float64)  # untouched pages are never committed
+    timing = np.zeros(8 + max(threads, 1), dtype=np.float64)
+    vals = np.ascontiguousarray(values, dtype=np.float64)
+    a = [_i32(sym.A2p), _i32(sym.A2i), _sz(sym.p), _i32(sym.s), _sz(sym.i_ptr), _i32(sym.super),
+         _i32(sym.sParent), _i32(sym.A1p), _i32(sym.A1i), _i32(sym.col2Sup), levelPtr, _i32(order)]
+    lib().oracle_set_threads(threads)
+    t0 = time.perf_counter()
+    ok = lib().oracle_cholesky_left_par_waveFront(
+        sym.n, P(a[0]), P(a[1]), P(vals), P(a[2]), P(a[3]), P(a[4]), P(lValues), P(a[5]),
+        sym.nsuper, P(timing), P(a[6]), P(a[7]), P(a[8]), P(a[9]), nl, P(a[10]), P(a[11]),
+        1, threads, int(w.max()) + 1, int(r.max()) + 1)
+    return bool(ok), time.perf_counter() - t0
+
+
 def rhs_init_blocked(sym, lValues):
     b = np.zeros(sym.n, dtype=np.float64)
     a = [_sz(sym.p), _i32(sym.s), _sz(sym.i_ptr), np.ascontiguousarray(lValues)]

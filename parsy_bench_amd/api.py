@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _native as N
 
-KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "--", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP"]
+KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "--", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP", "BACK_BLOCK", "---"]
 
 
 def device_count() -> int:
@@ -220,6 +220,11 @@ class Plan:
         if N.lib().parsy_backsolve_device(self._h, d_lValues, d_x, nrhs, ldx, stream) != 0:
             raise RuntimeError("parsy_backsolve_device failed: " + N.last_error())
 
+    def rhs_ones_device(self, d_lValues: int, d_b: int, stream: int = 0) -> None:
+        """d_b = L * 1 on the stored structure (the reference's rhsInitBlocked, common/Util.h:277)."""
+        if N.lib().parsy_rhs_ones_device(self._h, d_lValues, d_b, stream) != 0:
+            raise RuntimeError("parsy_rhs_ones_device failed: " + N.last_error())
+
     # device-pointer API ---------------------------------------------------------
     def factor_device(self, d_values: int, d_lValues: int, stream: int = 0, init: bool = True) -> None:
         if N.lib().parsy_factor_device_ex(self._h, d_values, d_lValues, stream, 0 if init else 1) != 0:
@@ -243,8 +248,8 @@ class Plan:
             raise RuntimeError("profile_collect: no profiled run to collect")
 
     def profile_get(self) -> dict:
-        ms = np.zeros(8, dtype=np.float64)
-        cnt = np.zeros(8, dtype=np.int32)
+        ms = np.zeros(10, dtype=np.float64)
+        cnt = np.zeros(10, dtype=np.int32)
         runs = C.c_int(0)
         N.lib().parsy_plan_profile_get(self._h, N.ptr(ms), N.ptr(cnt), C.byref(runs))
         return {"runs": runs.value, "ms": dict(zip(KIND_NAMES, ms.tolist())),

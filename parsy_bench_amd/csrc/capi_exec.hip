@@ -371,7 +371,7 @@ int parsy_plan_profile(parsy_plan* pl, int enable) {
     if (!pl) return -1;
     pl->profile = enable != 0;
     if (enable == 2) {  // reset the accumulators
-        for (int k = 0; k < 8; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
+        for (int k = 0; k < 10; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
         pl->profiled_runs = 0;
     }
     return 0;
@@ -381,7 +381,7 @@ int parsy_plan_profile_collect(parsy_plan* pl) { return pl ? parsy::plan_collect
 
 int parsy_plan_profile_get(parsy_plan* pl, double* kind_ms, int* kind_launches, int* runs) {
     if (!pl) return -1;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 10; ++k) {  // PARSY_PROFILE_KINDS entries each
         if (kind_ms) kind_ms[k] = pl->kind_ms[k];
         if (kind_launches) kind_launches[k] = pl->kind_launches[k];
     }
@@ -446,6 +446,18 @@ int parsy_backsolve_device(parsy_plan* pl, const double* d_lValues, double* d_x,
         return -1;
     }
     return parsy::plan_backsolve(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream);
+}
+
+int parsy_rhs_ones_device(parsy_plan* pl, const double* d_lValues, double* d_b, void* stream) {
+    if (!pl || !d_lValues || !d_b || pl->device < 0) {
+        set_last_error("parsy_rhs_ones_device: null argument or plan without a device");
+        return -1;
+    }
+    CAPI_HIP(hipSetDevice(pl->device), -1);
+    CAPI_HIP(hipMemsetAsync(d_b, 0, (size_t)pl->S.n * sizeof(double), (hipStream_t)stream), -1);
+    parsy::launch_rhs_ones(pl->dp, pl->S.nsuper, pl->S.max_rows, d_lValues, d_b, (hipStream_t)stream);
+    CAPI_HIP(hipGetLastError(), -1);
+    return 0;
 }
 
 int parsy_solve2_host(parsy_plan* pl, const double* lValues, double* x, int nrhs, int ldx, int forward,

@@ -57,6 +57,8 @@ void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, cons
                          hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
                          double* xscratch, int nrhs, int ldx, int chain, int epoch0, hipStream_t stream);
+void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
+                     hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

@@ -31,13 +31,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     S.rows.assign(P.s, P.s + P.i_ptr[n]);
     S.ssize = (int64_t)P.i_ptr[n];
     S.xsize = (int64_t)lC[n];
-    // diagnostics: PARSY_BIG_MINK (a huge value switches the BIG launches off), PARSY_PIECE_WIDTH (0: no pieces)
-    S.big_min_k = std::max(16, env_int("PARSY_BIG_MINK", kBigMinK));
-    S.piece_width = env_int("PARSY_PIECE_WIDTH", kPieceWidth);
-    if (S.piece_width > 0) S.piece_width = ceil_div(std::max(S.piece_width, kBigTile), kBigTile) * kBigTile;
-    if (S.piece_width < S.big_min_k) S.piece_width = 0;  // the pieces update each other through the BIG launches
-    S.push_group = std::max(1, env_int("PARSY_PUSH_GROUP", kPushGroup));
-
     // --- supernode descriptors ------------------------------------------------
     S.sn.resize(ns);
     for (int t = 0; t < ns; ++t) {
@@ -110,6 +103,19 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         }
     }
     if (S.relpos.size() > 0x7fffffffULL) throw std::runtime_error("schedule: relative index array exceeds int32");
+
+    // Which form the updates take follows the size of the job (measured on MI355X, 27-point grids with
+    // nested dissection): below about 1e11 update flops a factorization is a chain of latencies and the
+    // wave streams inside the chain launches are the shortest path; above it the LDS-staged BIG launches
+    // win (56^3 grid: 11.8 vs 13.1 ms); cutting the very wide supernodes into pieces pays from about 2e12
+    // (96^3 grid: 163 vs 174 ms).  PARSY_BIG_MINK / PARSY_PIECE_WIDTH override (diagnostics, tests).
+    S.big_min_k = S.update_flops >= kBigAutoFlops ? kBigMinK : INT_MAX;
+    S.piece_width = S.update_flops >= kPieceAutoFlops ? kPieceWidth : 0;
+    if (std::getenv("PARSY_BIG_MINK")) S.big_min_k = std::max(1, env_int("PARSY_BIG_MINK", kBigMinK));
+    if (std::getenv("PARSY_PIECE_WIDTH")) S.piece_width = env_int("PARSY_PIECE_WIDTH", kPieceWidth);
+    if (S.piece_width > 0) S.piece_width = ceil_div(std::max(S.piece_width, kBigTile), kBigTile) * kBigTile;
+    if (S.piece_width < S.big_min_k) S.piece_width = 0;  // the pieces update each other through the BIG launches
+    S.push_group = std::max(1, env_int("PARSY_PUSH_GROUP", kPushGroup));
 
     std::vector<int> tree(P.sparent, P.sparent + ns);
     level_sets(tree, S.levelPtr, S.levelSet);

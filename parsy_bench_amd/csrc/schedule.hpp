@@ -119,6 +119,8 @@ constexpr int kBigTile = 128;             // tile edge of the BIG (LDS-staged GE
 constexpr int kBigMinK = 128;             // updates from descendants at least this wide go through it (PARSY_BIG_MINK)
 constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this are factored as a chain of pieces
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
+constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
+constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 

@@ -663,4 +663,35 @@ void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                        P.solve_fix_list + first, x, xscratch, nrhs, ldx);
 }
 
+// b = L * 1 on the stored structure (the reference's rhsInitBlocked, common/Util.h:277-288: the right-hand
+// side its triangularTest solves, so that x = 1): every stored entry of a panel row is added to b[row].
+// One thread per panel row (lanes along the rows: coalesced column by column), rows of a tall panel
+// spread over gridDim.y workgroups.  b must be zero on entry.
+__global__ __launch_bounds__(kThreads) void k_rhs_ones(const SnDesc* __restrict__ sn,
+                                                       const int32_t* __restrict__ rows,
+                                                       const double* __restrict__ L, double* __restrict__ b) {
+    const SnDesc D = sn[blockIdx.x];
+    const double* __restrict__ G = L + D.px;
+    for (int i = blockIdx.y * kThreads + threadIdx.x; i < D.r; i += gridDim.y * kThreads) {
+        const int cmax = min(D.w, i + 1);  // the diagonal block is lower triangular
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = 0;
+        for (; c + 4 <= cmax; c += 4) {
+            s0 += G[(int64_t)c * D.r + i];
+            s1 += G[(int64_t)(c + 1) * D.r + i];
+            s2 += G[(int64_t)(c + 2) * D.r + i];
+            s3 += G[(int64_t)(c + 3) * D.r + i];
+        }
+        for (; c < cmax; ++c) s0 += G[(int64_t)c * D.r + i];
+        atomicAdd(&b[rows[D.pi + i]], (s0 + s1) + (s2 + s3));
+    }
+}
+
+void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
+                     hipStream_t stream) {
+    if (nsuper <= 0) return;
+    const int ny = std::max(1, std::min(16, (max_rows + kThreads - 1) / kThreads));
+    hipLaunchKernelGGL(k_rhs_ones, dim3(nsuper, ny), dim3(kThreads), 0, stream, P.sn, P.rows, L, b);
+}
+
 }  // namespace parsy
