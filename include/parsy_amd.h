@@ -181,6 +181,11 @@ int parsy_factor_status(parsy_plan* plan);
 int parsy_solve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs,
                        int ldx, void* stream);
 
+/* After the stream has been synchronised: 0 = the last forward / backward solve on this plan completed,
+ * -1 = a hand-off wait inside one of its chain launches timed out (internal error; x is not the solution).
+ * The host conveniences and the drop-in solves check it themselves and fail loudly. */
+int parsy_solve_status(parsy_plan* plan);
+
 /* Backward solve L' X = Y in place (same layout as parsy_solve_device).  Not part of the
  * reference (it only has the forward solve): forward + backward solve A x = b
  * for the permuted system, x = P' L'^-1 L^-1 P b. Asynchronous on `stream`. */

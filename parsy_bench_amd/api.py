@@ -179,6 +179,10 @@ class Plan:
     def status(self) -> int:
         return int(N.lib().parsy_factor_status(self._h))
 
+    def solve_status(self) -> int:
+        """0 = the last solve on this plan completed; -1 = a hand-off wait inside it timed out."""
+        return int(N.lib().parsy_solve_status(self._h))
+
     def solve(self, lValues, b):
         """Forward solve; b is (n,) or (n, nrhs) (any layout); returns x of the same shape."""
         b = np.asarray(b, dtype=np.float64)

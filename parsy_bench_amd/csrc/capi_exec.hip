@@ -117,6 +117,9 @@ parsy_plan* cached_chol_plan(int n, int supNo, const int* blockSet, const size_t
     h = fnv(h, blockSet, sizeof(int) * (supNo + 1));
     h = fnv(h, lR, sizeof(int) * Li_ptr[n]);
     h = fnv(h, c, sizeof(int) * (n + 1));
+    h = fnv(h, r, sizeof(int) * c[n]);            // A's rows and L's row pointers decide where A lands in L
+    h = fnv(h, Li_ptr, sizeof(size_t) * (n + 1));
+    h = fnv(h, lC, sizeof(size_t) * (n + 1));
     h = fnv(h, aTree, sizeof(int) * supNo);
     CacheKey key{blockSet, lR, c, h, n, supNo, 0};
     std::lock_guard<std::mutex> lk(g_mu);
@@ -136,6 +139,9 @@ parsy_plan* cached_chol_plan_prune(int n, int supNo, const int* blockSet, const 
     h = fnv(h, blockSet, sizeof(int) * (supNo + 1));
     h = fnv(h, lR, sizeof(int) * Li_ptr[n]);
     h = fnv(h, c, sizeof(int) * (n + 1));
+    h = fnv(h, r, sizeof(int) * c[n]);
+    h = fnv(h, Li_ptr, sizeof(size_t) * (n + 1));
+    h = fnv(h, lC, sizeof(size_t) * (n + 1));
     h = fnv(h, prunePtr, sizeof(int) * (supNo + 1));
     h = fnv(h, pruneSet, sizeof(int) * prunePtr[supNo]);
     CacheKey key{blockSet, lR, c, h, n, supNo, 2};
@@ -176,6 +182,8 @@ parsy_plan* cached_solve_plan(int n, int supNo, const size_t* Lp, const int* Li,
     uint64_t h = 1469598103934665603ULL;
     h = fnv(h, sup2col, sizeof(int) * (supNo + 1));
     h = fnv(h, Li, sizeof(int) * Li_ptr[n]);
+    h = fnv(h, Li_ptr, sizeof(size_t) * (n + 1));
+    h = fnv(h, Lp, sizeof(size_t) * (n + 1));
     CacheKey key{sup2col, Li, Lp, h, n, supNo, 1};
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_plans.find(key);
@@ -211,6 +219,8 @@ int dropin_solve(const char* who, int n, size_t* Lp, int* Li, double* Lx, size_t
                  int* sup2col, int supNo, double* x) {
     if (!Lp || !Li || !x) return 0;  // reference: Triangular_BCSC.h:24
     parsy_plan* pl = cached_solve_plan(n, supNo, Lp, Li, Li_ptr, sup2col);
+    std::unique_lock<std::mutex> use;
+    if (pl) use = std::unique_lock<std::mutex>(pl->use_mu);
     if (!pl || parsy_solve_host(pl, Lx, x, 1, n, nullptr) != 0) {
         loud(who);
         return 0;
@@ -342,6 +352,14 @@ int parsy_factor_status(parsy_plan* pl) {
     return v >= 0x7f7f7f7f ? 0 : v;  // < 0: an in-launch wait timed out (internal error)
 }
 
+int parsy_solve_status(parsy_plan* pl) {
+    if (!pl || pl->device < 0) return -1;
+    int v = 0;
+    if (hipMemcpy(&v, pl->dp.sinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v < 0) set_last_error("solve: a hand-off wait inside a chain launch timed out; x is not the solution");
+    return v < 0 ? -1 : 0;
+}
+
 int parsy_solve_device(parsy_plan* pl, const double* d_lValues, double* d_x, int nrhs, int ldx,
                        void* stream) {
     if (!pl || !d_lValues || !d_x) {
@@ -434,6 +452,7 @@ int parsy_solve_host(parsy_plan* pl, const double* lValues, double* x, int nrhs,
     CAPI_HIP(hipMemcpy(pl->h_x_dev, x, (size_t)need * 8, hipMemcpyHostToDevice), -1);
     if (parsy::plan_solve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
     CAPI_HIP(hipDeviceSynchronize(), -1);
+    if (parsy_solve_status(pl) != 0) return -1;  // (x stays untouched: it would not be the solution)
     if (seconds) *seconds = parsy_last_solve_ms(pl) * 1e-3;
     CAPI_HIP(hipMemcpy(x, pl->h_x_dev, (size_t)need * 8, hipMemcpyDeviceToHost), -1);
     return 0;
@@ -486,10 +505,12 @@ int parsy_solve2_host(parsy_plan* pl, const double* lValues, double* x, int nrhs
     if (forward) {
         if (parsy::plan_solve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
         CAPI_HIP(hipDeviceSynchronize(), -1);
+        if (parsy_solve_status(pl) != 0) return -1;
         sec += parsy_last_solve_ms(pl) * 1e-3;
     }
     if (parsy::plan_backsolve(pl, pl->h_L_dev, pl->h_x_dev, nrhs, ldx, nullptr) != 0) return -1;
     CAPI_HIP(hipDeviceSynchronize(), -1);
+    if (parsy_solve_status(pl) != 0) return -1;
     sec += parsy_last_solve_ms(pl) * 1e-3;
     if (seconds) *seconds = sec;
     CAPI_HIP(hipMemcpy(x, pl->h_x_dev, (size_t)need * 8, hipMemcpyDeviceToHost), -1);
@@ -518,6 +539,8 @@ bool cholesky_left_par_05(int n, int* c, int* r, double* values, size_t* lC, int
     }
     parsy_plan* pl = cached_chol_plan(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r);
     double dev_s = 0;
+    std::unique_lock<std::mutex> use;
+    if (pl) use = std::unique_lock<std::mutex>(pl->use_mu);
     if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
         loud(who);
         return false;
@@ -550,6 +573,8 @@ bool cholesky_left_par_05_prune(int n, int* c, int* r, double* values, size_t* l
     }
     parsy_plan* pl = cached_chol_plan_prune(n, supNo, blockSet, lC, Li_ptr, lR, prunePtr, pruneSet, c, r);
     double dev_s = 0;
+    std::unique_lock<std::mutex> use;
+    if (pl) use = std::unique_lock<std::mutex>(pl->use_mu);
     if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
         loud(who);
         return false;
@@ -576,6 +601,8 @@ bool cholesky_left_par_waveFront(int n, int* c, int* r, double* values, size_t* 
     }
     parsy_plan* pl = cached_chol_plan(n, supNo, blockSet, lC, Li_ptr, lR, aTree, col2Sup, cT, rT, c, r);
     double dev_s = 0;
+    std::unique_lock<std::mutex> use;
+    if (pl) use = std::unique_lock<std::mutex>(pl->use_mu);
     if (!pl || parsy_factor_host(pl, values, lValues, &dev_s) != 0) {
         loud(who);
         return false;

@@ -1499,6 +1499,13 @@ void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, 
                        P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L);
 }
 
+// Resident workgroups of the chain kernel per CU as the runtime sees them (registers, LDS); 0 on error.
+int chain_workgroups_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chol_chain, kThreads, 0) != hipSuccess) return 0;
+    return nb;
+}
+
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;

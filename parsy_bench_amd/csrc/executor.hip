@@ -51,6 +51,9 @@ int plan_upload_launches(parsy_plan* pl) {
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
         pl->launch_owned.push_back(d);
         pl->dp.tickets = (int*)d;
+        PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_solve_chain_launches, 1) * sizeof(int)));
+        pl->launch_owned.push_back(d);
+        pl->dp.stickets = (int*)d;
     }
     // hipMemcpy from pageable memory returns when the data is staged, hipMemset when it is enqueued:
     // both are only ordered against the NULL stream.  The caller's stream may be a non-blocking one,
@@ -86,6 +89,11 @@ static int plan_upload(parsy_plan* pl) {
         pl->owned.push_back(d);
         pl->dp.info = (int*)d;
         PARSY_HIP(hipMemset(d, 0x7f, sizeof(int)));
+        PARSY_HIP(hipMalloc(&d, sizeof(int)));
+        pl->owned.push_back(d);
+        pl->dp.sinfo = (int*)d;
+        PARSY_HIP(hipMemset(d, 0, sizeof(int)));
+        pl->n_flags = std::max<int64_t>(S.n_dslots, 1);
         const size_t fbytes = std::max<int64_t>(S.n_dslots, 1) * sizeof(int);
         PARSY_HIP(hipMalloc(&d, fbytes));
         pl->owned.push_back(d);
@@ -128,6 +136,11 @@ parsy_plan* plan_build(const PatternRef& P, const size_t* lC, const int* A2p, co
     if (device >= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+        // the schedule sizes its walker batches for 2 resident chain workgroups per CU: if the runtime
+        // admits fewer (another register / LDS budget), count the CUs accordingly
+        (void)hipSetDevice(device);
+        const int per_cu = chain_workgroups_per_cu();
+        if (per_cu == 1) cus = cus / 2;
     }
     try {
         build_schedule(P, lC, A2p, A2i, nullptr, pl->S, cus);
@@ -226,7 +239,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
             case kLaunchSolvePanel:
                 if (l.fused)
                     launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
-                                       pl->epoch, stream);
+                                       pl->epoch, l.jb, pl->solve_wait_bias, stream);
                 else
                     launch_solve_panel(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, stream);
                 break;
@@ -234,12 +247,33 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
             case kLaunchBackBlock:
-                launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, l.fused, pl->epoch, stream);
+                launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, l.fused, pl->epoch,
+                                    l.fused ? l.jb : 0, pl->solve_wait_bias, stream);
                 break;
         }
     }
     profile_mark(pl, -1, stream, cursor);
     if (pl->profile) pl->pev_kind.resize(cursor);
+}
+
+// Start of a forward / backward solve: a fresh epoch range for its passes (flags of earlier solves go
+// stale; on wrap-around the flags are cleared first, so that no old value can pass for a new one), its own
+// status word and ticket counters zeroed.
+static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream) {
+    if (pl->epoch > INT_MAX - 2 * passes - 2) {
+        PARSY_HIP(hipMemsetAsync(pl->dp.flags, 0, (size_t)pl->n_flags * sizeof(int), stream));
+        PARSY_HIP(hipMemsetAsync(pl->dp.tflags, 0, 2 * (size_t)std::max(pl->dp.n_tflags, 1) * sizeof(int), stream));
+        pl->epoch = 0;
+    }
+    pl->epoch += 1;  // first pass uses this value; the kernels add the pass index
+    PARSY_HIP(hipMemsetAsync(pl->dp.sinfo, 0, sizeof(int), stream));
+    PARSY_HIP(hipMemsetAsync(pl->dp.stickets, 0, (size_t)std::max(pl->S.n_solve_chain_launches, 1) * sizeof(int),
+                             stream));
+    // diagnostic: PARSY_DEBUG_SOLVE_STALL=1 makes every waiter of the chain launches wait for an epoch that
+    // is never published -- the timeout path of the hand-offs, exercised by the tests
+    const char* st = std::getenv("PARSY_DEBUG_SOLVE_STALL");
+    pl->solve_wait_bias = (st && st[0] == '1') ? (1 << 20) : 0;
+    return 0;
 }
 
 int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream) {
@@ -254,8 +288,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     const int64_t need = (int64_t)ldx * nrhs;
     // one epoch per pass of right-hand sides (what the chain launches publish / wait for)
     const int passes = (nrhs + 3) / 4;
-    if (pl->epoch > INT_MAX - 2 * passes - 2) pl->epoch = 0;
-    pl->epoch += 1;
+    if (solve_begin(pl, passes, stream) != 0) return -1;
     if (pl->S.max_width > kTile && pl->xscratch_len < need) {
         if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
         pl->xscratch = nullptr;
@@ -297,7 +330,14 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
         return -1;
     }
     const Schedule& S = pl->S;
-    pl->epoch = (pl->epoch == INT_MAX) ? 1 : pl->epoch + 1;  // flags of earlier factorizations go stale
+    // flags of earlier factorizations go stale; on wrap-around they are cleared, so that a value left by an
+    // early factorization cannot pass for a new one
+    if (pl->epoch >= INT_MAX - 4) {
+        PARSY_HIP(hipMemsetAsync(pl->dp.flags, 0, (size_t)pl->n_flags * sizeof(int), stream));
+        PARSY_HIP(hipMemsetAsync(pl->dp.tflags, 0, 2 * (size_t)std::max(pl->dp.n_tflags, 1) * sizeof(int), stream));
+        pl->epoch = 0;
+    }
+    pl->epoch += 1;
     PARSY_HIP(hipEventRecord(pl->ev_f0, stream));
     if (init) PARSY_HIP(hipMemsetAsync(d_L, 0, (size_t)S.xsize * sizeof(double), stream));
     // "no failed pivot" = 0x7f7f7f7f (kernels atomicMin the 1-based failing column into it)
@@ -325,8 +365,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     const int64_t need = (int64_t)ldx * nrhs;
     // one epoch per pass of right-hand sides (what the chain kernel publishes / waits for)
     const int passes = (nrhs + 7) / 8;
-    if (pl->epoch > INT_MAX - 2 * passes - 2) pl->epoch = 0;
-    pl->epoch += 1;  // first pass uses this value; the kernel adds the pass index
+    if (solve_begin(pl, passes, stream) != 0) return -1;
     if (pl->S.n_solve_wide > 0 && pl->xscratch_len < need) {
         // grows only when a larger right-hand-side block shows up (not per call)
         if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));

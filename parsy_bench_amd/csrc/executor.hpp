@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -12,6 +13,8 @@
 struct parsy_plan {
     parsy::Schedule S;
     int device = -1;          // < 0: host schedule only
+    std::mutex use_mu;        // the drop-in operators hold it across a call: flags, tickets, status and the
+                              // host-convenience buffers of a cached plan belong to one call at a time
     bool solve_only = false;  // built from L's pattern alone (no A, no update lists)
 
     // pattern arrays (uploaded once) and launch arrays (re-uploaded by set_active)
@@ -20,6 +23,8 @@ struct parsy_plan {
     parsy::DevicePattern dp;
     int64_t device_bytes = 0;
     int epoch = 0;            // factorization counter (value the chain launches publish / wait for)
+    int64_t n_flags = 1;      // entries of dp.flags
+    int solve_wait_bias = 0;  // diagnostic (PARSY_DEBUG_SOLVE_STALL): added to the epoch the solve's waiters wait for
 
     double* dinv = nullptr;       // inverse 64x64 diagonal blocks of the wide supernodes (solve)
     double* xscratch = nullptr;

@@ -35,6 +35,9 @@ struct DevicePattern {           // device copies of Schedule arrays
                                  // ([0, n_tflags): finished tiles, [n_tflags, 2 n_tflags): tiles prepared for the walker)
     int n_tflags = 0;
     int* tickets = nullptr;      // one counter per CHAIN launch (zeroed at the start of a factorization)
+    int* sinfo = nullptr;        // status of the last solve: 0 ok, < 0 a hand-off wait timed out (own word: a solve
+                                 // never touches the factorization's status)
+    int* stickets = nullptr;     // one counter per chain launch of the forward / backward solve
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -44,6 +47,7 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
                        hipStream_t stream);
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream);
 
@@ -52,11 +56,13 @@ void launch_solve_small(const DevicePattern& P, int first, int count, const doub
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream);
+                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
+                        hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
                          hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, hipStream_t stream);
+                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, int ticket, int wait_bias,
+                         hipStream_t stream);
 void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
                      hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,

@@ -405,7 +405,9 @@ void build_launches(Schedule& S, const uint8_t* active) {
     // launches): the path taken when a chain launch would not be resident.  Used by the tests.
     const char* fu = std::getenv("PARSY_FORCE_UNFUSED");
     const bool force_unfused = fu && fu[0] == '1';
-    const int max_chain = force_unfused ? -1 : kMaxChainWorkgroups;
+    // chain launches take their work by ticket (producers first): any number of workgroups is fine
+    const int max_chain = force_unfused ? -1 : INT_MAX;
+    S.n_solve_chain_launches = 0;
     S.active.assign(ns, 1);
     if (active) S.active.assign(active, active + ns);
     S.small_list.clear();
@@ -581,7 +583,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             for (int t : sbigs) chain_wgs += ceil_div(S.sn[t].r, kSolveRows);
             if (chain_wgs <= max_chain) {
                 // one launch: every 256-row chunk of every wide supernode of the level
-                Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, 0, 0, 1, 0, -1, 0};
+                Launch Lc{kLaunchSolvePanel, (int32_t)S.solve_panels.size(), 0, lev, S.n_solve_chain_launches++, 0, 1, 0, -1, 0};
                 for (int t : sbigs)
                     for (int c = 0; c * kSolveRows < S.sn[t].r; ++c)
                         S.solve_panels.push_back(PanelDesc{t, c, c * kSolveRows, 0});
@@ -628,7 +630,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (nbc > 1) wide_blocks += nbc;
         }
         if (wide_blocks > 0 && wide_blocks <= max_chain) {
-            Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 1, 0, -1, 0};
+            Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, S.n_solve_chain_launches++, 0, 1, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 const int nbc = ceil_div(S.sn[t].w, kTile);

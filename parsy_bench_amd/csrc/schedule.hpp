@@ -122,7 +122,6 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
-constexpr int kMaxChainWorkgroups = 512;  // SOLVE_CHAIN: every workgroup of the launch must be resident
 
 struct Schedule {
     int n = 0, nsuper = 0, nlevels = 0;
@@ -133,6 +132,7 @@ struct Schedule {
     int64_t n_dslots = 0;          // block columns of the tiled supernodes (64*64 doubles of scratch each)
     int64_t n_tflags = 0;          // tiles of the tiled supernodes (one publication flag each)
     int n_chain_launches = 0;      // CHAIN launches (one ticket counter each)
+    int n_solve_chain_launches = 0;  // chain launches of the forward and backward solve (one ticket counter each)
     int walker_batch = kWalkerBatch;  // walkers interleaved per batch: at most a quarter of the resident workgroups
                                       // (2 per CU), so that a small partition of the GPU cannot fill up with walkers
     double flops_stored = 0, update_flops = 0, reread_bytes = 0;

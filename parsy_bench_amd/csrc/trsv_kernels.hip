@@ -13,6 +13,7 @@
 namespace parsy {
 
 static constexpr int kThreads = 256;
+static constexpr unsigned long long kSolveSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock (as the factorization's waits)
 static constexpr int kLdDiag = kTile + 1;
 static constexpr int kRhs = 8;  // right-hand sides carried per pass over a panel
 
@@ -292,13 +293,19 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
                                                           double* __restrict__ x,
                                                           double* __restrict__ xscratch, int nrhs,
                                                           int ldx, int* __restrict__ flags, int epoch0,
-                                                          int* __restrict__ info) {
+                                                          int* __restrict__ info, int* __restrict__ ticket,
+                                                          int wait_bias) {
     __shared__ double Di[2][kTile * kLdDiag];  // inverse diagonal blocks, double buffered
     __shared__ double xs[kTile][NQ];
     __shared__ double ts[kTile][NQ];
-    __shared__ int32_t s_ok;
+    __shared__ int32_t s_ok, s_task;
     const int tid = threadIdx.x;
-    const PanelDesc pd = pds[blockIdx.x];
+    // chunks are listed producers first (the owner of a block column before the chunks below it) and a
+    // workgroup takes its chunk from a ticket counter when it starts: whatever it waits for belongs to a
+    // workgroup that has already started -- no assumption on residency or dispatch order
+    if (tid == 0) s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    const PanelDesc pd = pds[s_task];
     const SnDesc D = sn[pd.sn];
     const int r = D.r, w = D.w, chunk = pd.jb, row0 = pd.row0;
     const int nbc = (w + kTile - 1) / kTile;
@@ -384,9 +391,14 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
                 if (tid == 0) {
                     const unsigned long long t0 = wall_clock64();
                     int ok = 1;
-                    // epochs only grow: a later pass of this solve may already have raised the flag
-                    while (__hip_atomic_load(&flags[D.dslot + jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
-                        if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
+                    // epochs only grow: a later pass of this solve may already have raised the flag.  The wait is
+                    // bounded and watches the solve's status word: one timeout ends every wait of the solve
+                    int spins = 0;
+                    while (__hip_atomic_load(&flags[D.dslot + jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                               (epoch + wait_bias) < 0) {
+                        if ((++spins & 15) == 0 &&
+                            (wall_clock64() - t0 > kSolveSpinTicks ||
+                             __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
                             ok = 0;
                             break;
                         }
@@ -425,15 +437,17 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
 }
 
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, hipStream_t stream) {
+                        double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
+                        hipStream_t stream) {
     if (count <= 0) return;
     if (nrhs == 1)
         hipLaunchKernelGGL(k_solve_chain<1>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
-                           P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.info);
+                           P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.sinfo, P.stickets + ticket,
+                           wait_bias);
     else
         hipLaunchKernelGGL(k_solve_chain<kRhs>, dim3(count), dim3(kThreads), 0, stream, P.sn,
                            P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0,
-                           P.info);
+                           P.sinfo, P.stickets + ticket, wait_bias);
 }
 
 // ---------------------------------------------------------------------------
@@ -451,16 +465,20 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            const double* __restrict__ L,
                                                            double* __restrict__ x, double* __restrict__ xscratch,
                                                            int nrhs, int ldx, int chain, int* __restrict__ flags,
-                                                           int epoch0, int* __restrict__ info) {
+                                                           int epoch0, int* __restrict__ info,
+                                                           int* __restrict__ ticket, int wait_bias) {
     // chain != 0: every block column of the wide supernodes of a level is in this launch (all
     // resident); block jb takes the x of blocks jb+1.. of its supernode as they are published
     // (xscratch, 8-byte agent-scope atomics both sides + a flag per block and pass).
     __shared__ double Dg[kTile * kLdDiag];
     __shared__ double invd[kTile];
     __shared__ double ts[kTile][NQ];
-    __shared__ int s_ok;
+    __shared__ int s_ok, s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const PanelDesc pd = pds[blockIdx.x];
+    // chain launch: blocks are listed last block column first (producers first) and taken by ticket
+    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)blockIdx.x;
+    __syncthreads();
+    const PanelDesc pd = pds[s_task];
     const SnDesc D = sn[pd.sn];
     const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
     const double* __restrict__ G = L + D.px;
@@ -551,9 +569,14 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                     }
                     const unsigned long long t0 = wall_clock64();
                     bool ok = true;
-                    // epochs only grow: a later pass may already have raised the flag
-                    while (__hip_atomic_load(&flags[D.dslot + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
-                        if (wall_clock64() - t0 > 20000000ull) {  // 0.2 s at 100 MHz: give up, report
+                    // epochs only grow: a later pass may already have raised the flag; bounded, and one
+                    // timeout (status word) ends every wait of the solve
+                    int spins = 0;
+                    while (__hip_atomic_load(&flags[D.dslot + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                               (epoch + wait_bias) < 0) {
+                        if ((++spins & 15) == 0 &&
+                            (wall_clock64() - t0 > kSolveSpinTicks ||
+                             __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
                             ok = false;
                             break;
                         }
@@ -632,16 +655,17 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
 }
 
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, hipStream_t stream) {
+                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, int ticket, int wait_bias,
+                         hipStream_t stream) {
     if (count <= 0) return;
     if (nrhs == 1)
         hipLaunchKernelGGL(k_bsolve_block<1>, dim3(count), dim3(kThreads), 0, stream, P.sn,
                            P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.info);
+                           P.sinfo, P.stickets + ticket, wait_bias);
     else
         hipLaunchKernelGGL(k_bsolve_block<4>, dim3(count), dim3(kThreads), 0, stream, P.sn,
                            P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.info);
+                           P.sinfo, P.stickets + ticket, wait_bias);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.

@@ -522,3 +522,38 @@ def test_factor_with_pieces_and_big_launches(api, oracle, monkeypatch, name, pie
     tot = info["big_flops"] + info["tile_update_flops"] + info["inner_flops"]
     tot_ref = ref["big_flops"] + ref["tile_update_flops"] + ref["inner_flops"]
     assert tot <= tot_ref * (1 + 1e-12) + 1 and info["update_flops"] == ref["update_flops"]
+
+
+# ---------------------------------------------------------------------------
+# a hand-off wait of the solve's chain launches that times out is REPORTED: own status word, host
+# conveniences and drop-in solves fail, the factorization's status is untouched
+# ---------------------------------------------------------------------------
+def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypatch):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("lap30")   # has supernodes wider than a tile: chain launches in both solves
+    plan = api.Plan(sym, 0)
+    assert plan.info["max_width"] > 64
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    b = oracle.rhs_init_blocked(sym, lv)
+    x, _ = plan.solve(lv, b)
+    assert plan.solve_status() == 0 and np.abs(x - 1.0).max() < 1e-9
+    monkeypatch.setenv("PARSY_DEBUG_SOLVE_STALL", "1")   # waiters wait for an epoch nobody publishes
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve(lv, b)
+    assert plan.solve_status() == -1
+    assert plan.status() == 0                               # the factorization's status word is its own
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve2(lv, b, forward=False)
+    # the drop-in operator returns 0 (the reference's failure value) instead of a wrong x
+    xs = b.copy()
+    rc = api.leveledBlockedLsolve(sym.n, sym.p, sym.s, lv, int(sym.xsize), sym.i_ptr, sym.col2Sup, sym.super,
+                                  sym.nsuper, xs, sym.nlevels, sym.levelPtr, sym.levelSet, 1)
+    assert rc == 0 and np.array_equal(xs, b)
+    monkeypatch.delenv("PARSY_DEBUG_SOLVE_STALL")
+    x2, _ = plan.solve(lv, b)                               # the next solve starts clean
+    assert plan.solve_status() == 0 and np.abs(x2 - 1.0).max() < 1e-9
+    rc = api.leveledBlockedLsolve(sym.n, sym.p, sym.s, lv, int(sym.xsize), sym.i_ptr, sym.col2Sup, sym.super,
+                                  sym.nsuper, xs, sym.nlevels, sym.levelPtr, sym.levelSet, 1)
+    assert rc == 1 and np.abs(xs - 1.0).max() < 1e-9
+    api.dropin_reset()
