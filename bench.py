@@ -258,20 +258,24 @@ def main():
 
     cut = None
     plan_root = None
+    px = None
     if world > 1:
         cut = MG.cut_subtrees(sym, world)
+        px = MG.PackedExchange(sym, cut)
         plan.set_active(cut.mask(rank))
         if rank == 0:
             plan_root = api.Plan(sym, local_rank)
             plan_root.set_active(cut.root_mask())
             log(f"[bench] subtree cut: {len(cut.subtrees)} subtrees, {len(cut.root_nodes)} root-part "
                 f"supernodes, rank cost share {np.round(cut.rank_cost / cut.cost.sum(), 3).tolist()}, "
-                f"root share {cut.cost[cut.root_nodes].sum() / cut.cost.sum():.3f}")
+                f"root share {cut.cost[cut.root_nodes].sum() / cut.cost.sum():.3f}; exchange "
+                f"{px.packed_elements * 8 / 1e9:.2f} GB packed of {px.full_elements * 8 / 1e9:.2f} GB of panels")
 
     def factor_step():
         plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
         if world > 1:
-            MG.gather_to_root(L, cut, sym, rank, dist, stage_on_host=(backend != "nccl"))
+            # the ONE exchange step: the panel rows the root part reads, packed, point to point onto rank 0
+            px.run(L, rank, dist, stream, stage_on_host=(backend != "nccl"))
             if rank == 0:
                 plan_root.factor_device(values.data_ptr(), L.data_ptr(), stream, init=False)
 
@@ -304,6 +308,10 @@ def main():
                              "streams; not the headline value (that is one factorization after the other)"}
         del plans2[1:], Ls2[1:]
 
+    # after the timed factorizations the factor is distributed (subtree panels on their owners, root part on
+    # rank 0): collect the rest on rank 0 for the single-GPU solves below (not timed: not part of a factorization)
+    if world > 1:
+        MG.gather_to_root(L, cut, sym, rank, dist, stage_on_host=(backend != "nccl"))
     # ---- forward / backward solves (rank 0 holds the whole factor) -------------------------
     dt_s = dt_b = solve_err = None
     nrhs = args.nrhs
@@ -368,7 +376,8 @@ def main():
             "etree_levels": sym.nlevels, "cholesky_view": {k: info[k] for k in (
                 "n_pieces", "chol_levels", "piece_width", "big_min_k", "big_tasks", "big_entries")},
             "launches_per_factorization": info["chol_launches"],
-            "parallelism": "1 GPU" if world == 1 else f"etree subtrees over {world} GPUs + root part on rank 0",
+            "parallelism": "1 GPU" if world == 1 else (f"etree subtrees over {world} GPUs, one packed point-to-point "
+                                                       f"exchange of the rows the root part reads, root part on rank 0"),
         },
         "gflops_F": sym.flops_colcount / (dt_f / args.steps) / 1e9,
         "solves_per_sec": (args.steps * nrhs / dt_s) if dt_s else None,

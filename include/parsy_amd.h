@@ -194,6 +194,11 @@ int parsy_backsolve_device(parsy_plan* plan, const double* d_lValues, double* d_
 /* d_b = L * 1 on the stored structure (device pointers, n doubles, overwritten): the right-hand side the
  * reference's triangularTest solves (rhsInitBlocked, common/Util.h:277-288), so that L x = b has x = 1. */
 int parsy_rhs_ones_device(parsy_plan* plan, const double* d_lValues, double* d_b, void* stream);
+/* Device helper of the multi-GPU exchange: d_dst[dst_off[q] + i] = d_src[src_off[q] + i], i < len[q], for nseg
+ * contiguous runs (all pointers device pointers).  Packs the panel rows of a subtree that the root part
+ * reads into one send buffer, and unpacks them on the receiving rank. Asynchronous on `stream`. */
+int parsy_copy_segments_device(double* d_dst, const double* d_src, const int64_t* d_dst_off,
+                               const int64_t* d_src_off, const int32_t* d_len, int64_t nseg, void* stream);
 /* Host convenience: forward (if `forward` != 0) then backward solve on host buffers. */
 int parsy_solve2_host(parsy_plan* plan, const double* lValues, double* x, int nrhs, int ldx,
                       int forward, double* seconds);

@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
     "parsy_grid_nested_dissection", "parsy_order_nd", "parsy_plan_profile", "parsy_plan_profile_collect",
     "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve2_host",
-    "parsy_rhs_ones_device", "parsy_solve_status",
+    "parsy_rhs_ones_device", "parsy_solve_status", "parsy_copy_segments_device",
 ]
 
 
@@ -102,6 +102,7 @@ def _declare(lib):
     lib.parsy_solve2_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.parsy_rhs_ones_device.argtypes = [vp, vp, vp, vp]
     lib.parsy_solve_status.argtypes = [vp]
+    lib.parsy_copy_segments_device.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp]
     lib.parsy_factor_host.argtypes = [vp, vp, vp, vp]
     lib.parsy_solve_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.parsy_last_factor_ms.restype = C.c_double

@@ -95,13 +95,14 @@ DRIVERS = PKG / "drivers"
 
 
 def build_drivers(hipcc=None, run=None, force: bool = False):
-    """choleskyTest / triangularTest: the reference's example drivers over the C ABI; makingLowerHalf."""
+    """choleskyTest / choleskyTest03 / triangularTest: the reference's example drivers over the C ABI;
+    makingLowerHalf."""
     hipcc = hipcc or _hipcc()
     if run is None:
         def run(cmd):
             subprocess.run(cmd, check=True)
     outs = []
-    for name in ("choleskyTest", "triangularTest"):
+    for name in ("choleskyTest", "choleskyTest03", "triangularTest"):
         src, out = DRIVERS / f"{name}.cpp", DRIVERS / f"{name}.bin"
         if force or _stale(out, [src, DRIVERS / "mtx_io.hpp", LIB, PKG.parent / "include" / "parsy_amd.h"]):
             run([hipcc, "-x", "c++", "-O2", "-std=c++17", str(src), "-x", "none", "-o", str(out), str(LIB),

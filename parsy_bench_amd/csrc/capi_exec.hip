@@ -467,6 +467,17 @@ int parsy_backsolve_device(parsy_plan* pl, const double* d_lValues, double* d_x,
     return parsy::plan_backsolve(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream);
 }
 
+int parsy_copy_segments_device(double* d_dst, const double* d_src, const int64_t* d_dst_off,
+                               const int64_t* d_src_off, const int32_t* d_len, int64_t nseg, void* stream) {
+    if (nseg < 0 || (nseg > 0 && (!d_dst || !d_src || !d_dst_off || !d_src_off || !d_len))) {
+        set_last_error("parsy_copy_segments_device: null argument");
+        return -1;
+    }
+    parsy::launch_copy_segments(d_dst, d_src, d_dst_off, d_src_off, d_len, nseg, (hipStream_t)stream);
+    CAPI_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
 int parsy_rhs_ones_device(parsy_plan* pl, const double* d_lValues, double* d_b, void* stream) {
     if (!pl || !d_lValues || !d_b || pl->device < 0) {
         set_last_error("parsy_rhs_ones_device: null argument or plan without a device");

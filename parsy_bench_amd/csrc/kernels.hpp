@@ -65,6 +65,8 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
                          hipStream_t stream);
 void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
                      hipStream_t stream);
+void launch_copy_segments(double* dst, const double* src, const int64_t* dst_off, const int64_t* src_off,
+                          const int32_t* len, int64_t nseg, hipStream_t stream);
 void launch_solve_fixup(const DevicePattern& P, int first, int count, double* x,
                         const double* xscratch, int nrhs, int ldx, hipStream_t stream);
 

@@ -718,4 +718,26 @@ void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const dou
     hipLaunchKernelGGL(k_rhs_ones, dim3(nsuper, ny), dim3(kThreads), 0, stream, P.sn, P.rows, L, b);
 }
 
+// Copy contiguous runs of doubles between two device buffers: dst[dst_off[q] + i] = src[src_off[q] + i],
+// i < len[q].  The multi-GPU exchange packs with it the rows of a subtree's panels that the root part
+// reads (the tail of every panel column) and unpacks them on the receiving rank.
+__global__ __launch_bounds__(64) void k_copy_segments(double* __restrict__ dst, const double* __restrict__ src,
+                                                      const int64_t* __restrict__ dst_off,
+                                                      const int64_t* __restrict__ src_off,
+                                                      const int32_t* __restrict__ len, int64_t nseg) {
+    for (int64_t q = blockIdx.x; q < nseg; q += gridDim.x) {
+        const double* __restrict__ s = src + src_off[q];
+        double* __restrict__ d = dst + dst_off[q];
+        const int n = len[q];
+        for (int i = threadIdx.x; i < n; i += 64) d[i] = s[i];
+    }
+}
+
+void launch_copy_segments(double* dst, const double* src, const int64_t* dst_off, const int64_t* src_off,
+                          const int32_t* len, int64_t nseg, hipStream_t stream) {
+    if (nseg <= 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(nseg, 1 << 20);
+    hipLaunchKernelGGL(k_copy_segments, dim3(grid), dim3(64), 0, stream, dst, src, dst_off, src_off, len, nseg);
+}
+
 }  // namespace parsy

@@ -121,3 +121,101 @@ def gather_to_root(lvalues, cut: SubtreeCut, sym, rank: int, dist, root: int = 0
     for view, buf in landing:
         view.copy_(buf)
     return sum(stop - start for owner, start, stop in cut.slices(sym) if owner != root)
+
+
+class PackedExchange:
+    """The exchange step with only what the root part reads.
+
+    A root-part target reads, from a supernode d of a subtree, the rows of d that lie in the target's
+    columns and below (parallel_PB_Cholesky_05.h:137-149: rows lb..end of the descendant's panel).
+    Every root-part column comes after the subtree's last column (postorder), and a panel's rows are
+    sorted, so what can ever be read of d is the TAIL of each of its panel columns: rows with index >=
+    first column after the subtree.  Those tails -- one contiguous run per panel column -- are packed
+    into one send buffer per subtree, travel point to point, and are unpacked into the same positions of
+    the root rank's lValues.  The panels' upper parts stay with their owners (the factor is then
+    distributed: subtree panels on the owners, root part on the root rank; `gather_to_root` collects
+    it where one rank needs all of it, e.g. for a single-GPU solve).
+    """
+
+    def __init__(self, sym, cut: SubtreeCut, root: int = 0):
+        self.root = root
+        self.items = []  # per subtree: (owner, src_off int64[], len int32[], packed_off int64[], total)
+        w = np.diff(sym.super).astype(np.int64)
+        r = np.diff(sym.i_ptr[sym.super].astype(np.int64))
+        pi = sym.i_ptr[sym.super[:-1]].astype(np.int64)
+        p = sym.p.astype(np.int64)
+        self.full_elements = 0
+        self.packed_elements = 0
+        for first, last, owner, _ in cut.subtrees:
+            limit = int(sym.super[last + 1])
+            src, ln = [], []
+            for d in range(first, last + 1):
+                rows = sym.s[pi[d]: pi[d] + r[d]]
+                lb = int(np.searchsorted(rows, limit))
+                if lb >= r[d]:
+                    continue
+                c0 = int(sym.super[d])
+                src.append(p[c0: c0 + w[d]] + lb)
+                ln.append(np.full(int(w[d]), r[d] - lb, dtype=np.int32))
+            src = np.concatenate(src) if src else np.zeros(0, np.int64)
+            ln = np.concatenate(ln) if ln else np.zeros(0, np.int32)
+            off = np.zeros(len(ln), dtype=np.int64)
+            if len(ln):
+                np.cumsum(ln[:-1], out=off[1:])
+            total = int(ln.sum())
+            self.items.append((int(owner), src, ln, off, total))
+            if owner != root:
+                self.full_elements += int(p[sym.super[last + 1]] - p[sym.super[first]])
+                self.packed_elements += total
+        self._dev = {}   # device copies of the segment arrays, per item
+        self._buf = {}
+
+    def _segments(self, k, like):
+        """Segment arrays of item k on the device of tensor `like` (uploaded once)."""
+        import torch
+        if k not in self._dev:
+            _, src, ln, off, _ = self.items[k]
+            self._dev[k] = tuple(torch.from_numpy(a).to(like.device) for a in (src, ln, off))
+        return self._dev[k]
+
+    def _copy(self, dst, src, dst_off, src_off, ln, k, stream):
+        """dst[dst_off[q] + i] = src[src_off[q] + i]: HIP kernel on the device, numpy on host tensors."""
+        if dst.is_cuda:
+            from . import _native as N
+            s_src, s_len, s_off = self._segments(k, dst)
+            a_dst, a_src = (s_off, s_src) if dst_off is self.items[k][3] else (s_src, s_off)
+            if N.lib().parsy_copy_segments_device(dst.data_ptr(), src.data_ptr(), a_dst.data_ptr(), a_src.data_ptr(),
+                                                  s_len.data_ptr(), len(ln), stream) != 0:
+                raise RuntimeError("parsy_copy_segments_device failed: " + N.last_error())
+            return
+        d, s = dst.numpy(), src.numpy()
+        for q in range(len(ln)):
+            d[dst_off[q]: dst_off[q] + ln[q]] = s[src_off[q]: src_off[q] + ln[q]]
+
+    def run(self, lvalues, rank: int, dist, stream: int = 0, stage_on_host: bool = False):
+        """pack (owners) -> point-to-point -> unpack (root).  `lvalues`: 1-D torch tensor of xsize doubles.
+        The caller's stream must be the current torch stream (the send / receive are ordered on it)."""
+        import torch
+        ops, landing = [], []
+        for k, (owner, src, ln, off, total) in enumerate(self.items):
+            if owner == self.root or total == 0 or rank not in (owner, self.root):
+                continue
+            if k not in self._buf or self._buf[k].device != lvalues.device:
+                self._buf[k] = torch.empty(total, dtype=torch.float64, device=lvalues.device)
+            buf = self._buf[k]
+            if rank == owner:
+                self._copy(buf, lvalues, off, src, ln, k, stream)
+                ops.append(dist.P2POp(dist.isend, buf.cpu() if stage_on_host else buf, self.root))
+            else:
+                host = torch.empty(total, dtype=torch.float64) if stage_on_host else None
+                ops.append(dist.P2POp(dist.irecv, host if stage_on_host else buf, owner))
+                landing.append((k, host))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for k, host in landing:
+            _, src, ln, off, _ = self.items[k]
+            if host is not None:
+                self._buf[k].copy_(host)
+            self._copy(lvalues, self._buf[k], src, off, ln, k, stream)
+        return self.packed_elements

@@ -19,7 +19,7 @@ def _inputs(tmp_path, name="small3d"):
 def test_drivers_are_built_and_usage_is_reported():
     from parsy_bench_amd.build import build_native
     build_native()
-    for exe in ("choleskyTest.bin", "triangularTest.bin"):
+    for exe in ("choleskyTest.bin", "choleskyTest03.bin", "triangularTest.bin"):
         r = subprocess.run([str(DRV / exe)], capture_output=True, text=True)
         assert r.returncode != 0 and "input args are missing" in r.stdout
 
@@ -43,6 +43,22 @@ def test_choleskyTest_csv(tmp_path):
     total, par, root, symbolic, ordering = (float(v) for v in fields[7:12])
     assert total > 0 and par > 0 and root == 0 and symbolic > 0
     assert fields[12] == ""  # the reference's line ends with a comma
+
+
+@pytest.mark.gpu
+def test_choleskyTest03_csv(tmp_path):
+    """The wavefront driver (examples/choleskyTest03.cpp): nrelax = {4,16,0}, getLevelSet schedule,
+    cholesky_left_par_waveFront, sorted median; CSV = file, 6 echoed arguments, total, symbolic, ordering."""
+    mtx, order = _inputs(tmp_path)
+    r = subprocess.run([str(DRV / "choleskyTest03.bin"), mtx, "4", "1", "4", "0", "1", "2", order],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == mtx and fields[1:7] == ["4", "1", "4", "0", "1", "2"]
+    total, symbolic, ordering = (float(v) for v in fields[7:10])
+    assert total > 0 and symbolic > 0 and ordering >= 0
+    assert fields[10] == "" and len(fields) == 11  # the reference's line ends with a comma
+    assert "levels=" in r.stderr
 
 
 @pytest.mark.gpu

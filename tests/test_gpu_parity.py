@@ -276,38 +276,61 @@ def test_new_values_same_pattern(api, oracle):
 # ---------------------------------------------------------------------------
 # subtree shards on one device (what two ranks do, minus the wire)
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_sharded_factorization_on_one_device(api, oracle, nranks):
+@pytest.mark.parametrize("name,nranks", [("lap30", 2), ("lap30", 4), ("flan", 8)])
+def test_sharded_factorization_on_one_device(api, oracle, name, nranks):
+    """What N ranks do, minus the wire: every "rank" factors its subtrees into its own buffer, the rows the
+    root part reads are packed (multigpu.PackedExchange's segments, the library's copy kernel) and unpacked
+    into rank 0's buffer, rank 0 factors the root part.  The root-part panels must equal the unsharded
+    factorization bit for bit -- also for the Flan-class input (BASELINE configs[4]'s cut over 8 ranks;
+    BIG launches and pieces active), which is too large for the CPU checker."""
     import torch
-    from parsy_bench_amd import inspector as I, multigpu as MG
-    A, perm, sym = problem("lap30")
+    from parsy_bench_amd import inspector as I, matrices as M, multigpu as MG
+    if name == "flan":
+        A, perm = M.workload(name)
+        sym = I.analyze(A, perm)
+    else:
+        A, perm, sym = problem(name)
     cut = MG.cut_subtrees(sym, nranks)
+    px = MG.PackedExchange(sym, cut)
+    assert 0 < px.packed_elements < px.full_elements
     dev = torch.device("cuda", 0)
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
     Lfull = torch.zeros(int(sym.xsize), dtype=torch.float64, device=dev)
+    Lr = torch.empty_like(Lfull)
     plan = api.Plan(sym, 0)
-    # each "rank" factors its subtrees into its own buffer; its slices are then copied over
+    # each "rank" factors its subtrees into the scratch buffer; the tails of its panels are packed and
+    # unpacked into rank 0's buffer (rank 0's own subtrees are already there)
     for rk in range(nranks):
-        Lr = torch.empty_like(Lfull)
         plan.set_active(cut.mask(rk))
-        plan.factor_device(values.data_ptr(), Lr.data_ptr(), 0)
+        plan.factor_device(values.data_ptr(), (Lfull if rk == 0 else Lr).data_ptr(), 0)
         torch.cuda.synchronize()
+        assert plan.status() == 0
         if rk == 0:
-            Lfull.copy_(Lr)  # rank 0's buffer also holds A scattered into the root panels
-        else:
-            for owner, a, b in cut.slices(sym):
-                if owner == rk:
-                    Lfull[a:b] = Lr[a:b]
+            continue
+        for k, (owner, src, ln, off, total) in enumerate(px.items):
+            if owner != rk or total == 0:
+                continue
+            buf = torch.empty(total, dtype=torch.float64, device=dev)
+            px._copy(buf, Lr, off, src, ln, k, 0)
+            px._copy(Lfull, buf, src, off, ln, k, 0)
+        torch.cuda.synchronize()
     plan.set_active(cut.root_mask())
     plan.factor_device(values.data_ptr(), Lfull.data_ptr(), 0, init=False)
     torch.cuda.synchronize()
     assert plan.status() == 0
-    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
-    got = Lfull.cpu().numpy()
-    assert np.abs(got - lo).max() <= FACTOR_TOL * np.abs(lo).max()
     plan.set_active(None)
-    lv, _ = plan.factor(sym.A2x)
-    assert np.array_equal(lv, got)  # sharding does not change a single bit
+    plan.factor_device(values.data_ptr(), Lr.data_ptr(), 0)   # unsharded, same plan
+    torch.cuda.synchronize()
+    assert plan.status() == 0
+    for s in cut.root_nodes:                                   # sharding does not change a single bit
+        a, b = int(sym.p[sym.super[s]]), int(sym.p[sym.super[s + 1]])
+        assert bool(torch.equal(Lfull[a:b], Lr[a:b]))
+    for owner, a, b in cut.slices(sym):                        # rank 0's own subtrees too
+        if owner == 0:
+            assert bool(torch.equal(Lfull[a:b], Lr[a:b]))
+    if name != "flan":
+        ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+        assert np.abs(Lr.cpu().numpy() - lo).max() <= FACTOR_TOL * np.abs(lo).max()
 
 
 # ---------------------------------------------------------------------------

@@ -52,11 +52,18 @@ def _rank_main(rank, world, port, name, out_dir):
 
     lv = torch.zeros(int(sym.xsize), dtype=torch.float64)
     factor_subset(cut.mask(rank), lv.numpy())
-    moved = MG.gather_to_root(lv, cut, sym, rank, dist)
+    # the exchange step in its packed form: only the panel rows the root part reads travel
+    px = MG.PackedExchange(sym, cut)
+    packed = px.run(lv, rank, dist)
     if rank == 0:
         factor_subset(cut.root_mask(), lv.numpy())
+        np.save(Path(out_dir) / "root_part.npy", lv.numpy().copy())
+    # the rest of the subtree panels follows where one rank wants the whole factor
+    moved = MG.gather_to_root(lv, cut, sym, rank, dist)
+    if rank == 0:
         np.save(Path(out_dir) / "sharded.npy", lv.numpy())
-        np.save(Path(out_dir) / "moved.npy", np.array([moved, len(cut.subtrees), len(cut.root_nodes)]))
+        np.save(Path(out_dir) / "moved.npy", np.array([moved, len(cut.subtrees), len(cut.root_nodes), packed,
+                                                      px.full_elements]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +78,15 @@ def test_two_rank_subtree_factorization_matches_single_process(tmp_path, oracle,
     A, perm, sym = problem(name)
     ok, ref, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
     got = np.load(tmp_path / "sharded.npy")
-    moved, nsub, nroot = np.load(tmp_path / "moved.npy")
+    moved, nsub, nroot, packed, full = np.load(tmp_path / "moved.npy")
     assert ok and np.array_equal(got, ref)
     assert nsub >= 2 and nroot >= 1 and moved > 0
+    # the packed exchange moved less than the whole panels and was enough for the root part: every
+    # root-part panel is already final (bitwise) before the full gather
+    assert 0 < packed < full == moved
+    from parsy_bench_amd import multigpu as MG
+    cut = MG.cut_subtrees(sym, 2)
+    rp = np.load(tmp_path / "root_part.npy")
+    for s in cut.root_nodes:
+        a, b = int(sym.p[sym.super[s]]), int(sym.p[sym.super[s + 1]])
+        assert np.array_equal(rp[a:b], ref[a:b])
