@@ -93,8 +93,9 @@ static int plan_upload(parsy_plan* pl) {
         pl->owned.push_back(d);
         pl->dp.sinfo = (int*)d;
         PARSY_HIP(hipMemset(d, 0, sizeof(int)));
-        pl->n_flags = std::max<int64_t>(S.n_dslots, 1);
-        const size_t fbytes = std::max<int64_t>(S.n_dslots, 1) * sizeof(int);
+        pl->n_flags = std::max<int64_t>(S.n_dslots, 1) * kPassLanes;
+        const size_t fbytes = std::max<int64_t>(S.n_dslots, 1) * kPassLanes * sizeof(int);
+        pl->dp.flag_stride = (int)std::max<int64_t>(S.n_dslots, 1);
         PARSY_HIP(hipMalloc(&d, fbytes));
         pl->owned.push_back(d);
         pl->dp.flags = (int*)d;
@@ -235,7 +236,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 }
                 break;
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
-            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, Lc, x, nrhs, ldx, stream); break;
+            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused)
                     launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,

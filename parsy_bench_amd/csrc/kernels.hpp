@@ -9,6 +9,8 @@
 
 namespace parsy {
 
+constexpr int kPassLanes = 8;    // passes over the right-hand sides of a solve that run side by side
+
 struct DevicePattern {           // device copies of Schedule arrays
     const SnDesc* sn = nullptr;           // the supernodes (solve kernels)
     const SnDesc* csn = nullptr;          // Cholesky view (pieces of the very wide ones): Cholesky kernels
@@ -35,6 +37,7 @@ struct DevicePattern {           // device copies of Schedule arrays
                                  // ([0, n_tflags): finished tiles, [n_tflags, 2 n_tflags): tiles prepared for the walker)
     int n_tflags = 0;
     int* tickets = nullptr;      // one counter per CHAIN launch (zeroed at the start of a factorization)
+    int flag_stride = 0;         // flags holds kPassLanes sets of this many entries (one per lane of passes)
     int* sinfo = nullptr;        // status of the last solve: 0 ok, < 0 a hand-off wait timed out (own word: a solve
                                  // never touches the factorization's status)
     int* stickets = nullptr;     // one counter per chain launch of the forward / backward solve
@@ -51,7 +54,7 @@ int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream);
 
-void launch_solve_small(const DevicePattern& P, int first, int count, const double* L, double* x,
+void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, const double* L, double* x,
                         int nrhs, int ldx, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);

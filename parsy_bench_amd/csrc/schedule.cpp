@@ -571,8 +571,12 @@ void build_launches(Schedule& S, const uint8_t* active) {
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t]) continue;
-                if (S.sn[t].w <= kTile) S.solve_small_list.push_back(t);
-                else sbigs.push_back(t);
+                if (S.sn[t].w <= kTile) {
+                    S.solve_small_list.push_back(t);
+                    L.jb = std::max<int32_t>(L.jb, S.sn[t].w);  // widest supernode of the launch
+                } else {
+                    sbigs.push_back(t);
+                }
             }
             L.count = (int32_t)S.solve_small_list.size() - L.first;
             if (L.count > 0) S.solve.push_back(L);

@@ -8,6 +8,9 @@
 // HBM-bound: every stored L value is read once per pass of kRhs right-hand sides.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace parsy {
@@ -16,6 +19,9 @@ static constexpr int kThreads = 256;
 static constexpr unsigned long long kSolveSpinTicks = 200000000ull;  // 2 s of the 100 MHz wall clock (as the factorization's waits)
 static constexpr int kLdDiag = kTile + 1;
 static constexpr int kRhs = 8;  // right-hand sides carried per pass over a panel
+// Passes over the right-hand sides are independent of each other: up to kPassLanes of them run side by
+// side (workgroups of their own; the chain launches keep one set of flags per lane), the rest follow in
+// rounds.  A block of 64 right-hand sides then costs about one pass of latency instead of eight.
 
 // Forward solve of the staged block xs[c][q] (c < w <= 64, q < nq) with the lower-triangular
 // block Dg (column-major, ld kLdDiag; entries outside w x w must be an identity).  Blocked by
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
         if (i >= c && i < w && c < w) v = G[(int64_t)c * r + i];
         Dg[c * kLdDiag + i] = v;
     }
-    for (int q0 = 0; q0 < nrhs; q0 += kRhs) {
+    bool first = true;
+    for (int q0 = blockIdx.y * kRhs; q0 < nrhs; q0 += gridDim.y * kRhs) {
         const int nq = min(kRhs, nrhs - q0);
         __syncthreads();
         for (int e = tid; e < wpad * nq; e += kThreads) {
@@ -116,7 +123,9 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
             xs[c][q] = (c < w) ? x[(int64_t)(q0 + q) * ldx + D.c0 + c] : 0.0;
         }
         __syncthreads();
-        if (q0 == 0) block_solve_inv16(Dg, invd, xs, w, nq, tid);
+        const bool was_first = first;
+        first = false;
+        if (was_first) block_solve_inv16(Dg, invd, xs, w, nq, tid);
         else block_solve_apply16(Dg, invd, xs, w, nq, tid);
         for (int e = tid; e < w * nq; e += kThreads) {
             const int q = e / w, c = e - q * w;
@@ -139,11 +148,174 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
     }
 }
 
-void launch_solve_small(const DevicePattern& P, int first, int count, const double* L, double* x,
+// SOLVE_SMALL for many right-hand sides (nrhs >= 16): up to 64 of them per pass over the panel, so that L is
+// read once per 64 right-hand sides instead of once per 8, and the products run on the matrix cores
+// (v_mfma_f64_16x16x4_f64).  Wave q owns right-hand sides 16q..16q+15 of the pass:
+//   (A) diagonal solve, blocked by 16 with the inverted 16x16 sub-blocks (as block_solve_inv16), every product
+//       an MFMA with both operands in LDS; a wave only touches its own 16 columns of xs: no barrier inside;
+//   (B) rows below the diagonal block, 16 at a time, distributed over the waves: x_s (64 x 64) sits in
+//       registers as the A operand, the 16 x 64 piece of L comes straight from the panel (16 consecutive rows
+//       per k: 128-B segments) as the B operand -- formed as x_s' L21' so that the lanes run along the ROWS --
+//       and is subtracted from x with atomics (the reference's `omp atomic`, Triangular_BCSC.h:154).
+typedef double double4_s __attribute__((ext_vector_type(4)));
+static constexpr int kRhsM = 64;        // right-hand sides per pass
+static int mrhs_min() {                 // from this many right-hand sides on (PARSY_MRHS_MIN: diagnostics)
+    static const int v = [] {
+        const char* e = std::getenv("PARSY_MRHS_MIN");
+        return e && *e ? std::atoi(e) : 16;
+    }();
+    return v;
+}
+static constexpr int kLdXs = kRhsM + 4; // row stride of xs in LDS
+
+template <int WMAX>  // widest supernode of the launch, rounded up to 16 / 32 / 64: sizes LDS and loops
+__global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __restrict__ sn,
+                                                               const int32_t* __restrict__ list,
+                                                               const int32_t* __restrict__ rows,
+                                                               const double* __restrict__ L,
+                                                               double* __restrict__ x, int nrhs, int ldx) {
+    constexpr int kLd = WMAX + 1;
+    __shared__ double Dg[WMAX * kLd];
+    __shared__ double invd[WMAX];
+    __shared__ double xs[WMAX * kLdXs];   // xs[c * kLdXs + q]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const SnDesc D = sn[list[blockIdx.x]];
+    const int r = D.r, w = D.w;
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    const int wpad = (w + 15) & ~15;
+
+    for (int e = tid; e < WMAX * WMAX; e += kThreads) {
+        const int c = e / WMAX, i = e - c * WMAX;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (i >= c && i < w && c < w) v = G[(int64_t)c * r + i];
+        Dg[c * kLd + i] = v;
+    }
+    __syncthreads();
+    // inverses of the 16x16 diagonal sub-blocks, stored transposed in the strict upper triangle (as
+    // block_solve_inv16): Dg[(b+r) * ld + b + c] = inv(L_bb)[r][c], r > c; reciprocal diagonal in invd
+    if (tid < WMAX) invd[tid] = 1.0 / Dg[tid * kLd + tid];
+    __syncthreads();
+    if (tid < WMAX && (tid & ~15) < w) {
+        const int b16 = tid & ~15, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLd + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLd + b16 + c] = y[rr];
+    }
+    for (int q0 = 0; q0 < nrhs; q0 += kRhsM) {
+        const int nq = min(kRhsM, nrhs - q0);
+        __syncthreads();  // inverses written / xs of the previous pass consumed
+        for (int e = tid; e < WMAX * kRhsM; e += kThreads) {
+            const int q = e / WMAX, c = e - q * WMAX;
+            xs[c * kLdXs + q] = (c < w && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + c] : 0.0;
+        }
+        __syncthreads();
+        // ---- (A) wave `wave` solves its 16 right-hand sides
+        if (16 * wave < nq) {
+            const int qc = 16 * wave + l15;  // this lane's right-hand side as B operand / result column
+            for (int b16 = 0; b16 < wpad; b16 += 16) {
+                // y_b = inv(L_bb) x_b
+                double4_s acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = 4 * st + kq, i = l15;
+                    double av = 0.0;                       // inv(L_bb)[i][k]
+                    if (k < i) av = Dg[(b16 + i) * kLd + b16 + k];
+                    else if (k == i) av = invd[b16 + i];
+                    const double bv = xs[(b16 + k) * kLdXs + qc];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xs[(b16 + kq + 4 * v) * kLdXs + qc] = acc[v];
+                // the sub-blocks below: x_b2 -= L(b2, b) y_b
+                for (int b2 = b16 + 16; b2 < wpad; b2 += 16) {
+                    double4_s a2 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int k = 4 * st + kq;
+                        const double av = Dg[(b16 + k) * kLd + b2 + l15];   // L[b2 + i][b16 + k]
+                        const double bv = xs[(b16 + k) * kLdXs + qc];
+                        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a2, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xs[(b2 + kq + 4 * v) * kLdXs + qc] -= a2[v];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < w * nq; e += kThreads) {
+            const int q = e / w, c = e - q * w;
+            x[(int64_t)(q0 + q) * ldx + D.c0 + c] = xs[c * kLdXs + q];
+        }
+        // ---- (B) rows below the diagonal block
+        const int nfrag_n = (nq + 15) >> 4;
+        if (r > w) {
+            constexpr int kSt = WMAX / 4;
+            double xa[4][kSt];  // A operands: xa[n][st] = x_s[c = 4 st + kq][rhs 16 n + l15]
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int st = 0; st < kSt; ++st) xa[n][st] = xs[(4 * st + kq) * kLdXs + 16 * n + l15];
+            for (int k0 = w + 16 * wave; k0 < r; k0 += 16 * (kThreads / 64)) {
+                const int row_l = min(k0 + l15, r - 1);
+                double lv[kSt];
+#pragma unroll
+                for (int st = 0; st < kSt; ++st) {
+                    const int c = 4 * st + kq;
+                    lv[st] = (c < w) ? G[(int64_t)c * r + row_l] : 0.0;
+                }
+                const int xrow = ri[row_l];
+                const bool rok = k0 + l15 < r;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n < nfrag_n) {
+                        double4_s acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int st = 0; st < kSt; ++st)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[n][st], lv[st], acc, 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int q = 16 * n + kq + 4 * v;
+                            if (rok && q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + xrow], -acc[v]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, const double* L, double* x,
                         int nrhs, int ldx, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_solve_small, dim3(count), dim3(kThreads), 0, stream, P.sn,
-                       P.solve_small_list + first, P.rows, L, x, nrhs, ldx);
+    if (nrhs >= mrhs_min()) {
+        const int32_t* list = P.solve_small_list + first;
+        if (wmax <= 16)
+            hipLaunchKernelGGL(k_solve_small_mrhs<16>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
+                               nrhs, ldx);
+        else if (wmax <= 32)
+            hipLaunchKernelGGL(k_solve_small_mrhs<32>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
+                               nrhs, ldx);
+        else
+            hipLaunchKernelGGL(k_solve_small_mrhs<64>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
+                               nrhs, ldx);
+    } else {
+        hipLaunchKernelGGL(k_solve_small, dim3(count, std::min(kPassLanes, (nrhs + kRhs - 1) / kRhs)),
+                           dim3(kThreads), 0, stream, P.sn, P.solve_small_list + first, P.rows, L, x, nrhs, ldx);
+    }
 }
 
 // SOLVE_PANEL: block column jb of a wide supernode.  Every workgroup solves the
@@ -294,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
                                                           double* __restrict__ xscratch, int nrhs,
                                                           int ldx, int* __restrict__ flags, int epoch0,
                                                           int* __restrict__ info, int* __restrict__ ticket,
-                                                          int wait_bias) {
+                                                          int wait_bias, int nchunks, int fstride) {
     __shared__ double Di[2][kTile * kLdDiag];  // inverse diagonal blocks, double buffered
     __shared__ double xs[kTile][NQ];
     __shared__ double ts[kTile][NQ];
@@ -305,7 +477,10 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
     // workgroup that has already started -- no assumption on residency or dispatch order
     if (tid == 0) s_task = atomicAdd(ticket, 1);
     __syncthreads();
-    const PanelDesc pd = pds[s_task];
+    // the launch holds every chunk once per pass lane: tickets 0..nchunks-1 are lane 0, and so on
+    const int plane = s_task / nchunks;
+    const PanelDesc pd = pds[s_task - plane * nchunks];
+    flags += (int64_t)plane * fstride;   // one set of flags per lane
     const SnDesc D = sn[pd.sn];
     const int r = D.r, w = D.w, chunk = pd.jb, row0 = pd.row0;
     const int nbc = (w + kTile - 1) / kTile;
@@ -327,10 +502,10 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
             Di[buf][(e >> 6) * kLdDiag + (e & 63)] = regs[t];
         }
     };
-    int pass = 0;
-    for (int q0 = 0; q0 < nrhs; q0 += NQ, ++pass) {
+    for (int pass = plane; pass * NQ < nrhs; pass += kPassLanes) {
+        const int q0 = pass * NQ;
         const int nq = min(NQ, nrhs - q0);
-        const int epoch = epoch0 + pass;
+        const int epoch = epoch0 + pass / kPassLanes;   // round of this lane
         double xv[NQ], acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -440,14 +615,16 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream) {
     if (count <= 0) return;
+    const int nq = nrhs == 1 ? 1 : kRhs;
+    const int lanes = std::min(kPassLanes, (nrhs + nq - 1) / nq);
     if (nrhs == 1)
         hipLaunchKernelGGL(k_solve_chain<1>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
                            P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.sinfo, P.stickets + ticket,
-                           wait_bias);
+                           wait_bias, count, P.flag_stride);
     else
-        hipLaunchKernelGGL(k_solve_chain<kRhs>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+        hipLaunchKernelGGL(k_solve_chain<kRhs>, dim3(count * lanes), dim3(kThreads), 0, stream, P.sn,
                            P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0,
-                           P.sinfo, P.stickets + ticket, wait_bias);
+                           P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
 }
 
 // ---------------------------------------------------------------------------
@@ -466,7 +643,8 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            double* __restrict__ x, double* __restrict__ xscratch,
                                                            int nrhs, int ldx, int chain, int* __restrict__ flags,
                                                            int epoch0, int* __restrict__ info,
-                                                           int* __restrict__ ticket, int wait_bias) {
+                                                           int* __restrict__ ticket, int wait_bias, int nblocks,
+                                                           int fstride) {
     // chain != 0: every block column of the wide supernodes of a level is in this launch (all
     // resident); block jb takes the x of blocks jb+1.. of its supernode as they are published
     // (xscratch, 8-byte agent-scope atomics both sides + a flag per block and pass).
@@ -476,9 +654,12 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     __shared__ int s_ok, s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
-    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)blockIdx.x;
+    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
     __syncthreads();
-    const PanelDesc pd = pds[s_task];
+    // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on (one set of flags per lane)
+    const int plane = s_task / nblocks;
+    const PanelDesc pd = pds[s_task - plane * nblocks];
+    flags += (int64_t)plane * fstride;
     const SnDesc D = sn[pd.sn];
     const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
     const double* __restrict__ G = L + D.px;
@@ -524,10 +705,10 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     }
 
     const int nbc = (w + kTile - 1) / kTile;
-    int pass = 0;
-    for (int q0 = 0; q0 < nrhs; q0 += NQ, ++pass) {
+    for (int pass = plane; pass * NQ < nrhs; pass += kPassLanes) {
+        const int q0 = pass * NQ;
         const int nq = min(NQ, nrhs - q0);
-        const int epoch = epoch0 + pass;
+        const int epoch = epoch0 + pass / kPassLanes;   // round of this lane
         __syncthreads();
         for (int e = tid; e < kTile * NQ; e += kThreads) {
             const int c = e & 63, q = e >> 6;
@@ -658,14 +839,16 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
                          double* xscratch, int nrhs, int ldx, int chain, int epoch0, int ticket, int wait_bias,
                          hipStream_t stream) {
     if (count <= 0) return;
+    const int lanes = nrhs == 1 ? 1 : std::min(kPassLanes, (nrhs + 3) / 4);
+    const dim3 grid = chain ? dim3(count * lanes) : dim3(count, lanes);
     if (nrhs == 1)
-        hipLaunchKernelGGL(k_bsolve_block<1>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+        hipLaunchKernelGGL(k_bsolve_block<1>, grid, dim3(kThreads), 0, stream, P.sn,
                            P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.sinfo, P.stickets + ticket, wait_bias);
+                           P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
     else
-        hipLaunchKernelGGL(k_bsolve_block<4>, dim3(count), dim3(kThreads), 0, stream, P.sn,
+        hipLaunchKernelGGL(k_bsolve_block<4>, grid, dim3(kThreads), 0, stream, P.sn,
                            P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.sinfo, P.stickets + ticket, wait_bias);
+                           P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.

@@ -55,8 +55,10 @@ def test_factor_residual_dense(api, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
-@pytest.mark.parametrize("nrhs", [1, 3, 8, 19])
+@pytest.mark.parametrize("nrhs", [1, 3, 8, 16, 19, 64, 70])
 def test_solve_matches_oracle(api, oracle, name, nrhs):
+    """nrhs >= 16 takes the many-right-hand-side kernels (64 per pass over a panel, MFMA products): every
+    column is checked against the oracle's one-vector solve."""
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(1)
     b1 = oracle.rhs_init_blocked(sym, lo)  # b = L * 1  (common/Util.h:277)
