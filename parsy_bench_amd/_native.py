@@ -13,7 +13,8 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-_LIB_PATH = _PKG / "libparsy_amd.so"
+# PARSY_LIB: a diagnostic build of the same library (tools/: ablations, tuning variants) instead of the product
+_LIB_PATH = Path(os.environ["PARSY_LIB"]) if os.environ.get("PARSY_LIB") else _PKG / "libparsy_amd.so"
 _lib = None
 
 c_int_p = C.POINTER(C.c_int)

@@ -1289,7 +1289,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
 // source it is subtracted from the tile in the panel through the relative indices -- the tile
 // belongs to this workgroup alone within the launch, sources in list order: fixed summation order.
 // ---------------------------------------------------------------------------
-static constexpr int kBK = 16;                 // k extent of a staged chunk
+#ifndef PARSY_BK
+#define PARSY_BK 16
+#endif
+static constexpr int kBK = PARSY_BK;           // k extent of a staged chunk
 static constexpr int kBLd = kBigTile + 16;     // k stride of a staged chunk in LDS: lanes 16..31 (k + 1) of an
                                                // operand read hit the other half of the banks
 static constexpr int kBigThreads = 512;        // 8 waves: 2 (rows) x 4 (columns), 64 x 32 outputs each; two

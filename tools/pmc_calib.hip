@@ -45,6 +45,19 @@ __global__ __launch_bounds__(256) void calib_write8_sc1(double* __restrict__ p, 
         __hip_atomic_store(p + i, (double)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 8 B per lane, 64 lanes contiguous (512 B per wave instruction): the staging loads of k_chol_big and the
+// row loads of the solve kernels
+__global__ __launch_bounds__(256) void calib_read8(const double* __restrict__ p, double* __restrict__ out, long n) {
+    double acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += p[i];
+    if (acc == 12345.678) out[0] = acc;
+}
+
+// plain 8-B stores, contiguous lanes (k_chol_big's read-modify-write of the target tile)
+__global__ __launch_bounds__(256) void calib_write8(double* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = (double)i;
+}
+
 int main() {
     double *buf, *out;
     if (hipMalloc(&buf, kBytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
@@ -56,9 +69,12 @@ int main() {
         hipLaunchKernelGGL(calib_read8_mfma, dim3(4096), dim3(256), 0, 0, buf, out, ncols);
         hipLaunchKernelGGL(calib_read16, dim3(4096), dim3(256), 0, 0, (const double2*)buf, out, n / 2);
         hipLaunchKernelGGL(calib_write8_sc1, dim3(4096), dim3(256), 0, 0, buf, n);
+        hipLaunchKernelGGL(calib_read8, dim3(4096), dim3(256), 0, 0, buf, out, n);
+        hipLaunchKernelGGL(calib_write8, dim3(4096), dim3(256), 0, 0, buf, n);
     }
     hipDeviceSynchronize();
-    printf("{\"calib_read8_mfma_bytes\": %ld, \"calib_read16_bytes\": %ld, \"calib_write8_sc1_bytes\": %ld}\n",
-           read8_bytes, (long)kBytes, (long)kBytes);
+    printf("{\"calib_read8_mfma_bytes\": %ld, \"calib_read16_bytes\": %ld, \"calib_write8_sc1_bytes\": %ld, "
+           "\"calib_read8_bytes\": %ld, \"calib_write8_bytes\": %ld}\n",
+           read8_bytes, (long)kBytes, (long)kBytes, (long)kBytes, (long)kBytes);
     return 0;
 }
