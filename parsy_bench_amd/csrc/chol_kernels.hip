@@ -1329,35 +1329,65 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
     WaveEntry LE = ents[le];
     double vR[kLq], vC[kLq];
     int v_kend = 0;                   // valid k of the chunk held in vR / vC (-1: no chunk)
+    // per entry: this thread's two row pointers at k = lkh of the current chunk, and the distance of kLs columns
+    const double* __restrict__ l_pr = L;
+    const double* __restrict__ l_pc = L;
+    int64_t l_step = 0;
+    auto enter = [&]() {
+        const int mi = LE.mn & 255, nj = (LE.mn >> 8) & 255;
+        const double* __restrict__ base = L + LE.src + (int64_t)lkh * LE.ld;
+        l_pr = base + LE.ia + min(lrow, mi - 1);
+        l_pc = base + LE.ja + min(lrow, nj - 1);
+        l_step = (int64_t)kLs * LE.ld;
+    };
+    enter();
     auto fetch = [&]() {
         if (le >= e_end) {
             v_kend = -1;
             return;
         }
-        const int mi = LE.mn & 255, nj = (LE.mn >> 8) & 255;
         const int kend = min(kBK, LE.K - lk);
-        const double* __restrict__ pr = L + LE.src + LE.ia + min(lrow, mi - 1) + (int64_t)lk * LE.ld;
-        const double* __restrict__ pc = L + LE.src + LE.ja + min(lrow, nj - 1) + (int64_t)lk * LE.ld;
+        if (kend == kBK) {  // a full chunk: the same loads every time, no clamps
 #pragma unroll
-        for (int q = 0; q < kLq; ++q) {
-            const int64_t ko = (int64_t)min(lkh + kLs * q, kend - 1) * LE.ld;
-            vR[q] = pr[ko];
-            vC[q] = pc[ko];
+            for (int q = 0; q < kLq; ++q) {
+                vR[q] = l_pr[q * l_step];
+                vC[q] = l_pc[q * l_step];
+            }
+        } else {            // ragged end of a source: k past the end re-reads its last column (staged as 0)
+#pragma unroll
+            for (int q = 0; q < kLq; ++q) {
+                const int64_t ko = (int64_t)(min(lkh + kLs * q, kend - 1) - lkh) * LE.ld;
+                vR[q] = l_pr[ko];
+                vC[q] = l_pc[ko];
+            }
         }
         v_kend = kend;
         lk += kBK;
+        l_pr += (int64_t)kBK * LE.ld;
+        l_pc += (int64_t)kBK * LE.ld;
         if (lk >= LE.K) {
             lk = 0;
             ++le;
-            if (le < e_end) LE = ents[le];
+            if (le < e_end) {
+                LE = ents[le];
+                enter();
+            }
         }
     };
     auto stage = [&](int b) {
+        if (v_kend == kBK) {
 #pragma unroll
-        for (int q = 0; q < kLq; ++q) {
-            const int k = lkh + kLs * q;
-            S.R[b][k * kBLd + lrow] = k < v_kend ? vR[q] : 0.0;
-            S.C[b][k * kBLd + lrow] = k < v_kend ? vC[q] : 0.0;
+            for (int q = 0; q < kLq; ++q) {
+                S.R[b][(lkh + kLs * q) * kBLd + lrow] = vR[q];
+                S.C[b][(lkh + kLs * q) * kBLd + lrow] = vC[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kLq; ++q) {
+                const int k = lkh + kLs * q;
+                S.R[b][k * kBLd + lrow] = k < v_kend ? vR[q] : 0.0;
+                S.C[b][k * kBLd + lrow] = k < v_kend ? vC[q] : 0.0;
+            }
         }
     };
 
@@ -1378,6 +1408,10 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         if (diag && 64 * wr + 63 < 32 * wc) nfr = 0;  // block strictly above the diagonal of a diagonal tile
         if (nfr == 0 || nfc == 0) nfr = nfc = 0;
     };
+    // A wave whose block of the tile has no rows of this source skips the chunk; a ragged block skips the
+    // 16-row fragments it does not have (wave-uniform branches: a second, branch-free copy of the loop for
+    // full blocks made the compiler spill 153 registers; issuing all 8 products always lost more to the
+    // ragged windows than the branches cost: 428 vs 390 ms of BIG launches).
     auto compute = [&](int b, int nfr, int nfc) {
         if (nfr == 0) return;
         const double* __restrict__ Rb = &S.R[b][64 * wr + l15];

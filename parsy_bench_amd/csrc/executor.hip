@@ -213,8 +213,15 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         if (!on_side) {
             // everything enqueued so far on the main stream belongs to levels < l.level
             if (overlap && l.kind <= kLaunchBig) record_levels_below(l.level);
-            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig) && early_seen[l.level])
-                (void)hipStreamWaitEvent(stream, pl->ev_early_done[l.level], 0);
+            // A main-stream launch that touches level t's tiles (NEXT, CHAIN) comes after every side launch
+            // enqueued so far whose targets can be at level t: those with a level field <= t (a PUSH writes
+            // into EVERY level from its field upwards).  The side stream runs in order, so the latest of them
+            // covers the earlier ones; PUSH(t - 1) / TILES(t + 1) (field t + 1) stay free to overlap.
+            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig)) {
+                int lw = std::min<int>(l.level, (int)early_seen.size() - 1);
+                while (lw >= 0 && !early_seen[lw]) --lw;
+                if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
+            }
         }
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {

@@ -19,6 +19,21 @@ __global__ __launch_bounds__(256) void k_mfma(double* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (512 flops per wave)
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma4(double* out, int iters) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0;
+    double a = threadIdx.x * 1e-3, b = blockIdx.x * 1e-3 + 1.0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void k_fma(double* out, int iters) {
     double acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = i;
@@ -56,6 +71,8 @@ int main() {
         run("mfma_f64 1 acc", [&](int b, int it) { hipLaunchKernelGGL(k_mfma<1>, dim3(b), dim3(256), 0, 0, d, it); }, 32.0 * 1, blocks);
         run("mfma_f64 4 acc", [&](int b, int it) { hipLaunchKernelGGL(k_mfma<4>, dim3(b), dim3(256), 0, 0, d, it); }, 32.0 * 4, blocks);
         run("mfma_f64 8 acc", [&](int b, int it) { hipLaunchKernelGGL(k_mfma<8>, dim3(b), dim3(256), 0, 0, d, it); }, 32.0 * 8, blocks);
+        run("mfma_f64_4x4x4 8 acc", [&](int b, int it) { hipLaunchKernelGGL(k_mfma4<8>, dim3(b), dim3(256), 0, 0, d, it); }, 8.0 * 8, blocks);
+        run("mfma_f64_4x4x4 16 acc", [&](int b, int it) { hipLaunchKernelGGL(k_mfma4<16>, dim3(b), dim3(256), 0, 0, d, it); }, 8.0 * 16, blocks);
         run("v_fma_f64 16 chains", [&](int b, int it) { hipLaunchKernelGGL(k_fma, dim3(b), dim3(256), 0, 0, d, it); }, 2.0 * 16, blocks);
     }
     return 0;
