@@ -10,7 +10,8 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kLd = 144;
 template <int MODE>
-__global__ __launch_bounds__(512, 4) void k_loop(const double* __restrict__ src, double* out, int chunks, long stride) {
+__global__ __launch_bounds__(512, 4) void k_loop(const double* __restrict__ src, double* out, int chunks, long stride,
+                                                 int nfr, int nfc, double* __restrict__ tiles) {
     __shared__ double R[2][16 * kLd], C[2][16 * kLd];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, lrow = tid & 127, lkh = tid >> 7;
@@ -20,6 +21,26 @@ __global__ __launch_bounds__(512, 4) void k_loop(const double* __restrict__ src,
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
     const double* p = src + (long)(blockIdx.x & 255) * stride + lrow;  // (the host sizes src for 256 streams)
     double vR[4] = {0, 0, 0, 0}, vC[4] = {0, 0, 0, 0};
+    if (MODE >= 5) {  // the start of a task: first chunk fetched and staged, second fetched, then the barrier
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vR[q] = p[(long)(lkh + 4 * q) * 20000];
+            vC[q] = p[(long)(lkh + 4 * q) * 20000 + 128];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R[0][(lkh + 4 * q) * kLd + lrow] = vR[q];
+            C[0][(lkh + 4 * q) * kLd + lrow] = vC[q];
+        }
+        p += 16 * 20000L;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vR[q] = p[(long)(lkh + 4 * q) * 20000];
+            vC[q] = p[(long)(lkh + 4 * q) * 20000 + 128];
+        }
+        p += 16 * 20000L;
+        __syncthreads();
+    }
     for (int n = 0; n < chunks; ++n) {
         const int b = n & 1;
         if (MODE >= 2) {  // stage chunk n + 1
@@ -47,12 +68,38 @@ __global__ __launch_bounds__(512, 4) void k_loop(const double* __restrict__ src,
 #pragma unroll
             for (int f = 0; f < 2; ++f) cv[f] = Cb[(4 * ks + kq) * kLd + 16 * f];
 #pragma unroll
-            for (int fc = 0; fc < 2; ++fc)
+            for (int fc = 0; fc < 2; ++fc) {
+                if (MODE < 4 || fc < nfc) {
 #pragma unroll
-                for (int fr = 0; fr < 4; ++fr)
-                    acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 0);
+                    for (int fr = 0; fr < 4; ++fr)
+                        if (MODE < 4 || fr < nfr)
+                            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 0);
+                }
+            }
         }
         if (MODE >= 1) __syncthreads();
+    }
+    if (MODE >= 5) {  // the end of a source: read-modify-write of the 128 x 128 tile, 8 loads of a lane at a time
+        // 4096 tiles side by side in a panel of ld = 4096 * 128 rows: element (r, c) of a tile at c * ld + r
+        double* __restrict__ T = tiles + (size_t)(blockIdx.x & 4095) * 128;
+        const long tld = 4096L * 128;
+#pragma unroll
+        for (int fc = 0; fc < 2; ++fc)
+#pragma unroll
+            for (int fh = 0; fh < 4; fh += 2) {
+                double old[2][4];
+#pragma unroll
+                for (int fr = fh; fr < fh + 2; ++fr)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        old[fr - fh][v] = T[(long)(32 * wc + 16 * fc + kq + 4 * v) * tld + 64 * wr + 16 * fr + l15];
+#pragma unroll
+                for (int fr = fh; fr < fh + 2; ++fr)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        T[(long)(32 * wc + 16 * fc + kq + 4 * v) * tld + 64 * wr + 16 * fr + l15] = old[fr - fh][v] - acc[fc][fr][v];
+                asm volatile("" ::: "memory");
+            }
     }
     double s = 0;
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) s += acc[a][b][c];
@@ -67,7 +114,7 @@ __global__ void k_fill(double* p, size_t n) {
 }
 
 int main() {
-    double *d, *src;
+    double *d, *src, *tiles;
     const long stride = 4L << 20;  // doubles between the streams of two workgroups (32 MB)
     (void)hipMalloc(&d, 4096 * 512 * 8);
     const size_t src_doubles = (size_t)(256 * stride + 20000L * 16 * 2100 + 1024);  // 256 streams, <= 2000 chunks each
@@ -76,14 +123,16 @@ int main() {
     if (zeros) (void)hipMemset(src, 0, src_doubles * 8);
     else hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, src, src_doubles);
     printf("operands: %s\n", zeros ? "zeros" : "random");
+    if (hipMalloc(&tiles, (size_t)4096 * 128 * 128 * 8) != hipSuccess) return 1;  // 4096 tiles side by side (512 MB)
+    (void)hipMemset(tiles, 0, (size_t)4096 * 128 * 128 * 8);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     auto run = [&](const char* name, auto kern, int blocks, int chunks) {
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, src, d, 10, stride);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, src, d, 10, stride, 4, 2, tiles);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, src, d, chunks, stride);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, src, d, chunks, stride, 4, 2, tiles);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -97,6 +146,10 @@ int main() {
         run("C + staging stores", k_loop<2>, blocks, 2000);
         run("D + global loads (streaming)", k_loop<3>, blocks, 2000);
         run("D with 32-chunk tasks (K = 512)", k_loop<3>, blocks * 16, 32);
+        run("E = D + wave-uniform branch per MFMA", k_loop<4>, blocks, 2000);
+        run("E with 32-chunk tasks (K = 512)", k_loop<4>, blocks * 16, 32);
+        run("F = E + task start + tile RMW, K = 512", k_loop<5>, blocks * 16, 32);
+        run("F with K = 2048", k_loop<5>, blocks * 4, 128);
     }
     return 0;
 }
