@@ -611,10 +611,202 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
     }
 }
 
+// SOLVE_CHAIN for many right-hand sides (nrhs >= 16): the same protocol (256-row chunks, pull form, the owner of a
+// block column publishes x_jb, tickets, flags per lane of passes) with 64 right-hand sides per pass over the panel
+// and every product on v_mfma_f64_16x16x4_f64, so that L is read once per 64 right-hand sides.  Wave v of a chunk
+// owns its rows 64 v .. 64 v + 63; the running update of a row lives in accumulator layout as
+// D[i = right-hand side][j = row] (lanes along the rows), started at -x for the rows of the supernode's own
+// columns, so that the owner's t_jb = x - sum is just the negated accumulator.  x_jb = inv(L_jj) t_jb is an MFMA
+// product too (t through LDS into operand layout); the rows below the supernode's columns are scattered at the end
+// with atomics, as in the one-vector kernel.
+static constexpr int kLdXm = kRhsM + 16;  // row stride of the staged x_jb / t_jb (doubles): conflict-free operand reads
+
+__global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* __restrict__ sn,
+                                                                  const PanelDesc* __restrict__ pds,
+                                                                  const int32_t* __restrict__ rows,
+                                                                  const double* __restrict__ L,
+                                                                  const double* __restrict__ dinv,
+                                                                  double* __restrict__ x, double* __restrict__ xscratch,
+                                                                  int nrhs, int ldx, int* __restrict__ flags, int epoch0,
+                                                                  int* __restrict__ info, int* __restrict__ ticket,
+                                                                  int wait_bias, int nchunks, int fstride) {
+    __shared__ double Di[kTile * kLdDiag];   // inverse diagonal block of the block column being solved (owner)
+    __shared__ double xs[kTile * kLdXm];     // x_jb: xs[c * kLdXm + q]
+    __shared__ double ts[kTile * kLdXm];     // t_jb: ts[row * kLdXm + q]
+    __shared__ int32_t s_ok, s_task;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    if (tid == 0) s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int plane = s_task / nchunks;
+    const PanelDesc pd = pds[s_task - plane * nchunks];
+    flags += (int64_t)plane * fstride;
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w, chunk = pd.jb, row0 = pd.row0;
+    const int nbc = (w + kTile - 1) / kTile;
+    const double* __restrict__ G = L + D.px;
+    const int wrow0 = row0 + 64 * wave;                 // first panel row of this wave
+    int prow[4];                                        // this lane's row of each 16-row fragment (-1: past the panel)
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) prow[rf] = (wrow0 + 16 * rf + l15 < r) ? wrow0 + 16 * rf + l15 : -1;
+
+    for (int pass = plane; pass * kRhsM < nrhs; pass += kPassLanes) {
+        const int q0 = pass * kRhsM;
+        const int nq = min(kRhsM, nrhs - q0);
+        const int nfn = (nq + 15) >> 4;                 // 16-wide fragments of right-hand sides in use
+        const int epoch = epoch0 + pass / kPassLanes;
+        double4_s acc[4][4];                            // [fragment of right-hand sides][fragment of rows]
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int q = 16 * nf + kq + 4 * v;
+                    const bool diag = prow[rf] >= 0 && prow[rf] < w && q < nq;
+                    acc[nf][rf][v] = diag ? -x[(int64_t)(q0 + q) * ldx + D.c0 + prow[rf]] : 0.0;
+                }
+        for (int jb = 0; jb < nbc; ++jb) {
+            const int cb = jb * kTile, wbk = min(kTile, w - cb);
+            const int owner = cb / kSolveRows;
+            if (chunk < owner) break;
+            // this wave's rows of L against block column jb, in B-operand layout (lane = (k >> 2 group, row)):
+            // issued before the wait for x_jb
+            const bool wave_below = wrow0 + 64 > cb + wbk && wrow0 < r;
+            double lv[4][16];
+            if (wave_below) {
+#pragma unroll
+                for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int c = 4 * st + kq;
+                        const bool ok = prow[rf] >= cb + wbk && c < wbk;
+                        lv[rf][st] = ok ? G[(int64_t)(cb + c) * r + prow[rf]] : 0.0;
+                    }
+            }
+            __syncthreads();  // xs / ts of the previous block column are free
+            if (chunk == owner) {
+                // t_jb = -(accumulator) of the block's 64 rows (one wave holds them) -> LDS, row-major
+                const int wv_o = (cb - row0) >> 6;
+                for (int e = tid; e < kTile * kTile; e += kThreads) {  // inverse diagonal block -> LDS
+                    Di[(e >> 6) * kLdDiag + (e & 63)] = dinv[(int64_t)(D.dslot + jb) * (kTile * kTile) + e];
+                }
+                if (wave == wv_o) {
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                        for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                ts[(16 * rf + l15) * kLdXm + 16 * nf + kq + 4 * v] =
+                                    (16 * rf + l15 < wbk) ? -acc[nf][rf][v] : 0.0;
+                }
+                __syncthreads();
+                // x_jb = inv(L_jj) t_jb: wave n takes the right-hand sides 16 n .. 16 n + 15
+                if (wave < nfn) {
+                    double4_s xa[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int kr = 4 * st + kq;
+                        const double av = ts[kr * kLdXm + 16 * wave + l15];          // t[kr][q]
+#pragma unroll
+                        for (int rf = 0; rf < 4; ++rf) {
+                            const double bv = Di[kr * kLdDiag + 16 * rf + l15];      // inv[row][kr]
+                            xa[rf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xa[rf], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int q = 16 * wave + kq + 4 * v, c = 16 * rf + l15;
+                            xs[c * kLdXm + q] = xa[rf][v];
+                            if (c < wbk && q < nq) {
+                                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], xa[rf][v],
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = xa[rf][v];
+                            }
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(&flags[D.dslot + jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    int ok = 1, spins = 0;
+                    while (__hip_atomic_load(&flags[D.dslot + jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                               (epoch + wait_bias) < 0) {
+                        if ((++spins & 15) == 0 &&
+                            (wall_clock64() - t0 > kSolveSpinTicks ||
+                             __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                            ok = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    s_ok = ok;
+                }
+                __syncthreads();
+                if (!s_ok) {
+                    if (tid == 0) atomicMin(info, -1);
+                    return;
+                }
+                for (int e = tid; e < kTile * kRhsM; e += kThreads) {
+                    const int q = e >> 6, c = e & 63;
+                    xs[c * kLdXm + q] = (c < wbk && q < nq)
+                                            ? __hip_atomic_load(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c],
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : 0.0;
+                }
+                __syncthreads();
+            }
+            // rows below the diagonal block: accumulator += x_jb' L(rows, jb)'
+            if (wave_below) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    if (nf < nfn) {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) {
+                            const double av = xs[(4 * st + kq) * kLdXm + 16 * nf + l15];
+#pragma unroll
+                            for (int rf = 0; rf < 4; ++rf)
+                                acc[nf][rf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv[rf][st], acc[nf][rf], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // rows below the supernode's own columns: x[row] -= accumulated update
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+            if (prow[rf] >= w) {
+                const int xrow = rows[D.pi + prow[rf]];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int q = 16 * nf + kq + 4 * v;
+                        if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + xrow], -acc[nf][rf][v]);
+                    }
+            }
+        }
+    }
+}
+
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream) {
     if (count <= 0) return;
+    if (nrhs >= mrhs_min()) {
+        const int lanes_m = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
+        hipLaunchKernelGGL(k_solve_chain_mrhs, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn,
+                           P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.sinfo,
+                           P.stickets + ticket, wait_bias, count, P.flag_stride);
+        return;
+    }
     const int nq = nrhs == 1 ? 1 : kRhs;
     const int lanes = std::min(kPassLanes, (nrhs + nq - 1) / nq);
     if (nrhs == 1)
