@@ -179,11 +179,13 @@ class PackedExchange:
         return self._dev[k]
 
     def _copy(self, dst, src, dst_off, src_off, ln, k, stream):
-        """dst[dst_off[q] + i] = src[src_off[q] + i]: HIP kernel on the device, numpy on host tensors."""
+        """dst[dst_off[q] + i] = src[src_off[q] + i], i < ln[q] (the host arrays of item k, in either role):
+        the library's copy kernel on device tensors, numpy on host tensors."""
         if dst.is_cuda:
             from . import _native as N
             s_src, s_len, s_off = self._segments(k, dst)
-            a_dst, a_src = (s_off, s_src) if dst_off is self.items[k][3] else (s_src, s_off)
+            packing = dst_off is self.items[k][3]   # packed offsets on the destination side: pack, else unpack
+            a_dst, a_src = (s_off, s_src) if packing else (s_src, s_off)
             if N.lib().parsy_copy_segments_device(dst.data_ptr(), src.data_ptr(), a_dst.data_ptr(), a_src.data_ptr(),
                                                   s_len.data_ptr(), len(ln), stream) != 0:
                 raise RuntimeError("parsy_copy_segments_device failed: " + N.last_error())
