@@ -158,6 +158,10 @@ int parsy_plan_set_active(parsy_plan* plan, const uint8_t* mask);
  * returns the number of tiles that would never be finished -- 0 means the schedule cannot
  * deadlock at that residency -- or -1 for a bad argument.  The kernel runs 2 workgroups per CU. */
 long long parsy_plan_chain_check(const parsy_plan* plan, int slots);
+/* Host-side consistency check of the factorization's schedule (pieces, levels, windows of the update entries,
+ * exact cover of every (target, descendant) update, launch order): number of violations, 0 = consistent
+ * (parsy_last_error describes the first one).  For tests and for callers that build plans from their own arrays. */
+long long parsy_plan_check(const parsy_plan* plan);
 
 /* Numeric factorization, everything on the device.
  *   d_values  device, nnz(A2) doubles (same order as the host `values`)

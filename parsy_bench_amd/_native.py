@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
     "parsy_grid_nested_dissection", "parsy_order_nd", "parsy_plan_profile", "parsy_plan_profile_collect",
     "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve2_host",
-    "parsy_rhs_ones_device", "parsy_solve_status", "parsy_copy_segments_device",
+    "parsy_rhs_ones_device", "parsy_solve_status", "parsy_copy_segments_device", "parsy_plan_check",
 ]
 
 
@@ -95,6 +95,8 @@ def _declare(lib):
     lib.parsy_plan_set_active.argtypes = [vp, vp]
     lib.parsy_plan_chain_check.argtypes = [vp, C.c_int]
     lib.parsy_plan_chain_check.restype = C.c_longlong
+    lib.parsy_plan_check.argtypes = [vp]
+    lib.parsy_plan_check.restype = C.c_longlong
     lib.parsy_factor_device.argtypes = [vp, vp, vp, vp]
     lib.parsy_factor_device_ex.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.parsy_factor_status.argtypes = [vp]

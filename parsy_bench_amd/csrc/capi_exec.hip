@@ -321,6 +321,17 @@ long long parsy_plan_chain_check(const parsy_plan* pl, int slots) {
     return (long long)simulate_chain(pl->S, slots);
 }
 
+long long parsy_plan_check(const parsy_plan* pl) {
+    if (!pl) {
+        set_last_error("parsy_plan_check: null plan");
+        return -1;
+    }
+    std::string what;
+    const long long bad = (long long)parsy::check_schedule(pl->S, what);
+    if (bad) set_last_error("parsy_plan_check: " + what);
+    return bad;
+}
+
 int parsy_plan_set_active(parsy_plan* pl, const uint8_t* mask) {
     if (!pl) return -1;
     parsy::build_launches(pl->S, mask);

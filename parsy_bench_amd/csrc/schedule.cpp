@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstdint>
 #include <stdexcept>
@@ -738,6 +739,113 @@ int64_t simulate_chain(const Schedule& S, int slots) {
         stuck += (count - next) + (int64_t)resident.size();
     }
     return stuck;
+}
+
+int64_t check_schedule(const Schedule& S, std::string& what) {
+    int64_t bad = 0;
+    auto fail = [&](const std::string& msg) {
+        if (bad++ == 0) what = msg;
+    };
+    if (S.solve_only) return 0;
+    const int nc = (int)S.csn.size();
+    // ---- pieces tile their supernode; levels respect the chain-extended etree
+    for (int t = 0; t < S.nsuper; ++t) {
+        int cols = 0;
+        for (int p = S.piece0[t]; p < S.piece0[t + 1]; ++p) {
+            const SnDesc& C = S.csn[p];
+            if (C.c0 != S.sn[t].c0 + cols || C.rbias != cols || C.r != S.sn[t].r - cols || C.ld != S.sn[t].r)
+                fail("piece " + std::to_string(p) + " is not a window of its supernode's panel");
+            if (p > S.piece0[t] && S.level_of[p] != S.level_of[p - 1] + 1) fail("pieces of a supernode are not on consecutive levels");
+            cols += C.w;
+        }
+        if (cols != S.sn[t].w) fail("pieces of supernode " + std::to_string(t) + " do not add up to its width");
+    }
+    // ---- every update comes from a lower level; wave + BIG entries cover it exactly (flop identity)
+    std::vector<double> covered(S.upd.size(), 0.0);
+    auto entry_flops = [](const WaveEntry& E, bool same_window) {
+        const double K = E.K, mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+        return same_window ? K * nj * (nj + 1) + 2.0 * K * (mi - nj) * nj : 2.0 * K * mi * nj;
+    };
+    for (int t = 0; t < nc; ++t) {
+        const SnDesc& T = S.csn[t];
+        for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
+            if (S.level_of[S.upd_src[u]] >= S.level_of[t]) fail("update " + std::to_string(u) + " comes from a level that is not below its target");
+        if (is_small(T) || T.nupd == 0) continue;
+        // map an entry back to its update: (src, K) is unique among the updates of one target
+        auto find_upd = [&](const WaveEntry& E) -> int64_t {
+            for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
+                if (S.upd[u].src == E.src && S.upd[u].K == E.K) return u;
+            return -1;
+        };
+        if (S.sn_wp0[t] >= 0) {
+            const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
+            const int64_t* wp = &S.wave_ptr[S.sn_wp0[t]];
+            for (size_t key = 0; key < (size_t)nbc * nbr * 8; ++key)
+                for (int64_t e = wp[key]; e < wp[key + 1]; ++e) {
+                    const WaveEntry& E = S.wave_entries[(size_t)e];
+                    const int64_t u = find_upd(E);
+                    const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+                    if (u < 0 || mi < 1 || mi > kSub || nj < 1 || nj > kSub || E.ia + mi > S.upd[u].m || E.ja + nj > S.upd[u].n1) {
+                        fail("wave entry " + std::to_string(e) + " of piece " + std::to_string(t) + " has a bad window");
+                        continue;
+                    }
+                    covered[(size_t)u] += entry_flops(E, E.ia == E.ja);
+                }
+        }
+    }
+    for (const Schedule::BigTask& b : S.big_all) {
+        const SnDesc& T = S.csn[b.sn];
+        if (b.src_level >= S.level_of[b.sn] || (b.next != 0) != (b.src_level == S.level_of[b.sn] - 1))
+            fail("BIG task of piece " + std::to_string(b.sn) + " is filed under the wrong source level");
+        if (b.row0 % kBigTile || b.col0 % kBigTile || b.row0 < b.col0 || b.row0 >= T.r || b.col0 >= T.w)
+            fail("BIG task of piece " + std::to_string(b.sn) + " has a bad tile origin");
+        for (int64_t e = b.e0; e < b.e1; ++e) {
+            const WaveEntry& E = S.big_entries[(size_t)e];
+            int64_t u = -1;
+            for (int64_t q = T.upd0; q < T.upd0 + T.nupd; ++q)
+                if (S.upd[q].src == E.src && S.upd[q].K == E.K) u = q;
+            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+            const bool ident = (E.mn >> 16) != 0;
+            if (u < 0 || mi < 1 || mi > kBigTile || nj < 1 || nj > kBigTile || E.ia + mi > S.upd[u].m || E.ja + nj > S.upd[u].n1 ||
+                ident != (S.upd[u].rel < 0) || S.level_of[S.upd_src[u]] != b.src_level) {
+                fail("BIG entry " + std::to_string(e) + " of piece " + std::to_string(b.sn) + " has a bad window or source");
+                continue;
+            }
+            // the rows it names land in the task's tile
+            auto rel_at = [&](int k) { return ident ? k : S.relpos[(size_t)S.upd[u].rel + k] - T.rbias; };
+            if (rel_at(E.ia) / kBigTile != b.row0 / kBigTile || rel_at(E.ia + mi - 1) / kBigTile != b.row0 / kBigTile ||
+                rel_at(E.ja) / kBigTile != b.col0 / kBigTile || rel_at(E.ja + nj - 1) / kBigTile != b.col0 / kBigTile)
+                fail("BIG entry " + std::to_string(e) + " names rows outside its task's tile");
+            covered[(size_t)u] += entry_flops(E, E.ia == E.ja);
+        }
+    }
+    for (int t = 0; t < nc; ++t) {
+        const SnDesc& T = S.csn[t];
+        if (is_small(T)) continue;
+        for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
+            const UpdDesc& U = S.upd[u];
+            const double want = (double)U.K * U.n1 * (U.n1 + 1) + 2.0 * U.K * (double)(U.m - U.n1) * U.n1;
+            if (std::abs(covered[(size_t)u] - want) > 1e-9 * want + 0.5)
+                fail("update " + std::to_string(u) + " of piece " + std::to_string(t) + " is not covered exactly once by its entries");
+        }
+    }
+    // ---- launch sequence: a side launch comes before the main-stream launches of the level that waits for it and
+    // after every main-stream launch of the levels it waits for; the main stream never goes down a level
+    int main_level = -1;
+    for (size_t i = 0; i < S.chol.size(); ++i) {
+        const Launch& l = S.chol[i];
+        if (l.side) {
+            if (l.wait_level >= 0 && main_level > l.wait_level + 0 && main_level >= l.level)
+                fail("side launch " + std::to_string(i) + " is enqueued after the level that waits for it");
+            for (size_t j = i + 1; j < S.chol.size(); ++j)
+                if (!S.chol[j].side && S.chol[j].level <= l.wait_level)
+                    fail("side launch " + std::to_string(i) + " precedes a main-stream launch of a level it waits for");
+        } else {
+            if (l.level < main_level) fail("main-stream launches go down a level");
+            main_level = l.level;
+        }
+    }
+    return bad;
 }
 
 }  // namespace parsy

@@ -122,3 +122,45 @@ def test_chain_dry_run_with_many_walkers():
             assert N.lib().parsy_plan_chain_check(h, slots) == 0
     finally:
         N.lib().parsy_plan_destroy(h)
+
+
+@pytest.mark.parametrize("name,piece,mink,group", [
+    ("small3d", None, None, None), ("mid3d", None, None, None), ("ex15", None, None, None), ("nd24k", None, None, None),
+    ("mid3d", 128, 16, 1), ("mid3d", 128, 48, 2), ("lap30", 128, 32, 1), ("lap30", 256, 64, 4), ("lap30", 0, 16, 1),
+    ("nd24k", 512, 128, 1), ("nd24k", 256, 64, 2), ("72x72x72", None, None, None)])
+def test_cholesky_view_is_consistent(monkeypatch, name, piece, mink, group):
+    """The schedule the factorization runs on -- supernodes cut into pieces, updates filed as wave-stream or
+    BIG entries by source level -- checked on the host (parsy_plan_check): pieces tile their supernode on
+    consecutive levels, every update comes from a lower level, every entry's windows lie inside its update and
+    (BIG) inside its task's tile, the entries cover every update exactly once (flop identity with the reference's
+    DSYRK + DGEMM counts), side launches sit between the levels they wait for and the level that waits for them."""
+    from parsy_bench_amd import matrices as M
+    if name in ("72x72x72",):
+        A, perm = M.workload(name)
+        sym = I.analyze(A, perm)
+    else:
+        A, perm, sym = problem(name)
+    if piece is not None:
+        monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+        monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+        monkeypatch.setenv("PARSY_PUSH_GROUP", str(group))
+    h, info = host_plan(sym)
+    try:
+        bad = N.lib().parsy_plan_check(h)
+        assert bad == 0, N.last_error()
+        if piece:
+            assert info["piece_width"] == piece
+            if sym.maxSupWid > piece * 3 // 2:
+                assert info["n_pieces"] > sym.nsuper and info["chol_levels"] > sym.nlevels
+            assert info["big_tasks"] > 0
+        if piece is None and name == "72x72x72":
+            assert info["big_tasks"] > 0 and info["piece_width"] == 0   # chosen by the size of the job
+        # the chain launches of the view cannot deadlock either
+        assert N.lib().parsy_plan_chain_check(h, 512) == 0
+        # restricting the launches to a subtree keeps the sequence consistent
+        cut = MG.cut_subtrees(sym, 2)
+        for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+            assert N.lib().parsy_plan_set_active(h, N.ptr(np.ascontiguousarray(mask))) == 0
+            assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+    finally:
+        N.lib().parsy_plan_destroy(h)
