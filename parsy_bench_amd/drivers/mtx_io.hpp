@@ -74,12 +74,7 @@ inline bool read_lower_mtx(const std::string& path, int& n, std::vector<int>& Ap
         Ax[k] = v;
         Ap[c + 1]++;
     }
-    for (int j = 0; j < n; ++j) {
-        if (Ap[j + 1] == 0 || Ai[Ap[j]] != j) {
-            // (checked after the prefix sum below)
-        }
-        Ap[j + 1] += Ap[j];
-    }
+    for (int j = 0; j < n; ++j) Ap[j + 1] += Ap[j];
     for (int j = 0; j < n; ++j)
         if (Ap[j + 1] == Ap[j] || Ai[Ap[j]] != j) {
             std::cerr << path << ": column " << j << " has no diagonal entry\n";
