@@ -135,7 +135,11 @@ typedef struct parsy_plan_info {
     int32_t n_pieces;              /* supernodes of the Cholesky view (very wide ones cut into pieces) */
     int32_t chol_levels;           /* levels of the Cholesky view's (chain-extended) etree */
     int32_t piece_width, big_min_k;
-    int32_t pad_;
+    /* subtree launches: etree subtrees of narrow supernodes walked by one workgroup each (the reference's
+     * w-partitions, parallel_PB_Cholesky_05.h:66-84 / Triangular_BCSC.h:171-232) and the supernodes in them */
+    int32_t chol_subtrees, chol_subtree_supernodes;
+    int32_t solve_subtrees, solve_subtree_supernodes;
+    int32_t backsolve_launches;    /* kernel launches per backward solve */
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

@@ -52,7 +52,10 @@ class PlanInfo(C.Structure):
         ("inner_flops", C.c_double), ("tile_update_flops", C.c_double),
         ("big_flops", C.c_double), ("big_entries", C.c_int64), ("big_tasks", C.c_int32),
         ("n_pieces", C.c_int32), ("chol_levels", C.c_int32), ("piece_width", C.c_int32),
-        ("big_min_k", C.c_int32), ("pad_", C.c_int32),
+        ("big_min_k", C.c_int32),
+        ("chol_subtrees", C.c_int32), ("chol_subtree_supernodes", C.c_int32),
+        ("solve_subtrees", C.c_int32), ("solve_subtree_supernodes", C.c_int32),
+        ("backsolve_launches", C.c_int32),
     ]
 
     def as_dict(self):

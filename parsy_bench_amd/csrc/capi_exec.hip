@@ -310,6 +310,13 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->chol_levels = S.cnlevels;
     o->piece_width = S.piece_width;
     o->big_min_k = S.big_min_k;
+    // as launched (active supernodes only)
+    o->chol_subtrees = (int32_t)S.small_ranges.size() / 2;
+    for (size_t b = 0; b + 1 < S.small_ranges.size(); b += 2) o->chol_subtree_supernodes += S.small_ranges[b + 1] - S.small_ranges[b];
+    o->solve_subtrees = (int32_t)S.solve_small_ranges.size() / 2;
+    for (size_t b = 0; b + 1 < S.solve_small_ranges.size(); b += 2)
+        o->solve_subtree_supernodes += S.solve_small_ranges[b + 1] - S.solve_small_ranges[b];
+    o->backsolve_launches = (int32_t)S.bsolve.size();
     return 0;
 }
 

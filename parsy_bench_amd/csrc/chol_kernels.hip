@@ -182,12 +182,19 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
                                                          const UpdDesc* __restrict__ upd,
                                                          const int32_t* __restrict__ relpos,
                                                          const int32_t* __restrict__ list,
+                                                         const int32_t* __restrict__ ranges,
                                                          double* __restrict__ L,
                                                          int* __restrict__ info, int stage_cap) {
     // stage_cap (<= kSmallStage, host-chosen per launch): doubles per staged block
+    // ranges != null (subtree launch): the workgroup factors list[ranges[2b] .. ranges[2b+1]) one after the
+    // other -- a subtree of the etree in index order, so every descendant of a supernode has been stored by
+    // this same workgroup (same CU, same L1: ordered by the barrier that ends each supernode)
     extern __shared__ __attribute__((aligned(16))) double P[];  // panel, then 2 stages, then 2 index rings
     const int tid = threadIdx.x;
-    const SnDesc D = sn[list[blockIdx.x]];
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+  for (int qsn = q_begin; qsn < q_end; ++qsn) {
+    const SnDesc D = sn[list[qsn]];
     const int r = D.r, w = D.w, total = r * w;
     double* __restrict__ G = L + D.px;
 #ifdef PARSY_STAMPS
@@ -435,17 +442,21 @@ __global__ __launch_bounds__(kThreads) void k_chol_small(const SnDesc* __restric
     STRACE(4);
     for (int e = tid; e < total; e += kThreads) G[e] = P[e];
     STRACE(5);
+    __syncthreads();  // subtree launch: the panel is stored (and LDS free) before the next supernode starts
+  }
 }
 
-void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
-                       hipStream_t stream) {
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, bool subtrees,
+                       double* L, hipStream_t stream) {
     if (count <= 0) return;
     // panel (padded to 16 B) + two staged blocks + four index-ring slots + the POTRF's scratch
     stage_cap = min(max(stage_cap, 2), kSmallStage);
     const size_t lds = (size_t)((lds_bytes + 15) & ~15) + 2 * (size_t)stage_cap * sizeof(double) +
                        4 * kSmallRelCap * sizeof(int32_t) + (kPotrfScratch + kTile) * sizeof(double);
-    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.csn,
-                       P.upd, P.relpos, P.small_list + first, L, P.info, stage_cap);
+    // subtree launch: `first` counts (begin, end) pairs of small_ranges, which index the whole list
+    hipLaunchKernelGGL(k_chol_small, dim3(count), dim3(kThreads), lds, stream, P.csn, P.upd, P.relpos,
+                       subtrees ? P.small_list : P.small_list + first,
+                       subtrees ? P.small_ranges + 2 * first : nullptr, L, P.info, stage_cap);
 }
 
 // ---------------------------------------------------------------------------

@@ -39,6 +39,9 @@ int plan_upload_launches(parsy_plan* pl) {
     pl->launch_owned.clear();
     const Schedule& S = pl->S;
     if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
+    if (upload(pl, S.small_ranges, pl->dp.small_ranges, true)) return -1;
+    if (upload(pl, S.solve_small_ranges, pl->dp.solve_small_ranges, true)) return -1;
+    if (upload(pl, S.bsolve_ranges, pl->dp.bsolve_ranges, true)) return -1;
     if (upload(pl, S.tiles, pl->dp.tiles, true)) return -1;
     if (upload(pl, S.big_tasks, pl->dp.big_tasks, true)) return -1;
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
@@ -225,7 +228,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
         }
         profile_mark(pl, l.kind, stream, cursor);
         switch (l.kind) {
-            case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, L, stream); break;
+            case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, l.fused == 2, L, stream); break;
             case kLaunchTiles:
             case kLaunchBig:
                 if (on_side) {
@@ -243,7 +246,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 }
                 break;
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
-            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, Lc, x, nrhs, ldx, stream); break;
+            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused)
                     launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
@@ -256,7 +259,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 break;
             case kLaunchBackBlock:
                 launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, l.fused, pl->epoch,
-                                    l.fused ? l.jb : 0, pl->solve_wait_bias, stream);
+                                    l.fused == 1 ? l.jb : 0, pl->solve_wait_bias, stream);
                 break;
         }
     }

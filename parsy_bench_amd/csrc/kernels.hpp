@@ -23,6 +23,9 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int64_t* split_ranges = nullptr;     // shares of the wave lists of tiles whose early stream is split
     double* tile_scratch = nullptr;            // partial tiles of the split streams
     const int32_t* small_list = nullptr;
+    const int32_t* small_ranges = nullptr;        // subtree launches: (begin, end) pairs into the lists,
+    const int32_t* solve_small_ranges = nullptr;  // one per workgroup
+    const int32_t* bsolve_ranges = nullptr;
     const TileDesc* tiles = nullptr;
     const WaveEntry* big_entries = nullptr;   // BIG launches: (source, row window, column window) per task
     const TileDesc* big_tasks = nullptr;
@@ -46,16 +49,16 @@ struct DevicePattern {           // device copies of Schedule arrays
 // lValues[a_dst[q]] = values[q]
 void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int64_t nnz,
                       hipStream_t stream);
-void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, double* L,
-                       hipStream_t stream);
+void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, bool subtrees,
+                       double* L, hipStream_t stream);
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
                        hipStream_t stream);
 
-void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, const double* L, double* x,
-                        int nrhs, int ldx, hipStream_t stream);
+void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
+                        double* x, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
@@ -64,7 +67,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
                          hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, int ticket, int wait_bias,
+                         double* xscratch, int nrhs, int ldx, int mode, int epoch0, int ticket, int wait_bias,
                          hipStream_t stream);
 void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
                      hipStream_t stream);

@@ -19,6 +19,31 @@ static int env_int(const char* name, int dflt) {
     return std::atoi(v);
 }
 
+// Subtrees of the etree that consist of eligible supernodes only and cost at most `cap`, as large as
+// possible: subtree[s] = its subtree (numbered from the last root down) or -1.  `parent` must be a
+// postordered forest (parent[s] > s); otherwise no subtree is formed.
+static int find_subtrees(const std::vector<int>& parent, const std::vector<uint8_t>& eligible,
+                         const std::vector<double>& cost, double cap, std::vector<int32_t>& subtree) {
+    const int ns = (int)parent.size();
+    subtree.assign(ns, -1);
+    std::vector<uint8_t> whole(eligible);  // the supernode and everything below it is eligible
+    std::vector<double> sub(cost);
+    for (int s = 0; s < ns; ++s) {
+        const int p = parent[s];
+        if (p < 0) continue;
+        if (p <= s) return 0;
+        if (!whole[s]) whole[p] = 0;
+        sub[p] += sub[s];
+    }
+    int count = 0;
+    for (int s = ns - 1; s >= 0; --s) {
+        const int p = parent[s];
+        if (p >= 0 && subtree[p] >= 0) subtree[s] = subtree[p];
+        else if (whole[s] && sub[s] <= cap) subtree[s] = count++;
+    }
+    return count;
+}
+
 void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
                     const uint8_t* active, Schedule& S, int compute_units) {
     S = Schedule();
@@ -212,6 +237,57 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             C.nupd = (int)((int64_t)S.upd.size() - C.upd0);
         }
     }
+    // --- subtrees walked by one workgroup each (see schedule.hpp).  Cost in flop equivalents: what the
+    // SMALL kernel executes plus a fixed amount per supernode and update (the small ones are latency);
+    // solves: panel entries.  The cap aims at kSubtreesPerCu subtrees per compute unit.
+    // A workgroup walks the supernodes of its subtree one after the other, siblings included, which level
+    // launches would run side by side: that only pays when the bottom of the etree saturates the device anyway
+    // (measured on MI355X: 45 000 narrow supernodes: factor -3 %, backward solve -7 %, forward solve -3 %;
+    // 1 300 .. 3 300 of them: +1 .. +9 % with subtrees), so by default subtrees are cut only where the
+    // eligible supernodes number at least kSubtreeMinPerSlot per subtree aimed at.
+    // PARSY_SUBTREES=k: always cut, aiming at k subtrees per compute unit (0: never; diagnostics, tests).
+    const bool forced = std::getenv("PARSY_SUBTREES") != nullptr;
+    const int per_cu = env_int("PARSY_SUBTREES", kSubtreesPerCu);
+    if (per_cu > 0) {
+        const int cus = compute_units > 0 ? compute_units : 256;
+        std::vector<uint8_t> elig(ns, 0);
+        auto cut = [&](std::vector<double>& cost, double min_cost, std::vector<int32_t>& subtree) {
+            double total = 0;
+            int64_t members = 0;
+            {   // everything that could be in a subtree at all
+                std::vector<int32_t> all;
+                find_subtrees(tree, elig, cost, 1e300, all);
+                for (int t = 0; t < ns; ++t)
+                    if (all[t] >= 0) {
+                        total += cost[t];
+                        ++members;
+                    }
+            }
+            if (!forced && members < (int64_t)kSubtreeMinPerSlot * per_cu * cus) return 0;
+            return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)per_cu * cus)), subtree);
+        };
+        if (!S.solve_only) {
+            S.chol_cost.assign(ns, 0.0);
+            for (int t = 0; t < ns; ++t) {
+                const SnDesc& C = S.csn[S.piece0[t]];
+                elig[t] = S.piece0[t + 1] - S.piece0[t] == 1 && is_small(C);
+                double c = 5e4 + (double)C.w * C.r * C.r;
+                for (int64_t u = C.upd0; u < C.upd0 + C.nupd && elig[t]; ++u)
+                    c += 1e4 + 2.0 * S.upd[u].K * (double)S.upd[u].m * S.upd[u].n1;
+                S.chol_cost[t] = c;
+            }
+            S.n_chol_subtrees = cut(S.chol_cost, kSubtreeMinCost, S.chol_subtree);
+        }
+        S.solve_cost.assign(ns, 0.0);
+        for (int t = 0; t < ns; ++t) {
+            elig[t] = S.sn[t].w <= kTile;
+            S.solve_cost[t] = 2e3 + (double)S.sn[t].w * S.sn[t].r;
+        }
+        S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree);
+    }
+    if (S.chol_subtree.empty()) S.chol_subtree.assign(ns, -1);
+    if (S.solve_subtree.empty()) S.solve_subtree.assign(ns, -1);
+
     // Updates that go through the BIG launches: wide descendants, and EVERY update of a split supernode's
     // pieces (what little reaches those from narrow descendants would otherwise be a TILES launch per
     // piece, in between the PUSH launches of the side stream).
@@ -445,15 +521,56 @@ void build_launches(Schedule& S, const uint8_t* active) {
         L.count = (int32_t)v.size();
         return L;
     };
+    // The active supernodes of every subtree in index order (descendants first), subtrees by falling cost:
+    // fn(supernode) appends to the kind's list; returns the (begin, end) pairs of the list positions.
+    auto subtree_ranges = [&](const std::vector<int32_t>& subtree, int count, const std::vector<double>& cost,
+                              auto&& position, auto&& append, std::vector<int32_t>& ranges) {
+        std::vector<std::vector<int32_t>> members((size_t)count);
+        std::vector<double> total((size_t)count, 0.0);
+        for (int t = 0; t < ns; ++t)
+            if (subtree[t] >= 0 && S.active[t]) {
+                members[(size_t)subtree[t]].push_back(t);
+                total[(size_t)subtree[t]] += cost[t];
+            }
+        std::vector<int32_t> order;
+        for (int k = 0; k < count; ++k)
+            if (!members[(size_t)k].empty()) order.push_back(k);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return total[(size_t)a] > total[(size_t)b]; });
+        for (int k : order) {
+            ranges.push_back(position());
+            for (int32_t t : members[(size_t)k]) append(t);
+            ranges.push_back(position());
+        }
+        return (int32_t)order.size();
+    };
+    S.small_ranges.clear();
+    S.solve_small_ranges.clear();
+    S.bsolve_ranges.clear();
+    S.bsolve_blocks.clear();
     for (int lev = 0; lev < S.cnlevels && !S.solve_only; ++lev) {
         level_begin.push_back(S.chol.size());
         bigs.clear();
         // ---- Cholesky -------------------------------------------------------------
+        if (lev == 0 && S.n_chol_subtrees > 0) {
+            // the subtrees of SMALL supernodes, one workgroup each: LDS and stage sized for the largest member
+            Launch L{kLaunchSmall, 0, 0, 0, 0, 0, 2, 0, -1, 0};
+            L.count = subtree_ranges(
+                S.chol_subtree, S.n_chol_subtrees, S.chol_cost, [&] { return (int32_t)S.small_list.size(); },
+                [&](int32_t t) {
+                    const SnDesc& T = S.csn[S.piece0[t]];
+                    S.small_list.push_back(S.piece0[t]);
+                    L.lds_bytes = std::max<int32_t>(L.lds_bytes, T.w * T.r * (int)sizeof(double));
+                    for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
+                        L.jb = std::max<int32_t>(L.jb, std::min<int64_t>((int64_t)S.upd[u].m * S.upd[u].K, 2048));
+                },
+                S.small_ranges);
+            if (L.count > 0) S.chol.push_back(L);
+        }
         {
             Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.clevelPtr[lev]; q < S.clevelPtr[lev + 1]; ++q) {
                 const int t = S.clevelSet[q];
-                if (!S.active[S.csn_real[t]]) continue;
+                if (!S.active[S.csn_real[t]] || S.chol_subtree[S.csn_real[t]] >= 0) continue;
                 const SnDesc& T = S.csn[t];
                 if (is_small(T)) {
                     S.small_list.push_back(t);
@@ -567,11 +684,22 @@ void build_launches(Schedule& S, const uint8_t* active) {
     for (int lev = 0; lev < S.nlevels; ++lev) {
         sbigs.clear();
         // ---- forward solve ----------------------------------------------------------
+        if (lev == 0 && S.n_solve_subtrees > 0) {
+            Launch L{kLaunchSolveSmall, 0, 0, 0, 0, 0, 2, 0, -1, 0};
+            L.count = subtree_ranges(
+                S.solve_subtree, S.n_solve_subtrees, S.solve_cost, [&] { return (int32_t)S.solve_small_list.size(); },
+                [&](int32_t t) {
+                    S.solve_small_list.push_back(t);
+                    L.jb = std::max<int32_t>(L.jb, S.sn[t].w);
+                },
+                S.solve_small_ranges);
+            if (L.count > 0) S.solve.push_back(L);
+        }
         {
             Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
-                if (!S.active[t]) continue;
+                if (!S.active[t] || S.solve_subtree[t] >= 0) continue;
                 if (S.sn[t].w <= kTile) {
                     S.solve_small_list.push_back(t);
                     L.jb = std::max<int32_t>(L.jb, S.sn[t].w);  // widest supernode of the launch
@@ -623,13 +751,13 @@ void build_launches(Schedule& S, const uint8_t* active) {
     // jb+1.. of its supernode; every workgroup of the launch must be resident) and one launch for the
     // supernodes of a single block; when the chain would not be resident, one launch per block-column
     // index from the last one down.
-    S.bsolve_blocks.clear();
     S.bsolve.clear();
+    auto in_level_launches = [&](int t) { return S.active[t] && S.solve_subtree[t] < 0; };
     for (int lev = S.nlevels - 1; lev >= 0; --lev) {
         int maxnb = 0, wide_blocks = 0;
         for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
             const int t = S.levelSet[q];
-            if (!S.active[t]) continue;
+            if (!in_level_launches(t)) continue;
             const int nbc = ceil_div(S.sn[t].w, kTile);
             maxnb = std::max(maxnb, nbc);
             if (nbc > 1) wide_blocks += nbc;
@@ -647,7 +775,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
             Launch Ln{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
-                if (S.active[t] && ceil_div(S.sn[t].w, kTile) == 1) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
+                if (in_level_launches(t) && ceil_div(S.sn[t].w, kTile) == 1) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
             }
             Ln.count = (int32_t)S.bsolve_blocks.size() - Ln.first;
             if (Ln.count > 0) S.bsolve.push_back(Ln);
@@ -657,11 +785,26 @@ void build_launches(Schedule& S, const uint8_t* active) {
             Launch Lb{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, jb, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
-                if (S.active[t] && ceil_div(S.sn[t].w, kTile) > jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
+                if (in_level_launches(t) && ceil_div(S.sn[t].w, kTile) > jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
             }
             Lb.count = (int32_t)S.bsolve_blocks.size() - Lb.first;
             if (Lb.count > 0) S.bsolve.push_back(Lb);
         }
+    }
+    if (S.n_solve_subtrees > 0) {
+        // the subtrees last: every ancestor outside them is final; inside, a workgroup walks from the subtree's
+        // root down (the forward order reversed)
+        Launch L{kLaunchBackBlock, 0, 0, 0, 0, 0, 2, 0, -1, 0};
+        std::vector<int32_t> members;
+        L.count = subtree_ranges(
+            S.solve_subtree, S.n_solve_subtrees, S.solve_cost,
+            [&] {
+                for (size_t q = members.size(); q-- > 0;) S.bsolve_blocks.push_back(PanelDesc{members[q], 0, 0, 0});
+                members.clear();
+                return (int32_t)S.bsolve_blocks.size();
+            },
+            [&](int32_t t) { members.push_back(t); }, S.bsolve_ranges);
+        if (L.count > 0) S.bsolve.push_back(L);
     }
     if (!S.solve_fix_list.empty())
         S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0, 0, -1, 0});
@@ -828,6 +971,42 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             if (std::abs(covered[(size_t)u] - want) > 1e-9 * want + 0.5)
                 fail("update " + std::to_string(u) + " of piece " + std::to_string(t) + " is not covered exactly once by its entries");
         }
+    }
+    // ---- subtree launches: what a member depends on is in the same subtree; a workgroup's run is in index
+    // order; every active SMALL supernode is factored by exactly one workgroup of one launch
+    for (int t = 0; t < nc; ++t) {
+        const int real = S.csn_real[t], st = S.chol_subtree[real];
+        if (st < 0) continue;
+        if (!is_small(S.csn[t])) fail("supernode " + std::to_string(real) + " of a subtree is not a SMALL one");
+        for (int64_t u = S.csn[t].upd0; u < S.csn[t].upd0 + S.csn[t].nupd; ++u)
+            if (S.chol_subtree[S.csn_real[S.upd_src[u]]] != st)
+                fail("supernode " + std::to_string(real) + " of a subtree is updated from outside the subtree");
+    }
+    {
+        std::vector<int> seen(nc, 0);
+        for (const Launch& l : S.chol) {
+            if (l.kind != kLaunchSmall) continue;
+            if (l.fused == 2) {
+                for (int b = l.first; b < l.first + l.count; ++b) {
+                    const int32_t q0 = S.small_ranges[2 * (size_t)b], q1 = S.small_ranges[2 * (size_t)b + 1];
+                    if (q0 < 0 || q1 <= q0 || q1 > (int32_t)S.small_list.size()) {
+                        fail("subtree launch: bad range " + std::to_string(b));
+                        continue;
+                    }
+                    for (int32_t q = q0; q < q1; ++q) {
+                        seen[S.small_list[q]]++;
+                        if (q > q0 && S.small_list[q] <= S.small_list[q - 1]) fail("subtree launch: a run is not in index order");
+                        if (S.chol_subtree[S.csn_real[S.small_list[q]]] != S.chol_subtree[S.csn_real[S.small_list[q0]]])
+                            fail("subtree launch: a run mixes subtrees");
+                    }
+                }
+            } else {
+                for (int q = l.first; q < l.first + l.count; ++q) seen[S.small_list[q]]++;
+            }
+        }
+        for (int t = 0; t < nc; ++t)
+            if (seen[t] != ((is_small(S.csn[t]) && S.active[S.csn_real[t]]) ? 1 : 0))
+                fail("SMALL supernode " + std::to_string(t) + " is in " + std::to_string(seen[t]) + " launches");
     }
     // ---- launch sequence: a side launch comes before the main-stream launches of the level that waits for it and
     // after every main-stream launch of the levels it waits for; the main stream never goes down a level

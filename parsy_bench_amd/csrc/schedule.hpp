@@ -23,6 +23,15 @@
 //           to a workgroup that has already started: no residency assumption, no deadlock.
 // The solve mirrors it (SOLVE_SMALL: width <= 64; wide supernodes: one chain launch per level,
 // or SOLVE_PANEL per block column + one SOLVE_FIXUP when the chain would not be resident).
+//
+// Subtree launches (the reference's w-partitions: one thread walks the supernodes of a partition in
+// order, cholesky/parallel_PB_Cholesky_05.h:66-84, triangularSolve/Triangular_BCSC.h:171-232): the
+// bottom of the etree -- whole subtrees made of supernodes that a single workgroup handles (SMALL /
+// width <= 64) -- is cut into subtrees of bounded cost, and ONE workgroup walks each of them supernode by
+// supernode in index order (descendants first; the backward solve in reverse).  Everything a supernode
+// of such a subtree depends on lies in the same subtree, so there is no hand-off and no level barrier
+// inside it: one launch replaces the SMALL launches of the narrow levels, in the factorization and in
+// both solves.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -105,7 +114,8 @@ struct Launch {
     int32_t level;         // etree level of the targets; side launches: level whose main-stream launches wait for it
     int32_t jb;            // SMALL: stage size; CHAIN: index of its ticket counter; SOLVE_PANEL / BACK: block column
     int32_t lds_bytes;     // dynamic LDS (SMALL)
-    int32_t fused;         // SOLVE_PANEL: 1 = chain launch of the whole level
+    int32_t fused;         // SOLVE_PANEL / BACK: 1 = chain launch of the whole level; SMALL, SOLVE_SMALL, BACK:
+                           // 2 = subtree launch (first / count: (begin, end) pairs in the kind's range array)
     int32_t side;          // 1: runs on the plan's side stream (TILES), 0: main stream
     int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only)
     int32_t early;         // TILES: always 1 (kept for the launch dumps)
@@ -123,6 +133,9 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
+constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
+constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
+constexpr int kSubtreeMinPerSlot = 2;     // ... and only where there are this many eligible supernodes per subtree
 
 struct Schedule {
     int n = 0, nsuper = 0, nlevels = 0;
@@ -158,6 +171,14 @@ struct Schedule {
     std::vector<int32_t> rows;      // lR
     std::vector<WaveEntry> wave_entries;  // update streams of the tile kernel, one list per (tile, phase, wave)
     std::vector<int64_t> wave_ptr;        // ... in the order [supernode][J][I][phase][wave], one closing entry each
+
+    // Subtrees walked by one workgroup each (PARSY_SUBTREES=0: none): per supernode its subtree or -1, and
+    // the cost estimate the subtrees were cut by (launches start the expensive ones first)
+    std::vector<int32_t> chol_subtree, solve_subtree;
+    std::vector<double> chol_cost, solve_cost;
+    int n_chol_subtrees = 0, n_solve_subtrees = 0;
+    // (begin, end) pairs into small_list / solve_small_list / bsolve_blocks, one per workgroup of a subtree launch
+    std::vector<int32_t> small_ranges, solve_small_ranges, bsolve_ranges;
 
     // Cholesky launch data
     std::vector<int32_t> small_list;

@@ -92,9 +92,18 @@ __device__ __forceinline__ void block_solve_apply16(const double* Dg, const doub
     }
 }
 
-// SOLVE_SMALL: one workgroup per supernode of width <= 64.
+// An entry of x that earlier supernodes of the same launch may have updated with atomics (subtree launches: the
+// same workgroup, ordered by a fence + barrier): read at the L2, where the atomics were performed.
+__device__ __forceinline__ double ld_x(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// SOLVE_SMALL: one workgroup per supernode of width <= 64 -- or, ranges != null (subtree launch), per subtree
+// of such supernodes: list[ranges[2b] .. ranges[2b+1]) one after the other (index order: descendants first;
+// what they subtract from the x of the later ones is complete when those start).
 __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restrict__ sn,
                                                           const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ ranges,
                                                           const int32_t* __restrict__ rows,
                                                           const double* __restrict__ L,
                                                           double* __restrict__ x, int nrhs, int ldx) {
@@ -102,7 +111,16 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
     __shared__ double invd[kTile];
     __shared__ double xs[kTile][kRhs];
     const int tid = threadIdx.x;
-    const SnDesc D = sn[list[blockIdx.x]];
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+  for (int qsn = q_begin; qsn < q_end; ++qsn) {
+    if (qsn > q_begin) {
+        // this thread's atomics are performed (they execute at the device's coherence point: waiting for their
+        // completion is all it takes -- no L2 write-back as an agent-scope fence would do) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // ... and so are everybody's; Dg / xs are free again
+    }
+    const SnDesc D = sn[list[qsn]];
     const int r = D.r, w = D.w;
     const double* __restrict__ G = L + D.px;
     const int32_t* __restrict__ ri = rows + D.pi;
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
         __syncthreads();
         for (int e = tid; e < wpad * nq; e += kThreads) {
             const int q = e / wpad, c = e - q * wpad;
-            xs[c][q] = (c < w) ? x[(int64_t)(q0 + q) * ldx + D.c0 + c] : 0.0;
+            xs[c][q] = (c < w) ? ld_x(&x[(int64_t)(q0 + q) * ldx + D.c0 + c]) : 0.0;
         }
         __syncthreads();
         const bool was_first = first;
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
                 if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + row], -acc[q]);
         }
     }
+  }
 }
 
 // SOLVE_SMALL for many right-hand sides (nrhs >= 16): up to 64 of them per pass over the panel, so that L is
@@ -171,6 +190,7 @@ static constexpr int kLdXs = kRhsM + 4; // row stride of xs in LDS
 template <int WMAX>  // widest supernode of the launch, rounded up to 16 / 32 / 64: sizes LDS and loops
 __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __restrict__ sn,
                                                                const int32_t* __restrict__ list,
+                                                               const int32_t* __restrict__ ranges,
                                                                const int32_t* __restrict__ rows,
                                                                const double* __restrict__ L,
                                                                double* __restrict__ x, int nrhs, int ldx) {
@@ -181,7 +201,14 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const SnDesc D = sn[list[blockIdx.x]];
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;   // subtree launch: as k_solve_small
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+  for (int qsn = q_begin; qsn < q_end; ++qsn) {
+    if (qsn > q_begin) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const SnDesc D = sn[list[qsn]];
     const int r = D.r, w = D.w;
     const double* __restrict__ G = L + D.px;
     const int32_t* __restrict__ ri = rows + D.pi;
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
         __syncthreads();  // inverses written / xs of the previous pass consumed
         for (int e = tid; e < WMAX * kRhsM; e += kThreads) {
             const int q = e / WMAX, c = e - q * WMAX;
-            xs[c * kLdXs + q] = (c < w && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + c] : 0.0;
+            xs[c * kLdXs + q] = (c < w && q < nq) ? ld_x(&x[(int64_t)(q0 + q) * ldx + D.c0 + c]) : 0.0;
         }
         __syncthreads();
         // ---- (A) wave `wave` solves its 16 right-hand sides
@@ -296,25 +323,28 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
             }
         }
     }
+  }
 }
 
-void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, const double* L, double* x,
-                        int nrhs, int ldx, hipStream_t stream) {
+void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
+                        double* x, int nrhs, int ldx, hipStream_t stream) {
     if (count <= 0) return;
+    // subtree launch: `first` counts (begin, end) pairs of solve_small_ranges, which index the whole list
+    const int32_t* list = subtrees ? P.solve_small_list : P.solve_small_list + first;
+    const int32_t* ranges = subtrees ? P.solve_small_ranges + 2 * first : nullptr;
     if (nrhs >= mrhs_min()) {
-        const int32_t* list = P.solve_small_list + first;
         if (wmax <= 16)
-            hipLaunchKernelGGL(k_solve_small_mrhs<16>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
-                               nrhs, ldx);
+            hipLaunchKernelGGL(k_solve_small_mrhs<16>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
+                               P.rows, L, x, nrhs, ldx);
         else if (wmax <= 32)
-            hipLaunchKernelGGL(k_solve_small_mrhs<32>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
-                               nrhs, ldx);
+            hipLaunchKernelGGL(k_solve_small_mrhs<32>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
+                               P.rows, L, x, nrhs, ldx);
         else
-            hipLaunchKernelGGL(k_solve_small_mrhs<64>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, P.rows, L, x,
-                               nrhs, ldx);
+            hipLaunchKernelGGL(k_solve_small_mrhs<64>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
+                               P.rows, L, x, nrhs, ldx);
     } else {
         hipLaunchKernelGGL(k_solve_small, dim3(count, std::min(kPassLanes, (nrhs + kRhs - 1) / kRhs)),
-                           dim3(kThreads), 0, stream, P.sn, P.solve_small_list + first, P.rows, L, x, nrhs, ldx);
+                           dim3(kThreads), 0, stream, P.sn, list, ranges, P.rows, L, x, nrhs, ldx);
     }
 }
 
@@ -836,22 +866,30 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            int nrhs, int ldx, int chain, int* __restrict__ flags,
                                                            int epoch0, int* __restrict__ info,
                                                            int* __restrict__ ticket, int wait_bias, int nblocks,
-                                                           int fstride) {
+                                                           int fstride, const int32_t* __restrict__ ranges) {
     // chain != 0: every block column of the wide supernodes of a level is in this launch (all
     // resident); block jb takes the x of blocks jb+1.. of its supernode as they are published
     // (xscratch, 8-byte agent-scope atomics both sides + a flag per block and pass).
+    // ranges != null (subtree launch, chain == 0): task b is the run pds[ranges[2b] .. ranges[2b+1]) -- a subtree
+    // of single-block supernodes from its root down; the workgroup reads its own earlier x (same CU, plain
+    // stores and loads ordered by the barrier between two supernodes).
     __shared__ double Dg[kTile * kLdDiag];
     __shared__ double invd[kTile];
     __shared__ double ts[kTile][NQ];
-    __shared__ int s_ok, s_task;
+    __shared__ int s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
     if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
     __syncthreads();
     // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on (one set of flags per lane)
     const int plane = s_task / nblocks;
-    const PanelDesc pd = pds[s_task - plane * nblocks];
+    const int task = s_task - plane * nblocks;
     flags += (int64_t)plane * fstride;
+    const int q_begin = ranges ? ranges[2 * task] : task;
+    const int q_end = ranges ? ranges[2 * task + 1] : q_begin + 1;
+  for (int qsn = q_begin; qsn < q_end; ++qsn) {
+    if (qsn > q_begin) __syncthreads();  // the x of the supernode before is stored; Dg / ts are free again
+    const PanelDesc pd = pds[qsn];
     const SnDesc D = sn[pd.sn];
     const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
     const double* __restrict__ G = L + D.px;
@@ -1025,22 +1063,28 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 __hip_atomic_store(&flags[D.dslot + pd.jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+  }
 }
 
+// mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts
+// (begin, end) pairs of bsolve_ranges, which index the whole block list)
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int chain, int epoch0, int ticket, int wait_bias,
+                         double* xscratch, int nrhs, int ldx, int mode, int epoch0, int ticket, int wait_bias,
                          hipStream_t stream) {
     if (count <= 0) return;
+    const int chain = mode == 1;
+    const PanelDesc* pds = mode == 2 ? P.bsolve_blocks : P.bsolve_blocks + first;
+    const int32_t* ranges = mode == 2 ? P.bsolve_ranges + 2 * first : nullptr;
     const int lanes = nrhs == 1 ? 1 : std::min(kPassLanes, (nrhs + 3) / 4);
     const dim3 grid = chain ? dim3(count * lanes) : dim3(count, lanes);
     if (nrhs == 1)
-        hipLaunchKernelGGL(k_bsolve_block<1>, grid, dim3(kThreads), 0, stream, P.sn,
-                           P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
+        hipLaunchKernelGGL(k_bsolve_block<1>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
+                           nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
+                           P.flag_stride, ranges);
     else
-        hipLaunchKernelGGL(k_bsolve_block<4>, grid, dim3(kThreads), 0, stream, P.sn,
-                           P.bsolve_blocks + first, P.rows, L, x, xscratch, nrhs, ldx, chain, P.flags, epoch0,
-                           P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
+        hipLaunchKernelGGL(k_bsolve_block<4>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
+                           nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
+                           P.flag_stride, ranges);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.

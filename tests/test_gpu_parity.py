@@ -582,3 +582,104 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
                                   sym.nsuper, xs, sym.nlevels, sym.levelPtr, sym.levelSet, 1)
     assert rc == 1 and np.abs(xs - 1.0).max() < 1e-9
     api.dropin_reset()
+
+
+# ---------------------------------------------------------------------------
+# device helpers of the C ABI
+# ---------------------------------------------------------------------------
+def test_rhs_ones_device_is_the_references_rhsInitBlocked(api, oracle):
+    """parsy_rhs_ones_device: b = L 1 on the stored structure (common/Util.h:277-288), against the oracle's
+    restatement, on a factor with supernodes of every kind."""
+    import torch
+    A, perm, sym = problem("lap30")
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    dev = torch.device("cuda", 0)
+    L = torch.from_numpy(lv).to(dev)
+    b = torch.full((sym.n,), float("nan"), dtype=torch.float64, device=dev)
+    plan.rhs_ones_device(L.data_ptr(), b.data_ptr(), 0)
+    torch.cuda.synchronize()
+    want = oracle.rhs_init_blocked(sym, lv)
+    assert np.abs(b.cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_copy_segments_device_packs_and_unpacks(api):
+    import torch
+    from parsy_bench_amd import _native as N
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    src = torch.from_numpy(rng.standard_normal(100_000)).to(dev)
+    ln = rng.integers(0, 70, size=3000).astype(np.int32)          # some empty runs too
+    src_off = np.sort(rng.choice(100_000 - 70, size=3000, replace=False)).astype(np.int64)
+    dst_off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
+    total = int(ln.sum())
+    t = [torch.from_numpy(a).to(dev) for a in (dst_off, src_off, ln)]
+    packed = torch.zeros(total, dtype=torch.float64, device=dev)
+    assert N.lib().parsy_copy_segments_device(packed.data_ptr(), src.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+                                              t[2].data_ptr(), len(ln), 0) == 0
+    torch.cuda.synchronize()
+    h = src.cpu().numpy()
+    want = np.concatenate([h[o:o + l] for o, l in zip(src_off, ln)])
+    assert np.array_equal(packed.cpu().numpy(), want)
+    back = torch.zeros_like(src)
+    assert N.lib().parsy_copy_segments_device(back.data_ptr(), packed.data_ptr(), t[1].data_ptr(), t[0].data_ptr(),
+                                              t[2].data_ptr(), len(ln), 0) == 0
+    torch.cuda.synchronize()
+    mask = np.zeros(100_000, bool)
+    for o, l in zip(src_off, ln):
+        mask[o:o + l] = True
+    got = back.cpu().numpy()
+    assert np.array_equal(got[mask], h[mask]) and not got[~mask].any()
+    assert N.lib().parsy_copy_segments_device(None, None, None, None, None, 0, 0) == 0   # nothing to do
+    assert N.lib().parsy_copy_segments_device(None, src.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                              5, 0) != 0                                  # null destination
+
+
+# ---------------------------------------------------------------------------
+# subtree launches (the reference's w-partitions: one workgroup walks a subtree of narrow supernodes in order,
+# parallel_PB_Cholesky_05.h:66-84, Triangular_BCSC.h:171-232), forced onto small inputs with PARSY_SUBTREES
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
+@pytest.mark.parametrize("per_cu", [1, 16])
+def test_subtree_launches_match_level_launches(api, oracle, monkeypatch, name, per_cu):
+    A, sym, plan0, lv0, lo = _factor_both(api, oracle, name)   # level launches, compared with the oracle
+    assert plan0.info["chol_subtrees"] == 0
+    monkeypatch.setenv("PARSY_SUBTREES", str(per_cu))
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    assert info["chol_subtrees"] > 0 and info["solve_subtrees"] > 0
+    if per_cu == 1:
+        assert info["solve_subtree_supernodes"] > info["solve_subtrees"]   # walks of more than one supernode
+        assert info["solve_launches"] <= plan0.info["solve_launches"]
+        assert info["backsolve_launches"] <= plan0.info["backsolve_launches"]
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    assert np.array_equal(lv, lv0)   # same kernels, same order of sums per entry: bitwise
+    rng = np.random.default_rng(21)
+    for nrhs in (1, 5, 64, 70):
+        B = rng.standard_normal((sym.n, nrhs))
+        X, _ = plan.solve(lo, B if nrhs > 1 else B[:, 0])
+        Xb, _ = plan.solve2(lo, B, forward=False)
+        assert plan.solve_status() == 0
+        X = X.reshape(sym.n, -1)
+        for q in range(0, nrhs, 7):
+            xo = oracle.blocked_lsolve(sym, lo, B[:, q], "serial")
+            assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+            xb = oracle.blocked_ltsolve(sym, lo, B[:, q])
+            assert np.abs(Xb[:, q] - xb).max() <= SOLVE_TOL * max(1.0, np.abs(xb).max())
+
+
+def test_subtree_launches_report_a_bad_pivot(api, oracle, monkeypatch):
+    """A non-positive pivot inside a subtree: same failing column as the reference's (first one in column order)."""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("ex15")
+    monkeypatch.setenv("PARSY_SUBTREES", "1")
+    plan = api.Plan(sym, 0)
+    assert plan.info["chol_subtree_supernodes"] > 0
+    vals = sym.A2x.copy()
+    col = int(sym.super[0])                      # first column of a leaf: surely inside a subtree
+    assert sym.A2i[sym.A2p[col]] == col          # the diagonal entry comes first in its column
+    vals[sym.A2p[col]] = -1.0
+    lv, _ = plan.factor(vals)
+    ok, lo, bad = oracle.cholesky_05(sym, vals, I.trivial_hlevel(sym))
+    assert not ok and plan.status() == col + 1

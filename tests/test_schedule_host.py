@@ -35,7 +35,7 @@ def test_plan_counts_match_the_pattern(name):
         assert info["update_flops"] == pytest.approx(float((K * n1 * (n1 + 1) + 2 * K * (m - n1) * n1).sum()), rel=1e-12)
         assert info["relpos_len"] == int(m.sum())
         assert info["reread_bytes"] == pytest.approx(float(8 * (K * m).sum()), rel=1e-12)
-        assert info["chol_launches"] >= sym.nlevels and info["solve_launches"] >= sym.nlevels
+        assert info["chol_launches"] >= 1 and info["solve_launches"] >= 1  # (levels / subtrees: test below)
     finally:
         N.lib().parsy_plan_destroy(h)
 
@@ -162,5 +162,46 @@ def test_cholesky_view_is_consistent(monkeypatch, name, piece, mink, group):
         for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
             assert N.lib().parsy_plan_set_active(h, N.ptr(np.ascontiguousarray(mask))) == 0
             assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+    finally:
+        N.lib().parsy_plan_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "lap30"])
+def test_subtree_launches_replace_the_narrow_levels(name, monkeypatch):
+    """The bottom of the etree goes to subtree launches (one workgroup walks a whole subtree of narrow supernodes:
+    the reference's w-partitions, parallel_PB_Cholesky_05.h:66-84, Triangular_BCSC.h:171-232).  Host checks: the plan
+    is consistent (parsy_plan_check: members only depend on their own subtree, every SMALL supernode is launched once),
+    there are fewer launches than with level launches only (PARSY_SUBTREES=0), and a shard's launches stay consistent."""
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_SUBTREES", "0")
+    h0, levels_only = host_plan(sym)
+    N.lib().parsy_plan_destroy(h0)
+    assert levels_only["chol_subtrees"] == 0 and levels_only["solve_subtrees"] == 0
+    assert levels_only["chol_launches"] >= sym.nlevels and levels_only["solve_launches"] >= sym.nlevels
+    # small inputs get no subtrees by default (level launches are faster while the device is not saturated)
+    monkeypatch.delenv("PARSY_SUBTREES")
+    h1, by_default = host_plan(sym)
+    N.lib().parsy_plan_destroy(h1)
+    assert by_default["chol_subtrees"] == 0 and by_default["solve_launches"] == levels_only["solve_launches"]
+    monkeypatch.setenv("PARSY_SUBTREES", "2")   # forced: aim at 2 subtrees per compute unit
+    h, info = host_plan(sym)
+    try:
+        assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+        assert info["chol_subtrees"] > 0 and info["solve_subtrees"] > 0
+        assert info["chol_subtree_supernodes"] >= info["chol_subtrees"]
+        assert info["solve_subtree_supernodes"] > info["solve_subtrees"]      # they do merge supernodes
+        assert info["chol_launches"] <= levels_only["chol_launches"]
+        assert info["solve_launches"] <= levels_only["solve_launches"]
+        assert info["backsolve_launches"] <= levels_only["backsolve_launches"]
+        # a shard (every other subtree of a 2-way cut): only active supernodes are launched, still each exactly once
+        from parsy_bench_amd import multigpu as MG
+        cut = MG.cut_subtrees(sym, 2)
+        for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert N.lib().parsy_plan_set_active(h, N.ptr(m)) == 0, N.last_error()
+            assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+            pi = N.PlanInfo()
+            N.lib().parsy_plan_get_info(h, C.byref(pi))
+            assert pi.solve_subtree_supernodes <= int(m.sum())
     finally:
         N.lib().parsy_plan_destroy(h)
