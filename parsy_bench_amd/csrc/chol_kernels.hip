@@ -61,23 +61,31 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 
 // ---------------------------------------------------------------------------
 // POTRF of a 64x64 diagonal block by one 256-thread workgroup, register-blocked: thread
-// (ti, tj) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers.  Four columns per step:
-//   (1) the owner of the 4x4 diagonal micro-block broadcasts it through LDS,
-//   (2) every thread of that block column factors the micro-block itself (4 pivots in
-//       registers) and solves its own 4x4 block against it, then publishes the 4 new columns,
-//   (3) everybody applies the rank-4 update to its block.
+// (ti, tj) = (tid & 15, tid >> 4) keeps the 4x4 block rows 4ti.., cols 4tj.. in registers, so wave q
+// holds block columns 4q..4q+3 (all 64 rows).  Four columns per step tjj:
+//   (1) the wave that holds block column tjj takes the 4x4 diagonal micro-block from its owner lane
+//       (v_readlane: the values become wave-uniform) and factors it (4 pivots, redundantly);
+//   (2) the threads of block column tjj solve their own 4x4 block against it and publish the 4 new
+//       columns in LDS (two buffers, alternating: ONE workgroup barrier per step);
+//   (3) everybody applies the rank-4 update to its block -- the wave that holds the next block column
+//       then goes straight on to (1) while the others are still updating.
+// The published columns are laid out so that the 16 lanes along ti read / write consecutive 16-byte
+// pairs (rows 4t+2h, 4t+2h+1 of column k at pair index (2k + h) * 16 + t): no bank conflicts.
 // inv_out (64 doubles of LDS, optional) receives the reciprocals of the factor's diagonal.
-// Two barriers per 4 columns.  Entries outside the block (nb < 64) must be an identity so the
-// loop is uniform; strictly-upper entries pick up garbage that is never stored.  `scr` is
-// 16 + 64*5 doubles of LDS.  On return a[][] holds the factor; `bad` receives (1-based) the
-// first column whose pivot was not positive.  Pivots use rsqrt (1/sqrt(d) directly: the
-// divide-after-sqrt chain is the critical path of every block step).
+// Entries outside the block (nb < 64) must be an identity so the loop is uniform; strictly-upper
+// entries pick up garbage that is never stored.  `scr` is kPotrfScratch doubles of LDS, 16-byte
+// aligned.  On return a[][] holds the factor; `bad` receives (1-based) the first column whose pivot
+// was not positive.  Pivots use rsqrt (1/sqrt(d) directly: the divide-after-sqrt chain is the
+// critical path of every block step).
 // ---------------------------------------------------------------------------
-static constexpr int kPotrfScratch = 16 + kTile * 5;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+static constexpr int kPotrfScratch = 2 * 4 * kTile;
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
 __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restrict__ scr, int ti, int tj,
                                              int nb, int& bad, double* __restrict__ inv_out = nullptr) {
-    double* __restrict__ bufD = scr;        // 4x4 micro-block, row-major
-    double* __restrict__ bufP = scr + 16;   // [64 rows][4 cols], ld 5
     const bool lower = ti >= tj;
     bad = 0;
 #ifdef PARSY_STAMPS
@@ -87,62 +95,64 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
 #endif
     const int nsteps = (nb + 3) / 4;  // panels beyond the block are an identity: nothing to do
     for (int tjj = 0; tjj < nsteps; ++tjj) {
+        double2_t* __restrict__ pub = reinterpret_cast<double2_t*>(scr) + (tjj & 1) * (2 * kTile);
         PPROBE(0);
-        if (ti == tjj && tj == tjj) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) bufD[ri * 4 + ci] = a[ri][ci];
-        }
-        __syncthreads();
-        PPROBE(1);
-        if (tj == tjj && lower) {
-            double m[4][4], l[4][4], inv[4];
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) m[ri][ci] = bufD[ri * 4 + ci];
+        if ((tj >> 2) == (tjj >> 2)) {  // wave-uniform: the wave of block column tjj
+            const int src = __builtin_amdgcn_readfirstlane((tjj & 3) * 16 + tjj);  // lane of thread (tjj, tjj)
+            double l[4][4], inv[4];
+            int nonpos = 0;  // pivots of this step that were not positive (bit jj)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                double d = m[jj][jj];
+                double d = readlane_f64(a[jj][jj], src);
 #pragma unroll
                 for (int k = 0; k < jj; ++k) d = fma(-l[jj][k], l[jj][k], d);
-                if (!(d > 0.0) && bad == 0 && 4 * tjj + jj < nb) bad = 4 * tjj + jj + 1;
-                inv[jj] = rsqrt(d);
+                nonpos |= (d > 0.0) ? 0 : (1 << jj);
+                // 1/sqrt(d): hardware estimate + one correction step (the library's sequence without its
+                // fix-ups for zero / infinite arguments: such a pivot is reported, its factor is not used)
+                const double y0 = __builtin_amdgcn_rsq(d);
+                const double e = fma(-d * y0, y0, 1.0);
+                inv[jj] = fma(y0 * e, fma(e, 0.375, 0.5), y0);
                 l[jj][jj] = d * inv[jj];
 #pragma unroll
                 for (int ii = jj + 1; ii < 4; ++ii) {
-                    double v = m[ii][jj];
+                    double v = readlane_f64(a[ii][jj], src);
 #pragma unroll
                     for (int k = 0; k < jj; ++k) v = fma(-l[ii][k], l[jj][k], v);
                     l[ii][jj] = v * inv[jj];
                 }
             }
-            if (ti == tjj) {
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                    for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
-                if (inv_out) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) inv_out[4 * tjj + jj] = (4 * tjj + jj < nb) ? inv[jj] : 1.0;
-                }
-            } else {
-                // X l' = A  (4x4, row by row)
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        double v = a[ri][jj];
-#pragma unroll
-                        for (int k = 0; k < jj; ++k) v = fma(-a[ri][k], l[jj][k], v);
-                        a[ri][jj] = v * inv[jj];
-                    }
+            PPROBE(1);
+            if (nonpos && bad == 0 && tj == tjj && lower) {
+                const int jj = __builtin_ctz(nonpos);
+                if (4 * tjj + jj < nb) bad = 4 * tjj + jj + 1;
             }
+            if (tj == tjj && lower) {
+                if (ti == tjj) {
 #pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
+                    for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci) bufP[(4 * ti + ri) * 5 + ci] = a[ri][ci];
+                        for (int ci = 0; ci <= ri; ++ci) a[ri][ci] = l[ri][ci];
+                    if (inv_out) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) inv_out[4 * tjj + jj] = (4 * tjj + jj < nb) ? inv[jj] : 1.0;
+                    }
+                } else {
+                    // X l' = A  (4x4, row by row)
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            double v = a[ri][jj];
+#pragma unroll
+                            for (int k = 0; k < jj; ++k) v = fma(-a[ri][k], l[jj][k], v);
+                            a[ri][jj] = v * inv[jj];
+                        }
+                }
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) pub[(2 * ci + h) * 16 + ti] = double2_t{a[2 * h][ci], a[2 * h + 1][ci]};
+            }
         }
         PPROBE(2);
         __syncthreads();
@@ -150,11 +160,14 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
         if (lower && tj > tjj) {
             double li[4][4], lc[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    li[q][k] = bufP[(4 * ti + q) * 5 + k];
-                    lc[q][k] = bufP[(4 * tj + q) * 5 + k];
+                for (int h = 0; h < 2; ++h) {
+                    const double2_t x = pub[(2 * k + h) * 16 + ti], y = pub[(2 * k + h) * 16 + tj];
+                    li[2 * h][k] = x[0];
+                    li[2 * h + 1][k] = x[1];
+                    lc[2 * h][k] = y[0];
+                    lc[2 * h + 1][k] = y[1];
                 }
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
@@ -597,7 +610,7 @@ static constexpr unsigned long long kSpinTicks = 200000000ull;  // 2 s of the 10
 //   all waiters give up and parsy_factor_status() report < 0.
 struct TileLds {  // LDS of one workgroup of the tile kernel
     double T[4][kSub * kLdSub];       // the tile, one 32x33 sub-tile per wave
-    double colbuf[kPotrfScratch];     // POTRF scratch
+    alignas(16) double colbuf[kPotrfScratch];  // POTRF scratch
     double dgbuf[4 * kSub * kLdSub];  // diagonal block + its 16x16 inverses (TRSM) / the walker's next diagonal tile
     double s_invd[kTile];             // reciprocals of the diagonal of the block being solved against
     int32_t s_ok, s_task, s_cnt, s_cnt2;
