@@ -64,6 +64,7 @@ void launch_solve_panel(const DevicePattern& P, int first, int count, const doub
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream);
+hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
                          hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,

@@ -641,6 +641,211 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
     }
 }
 
+// SOLVE_CHAIN for ONE right-hand side: a dataflow of single waves, no workgroup barrier (but one when the
+// workgroup starts) and no flag in memory.
+// A workgroup = eight waves = one of the launch's 256-row chunks, taken from the launch's ticket counter (tickets
+// follow the row order, so whatever a wave waits for belongs to a workgroup that has started).  Two waves share
+// each 64-row block of the chunk (lane = row): wave p of the pair streams the block columns jb = p, p + 2, ... to
+// the left of its rows -- takes x_jb (64 values), applies its 64 x 64 piece of L (all 64 loads of a lane's row
+// issued BEFORE the wait) -- and keeps its part of the rows' running sum in registers.  A wave has 32 KiB of L in
+// flight, so a row block streams at twice that: what bounds a long chain is how fast the rows right below the
+// diagonal get through their block columns, not only the hand-off.  When the rows are diagonal block jb of the
+// supernode, wave 1 hands its part to wave 0 (LDS), which forms t = x - sum, x_jb = inv(L_jj) t (inverse diagonal
+// block staged in LDS when the wave starts: lower triangle, packed) and publishes the 64 values.
+// The hand-off is the data itself.  Across workgroups: xscratch is armed with a signalling-NaN pattern (kXArmed)
+// before the solve and a value is valid as soon as it differs from it -- every value is one 8-byte agent-scope
+// atomic, so the producer neither waits for its stores nor raises a flag, and the consumer's poll (lane c polls
+// value c) is the load of the data: one memory round trip per hand-off instead of three.  Inside a workgroup --
+// three hand-offs of the critical path out of four, diagonal block to next diagonal block -- x_jb goes through
+// LDS (one flag per row block, raised after its 64 values are written).
+// Arithmetic never produces the armed pattern (results of operations on NaNs are quiet NaNs); should the data
+// hold it, the wait times out and the solve's status word reports it, like any other abandoned hand-off.
+// Rows below the supernode's own columns are scattered at the end with atomics, as in the other kernels.
+static constexpr unsigned kXArmedWord = 0xFFF7A5A5u;   // both 32-bit halves of the armed pattern
+static constexpr long long kXArmed = (long long)(((unsigned long long)kXArmedWord << 32) | kXArmedWord);
+static constexpr int kInvPacked = kTile * (kTile + 1) / 2;   // packed lower triangle of an inverse diagonal block
+static constexpr int kChainThreads = 2 * kSolveRows;         // eight waves
+static constexpr int kChainFewChunks = 384;                  // launches of at most this many chunks: top of the tree
+
+// RB = 64-row blocks per workgroup (8 / RB waves share each of them): 4 where a launch has plenty of chunks, 2
+// where it is the top of the tree -- few, very wide supernodes: twice the workgroups (a CU sustains about
+// 45 GB/s of this access pattern, so the number of CUs that stream is what bounds a launch of few chunks) and
+// twice the waves behind every row block, for half of the diagonal-to-diagonal hand-offs inside a workgroup.
+template <int RB>
+__global__ __launch_bounds__(kChainThreads, 1) void k_solve_chain_w(const SnDesc* __restrict__ sn,
+                                                                    const PanelDesc* __restrict__ pds,
+                                                                    const int32_t* __restrict__ rows,
+                                                                    const double* __restrict__ L,
+                                                                    const double* __restrict__ dinv,
+                                                                    double* __restrict__ x, double* __restrict__ xscratch,
+                                                                    int* __restrict__ info, int* __restrict__ ticket,
+                                                                    int wait_bias) {
+    constexpr int G = kChainThreads / 64 / RB;   // waves per row block
+    constexpr int kParts = kSolveRows / kTile / RB;   // workgroups per 256-row chunk of the launch
+    __shared__ double s_inv[RB][kInvPacked + 1];   // column c of the inverse from row c on, at c*64 - c(c-1)/2
+                                                   // (+ one slot for the lanes above it)
+    __shared__ double s_x[RB * G][kTile];          // per wave: x_jb taken from memory / t
+    __shared__ double s_part[RB][G - 1][kTile];    // the other waves' parts of a diagonal block's sums, for wave 0
+    __shared__ double s_pub[RB][kTile];            // x of a diagonal block, for the waves of the blocks after it
+    __shared__ int s_parts_in[RB], s_ready[RB];
+    __shared__ int s_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = wave / G, p = wave % G;   // row block of the workgroup, wave of its group
+    if (threadIdx.x == 0) s_task = atomicAdd(ticket, 1);
+    if (threadIdx.x < RB) {
+        s_ready[threadIdx.x] = 0;
+        s_parts_in[threadIdx.x] = 0;
+    }
+    __syncthreads();   // (the only one: from here on the waves go their own way)
+    const PanelDesc pd = pds[s_task / kParts];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w;
+    const int row0_wg = pd.row0 + (s_task % kParts) * (RB * kTile);
+    const int row0 = row0_wg + kTile * rb;
+    if (row0 >= r) return;   // (the last chunk of a panel may have fewer than four blocks)
+    const int nbc = (w + kTile - 1) / kTile;
+    const double* __restrict__ G_ = L + D.px;
+    const int k = row0 + lane;          // this lane's panel row
+    const bool kv = k < r;
+    const bool is_diag = row0 < w;      // the rows hold diagonal block row0 / 64
+    const int nblk = is_diag ? row0 / kTile : nbc;   // block columns to the left of the rows
+    const int jb_wg = row0_wg / kTile;               // block columns from here on belong to this workgroup's waves
+    double* __restrict__ xs = s_x[wave];
+    double* __restrict__ inv = s_inv[rb];
+
+    double lv[kTile];
+    // every load is unconditional (no branch per column): rows past the panel read its last row (their sum is
+    // never used), columns past the supernode read its last column again (their x is zero).  The address walks
+    // from column to column by the panel's stride: one vector add per load, nothing else.
+    const char* __restrict__ lane_base = reinterpret_cast<const char*>(G_ + min(k, r - 1));
+    const int64_t col_stride = (int64_t)r * (int64_t)sizeof(double);
+    auto load_block = [&](int jb) {
+        const int cb = jb * kTile, last = w - 1 - cb;   // columns 0..last of the block exist (last >= 0)
+        const char* pcol = lane_base + (int64_t)cb * col_stride;
+#pragma unroll
+        for (int c = 0; c < kTile; ++c) {
+            lv[c] = *reinterpret_cast<const double*>(pcol);
+            pcol += (c < last) ? col_stride : 0;
+        }
+    };
+    auto inv_at = [&](int c) { return lane >= c ? c * kTile - c * (c - 1) / 2 + (lane - c) : kInvPacked; };
+    auto gave_up = [&](unsigned long long t0, int& spins) {   // bounded waits: one timeout ends every wait of the solve
+        if ((++spins & 15) != 0) return false;
+        return wall_clock64() - t0 > kSolveSpinTicks ||
+               __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0;
+    };
+    auto wait_lds = [&](int* flag, int want) {   // a counter of this workgroup's LDS
+        const unsigned long long t0 = wall_clock64();
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want || wait_bias != 0) {
+            if (gave_up(t0, spins)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return true;
+    };
+    if (is_diag && p == 0) {
+        // inverse diagonal block -> LDS (off the critical path: the wave starts well before its turn)
+        const double* __restrict__ src = dinv + (int64_t)(D.dslot + row0 / kTile) * (kTile * kTile);
+#pragma unroll
+        for (int c = 0; c < kTile; ++c)
+            lv[c] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(src + c * kTile) + (unsigned)lane * 8u);
+#pragma unroll
+        for (int c = 0; c < kTile; ++c) inv[inv_at(c)] = lv[c];
+    }
+    const double xv = (is_diag && p == 0 && k < w) ? x[D.c0 + k] : 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int jb = p; jb < nblk; jb += G) {
+        const int cb = jb * kTile, wbk = min(kTile, w - cb);
+        load_block(jb);   // all 64 loads of the lane's row are issued BEFORE the wait for x_jb
+        const double* __restrict__ xb = xs;
+        if (jb >= jb_wg) {
+            // ---- x_jb comes from a wave of this workgroup: LDS
+            if (!wait_lds(&s_ready[jb - jb_wg], 1)) {
+                if (lane == 0) atomicMin(info, -1);   // (the result is wrong and reported; nobody may hang)
+                return;
+            }
+            xb = s_pub[jb - jb_wg];
+        } else {
+            // ---- x_jb comes from another workgroup: lane c polls value c of the armed buffer
+            const long long* __restrict__ src = reinterpret_cast<const long long*>(xscratch + D.c0 + cb) + lane;
+            long long bits = 0;
+            const unsigned long long t0 = wall_clock64();
+            int spins = 0;
+            for (;;) {
+                bits = lane < wbk ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                if (__all(bits != kXArmed && wait_bias == 0)) break;
+                if (gave_up(t0, spins)) {
+                    if (lane == 0) atomicMin(info, -1);
+                    return;
+                }
+                // the rows right below the diagonal wait for the newest x: the critical path; the rows further
+                // down are never critical and poll at leisure
+                if (is_diag && jb >= nblk - G) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_wave_barrier();
+            xs[lane] = __longlong_as_double(bits);
+            __builtin_amdgcn_wave_barrier();   // (one wave: LDS operations complete in order)
+        }
+#pragma unroll
+        for (int c = 0; c < kTile; c += 4) {
+            // (16 columns at a time: all 64 LDS reads hoisted above the products would not fit beside lv)
+            if ((c & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+            a0 = fma(lv[c], xb[c], a0);
+            a1 = fma(lv[c + 1], xb[c + 1], a1);
+            a2 = fma(lv[c + 2], xb[c + 2], a2);
+            a3 = fma(lv[c + 3], xb[c + 3], a3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    if (is_diag) {
+        const int wbk = min(kTile, w - row0);
+        if (p != 0) {
+            // this wave's part of the sums -> wave 0 of the group
+            s_part[rb][p - 1][lane] = acc;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_fetch_add(&s_parts_in[rb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (!wait_lds(&s_parts_in[rb], G - 1)) {
+                if (lane == 0) atomicMin(info, -1);
+                return;
+            }
+            double others = 0.0;
+#pragma unroll
+            for (int q = 0; q < G - 1; ++q) others += s_part[rb][q][lane];
+            __builtin_amdgcn_wave_barrier();
+            xs[lane] = (lane < wbk) ? xv - (acc + others) : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < kTile; c += 2) {
+                if ((c & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                const double d0 = inv[inv_at(c)], d1 = inv[inv_at(c + 1)];
+                s0 = fma(c <= lane ? d0 : 0.0, xs[c], s0);
+                s1 = fma(c + 1 <= lane ? d1 : 0.0, xs[c + 1], s1);
+            }
+            const double xi = (lane < wbk) ? s0 + s1 : 0.0;
+            // to the waves of this workgroup through LDS (flag after the data) ...
+            s_pub[rb][lane] = xi;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(&s_ready[rb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ... to everybody else through the armed buffer, and into x
+            if (lane < wbk) {
+                __hip_atomic_store(&xscratch[D.c0 + row0 + lane], xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x[D.c0 + row0 + lane] = xi;
+            }
+            // a last diagonal block narrower than 64: the other rows of the block lie below the supernode's columns
+            // and take this block column too
+            if (kv && k >= w)
+                for (int c = 0; c < wbk; ++c) acc = fma(G_[(int64_t)(row0 + c) * r + k], s_pub[rb][c], acc);
+        }
+    }
+    // rows below the supernode's columns: each wave of the group scatters its own part of the sums
+    if (kv && k >= w) atomicAdd(&x[rows[D.pi + k]], -acc);
+}
+
 // SOLVE_CHAIN for many right-hand sides (nrhs >= 16): the same protocol (256-row chunks, pull form, the owner of a
 // block column publishes x_jb, tickets, flags per lane of passes) with 64 right-hand sides per pass over the panel
 // and every product on v_mfma_f64_16x16x4_f64, so that L is read once per 64 right-hand sides.  Wave v of a chunk
@@ -826,6 +1031,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* 
     }
 }
 
+// One right-hand side: the chain launches hand x over through xscratch itself (k_solve_chain_w); every entry must
+// hold the armed pattern when the solve starts.
+hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream) {
+    return hipMemsetD32Async((hipDeviceptr_t)xscratch, (int)kXArmedWord, (size_t)n * 2, stream);
+}
+
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream) {
@@ -839,11 +1050,16 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
     }
     const int nq = nrhs == 1 ? 1 : kRhs;
     const int lanes = std::min(kPassLanes, (nrhs + nq - 1) / nq);
-    if (nrhs == 1)
-        hipLaunchKernelGGL(k_solve_chain<1>, dim3(count), dim3(kThreads), 0, stream, P.sn, P.solve_panels + first,
-                           P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.sinfo, P.stickets + ticket,
-                           wait_bias, count, P.flag_stride);
-    else
+    if (nrhs == 1) {   // (xscratch was armed by the caller: solve_arm_handoff)
+        if (count <= kChainFewChunks)
+            hipLaunchKernelGGL(k_solve_chain_w<2>, dim3(2 * count), dim3(kChainThreads), 0, stream, P.sn,
+                               P.solve_panels + first, P.rows, L, dinv, x, xscratch, P.sinfo, P.stickets + ticket,
+                               wait_bias);
+        else
+            hipLaunchKernelGGL(k_solve_chain_w<4>, dim3(count), dim3(kChainThreads), 0, stream, P.sn,
+                               P.solve_panels + first, P.rows, L, dinv, x, xscratch, P.sinfo, P.stickets + ticket,
+                               wait_bias);
+    } else
         hipLaunchKernelGGL(k_solve_chain<kRhs>, dim3(count * lanes), dim3(kThreads), 0, stream, P.sn,
                            P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0,
                            P.sinfo, P.stickets + ticket, wait_bias, count, P.flag_stride);
