@@ -392,8 +392,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
     // one right-hand side: the chain launches hand x over through xscratch itself
     if (nrhs == 1 && pl->S.n_solve_wide > 0) PARSY_HIP(solve_arm_handoff(pl->xscratch, ldx, stream));
-    launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size(), pl->S.solve_wide_max_blocks, d_L, pl->dinv,
-                        stream);
+    launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -32,7 +32,7 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
-    const int32_t* solve_wide_list = nullptr;
+    const int32_t* solve_wide_list = nullptr;   // (supernode, block column) pairs: diagonal blocks to invert
     const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
@@ -65,7 +65,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream);
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
-void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
+void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
                          double* xscratch, int nrhs, int ldx, int mode, int epoch0, int ticket, int wait_bias,

@@ -279,8 +279,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.n_chol_subtrees = cut(S.chol_cost, kSubtreeMinCost, S.chol_subtree);
         }
         S.solve_cost.assign(ns, 0.0);
+        // solves: the subtrees of TINY supernodes (one wave walks one: the wave-per-supernode solve kernel)
         for (int t = 0; t < ns; ++t) {
-            elig[t] = S.sn[t].w <= kTile;
+            elig[t] = S.sn[t].w <= kTinyWidth;
             S.solve_cost[t] = 2e3 + (double)S.sn[t].w * S.sn[t].r;
         }
         S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree);
@@ -495,7 +496,6 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve_panels.clear();
     S.solve_fix_list.clear();
     S.solve_wide_list.clear();
-    S.solve_wide_max_blocks = 0;
     S.solve.clear();
     S.n_solve_wide = 0;
 
@@ -696,19 +696,29 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (L.count > 0) S.solve.push_back(L);
         }
         {
-            Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
+            // supernodes of one block column: the tiny ones (width <= kTinyWidth: one wave each) in a launch of
+            // their own when there are enough of them, the others one workgroup each
+            std::vector<int32_t> tiny, narrow;
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 if (!S.active[t] || S.solve_subtree[t] >= 0) continue;
-                if (S.sn[t].w <= kTile) {
+                if (S.sn[t].w <= kTinyWidth) tiny.push_back(t);
+                else if (S.sn[t].w <= kTile) narrow.push_back(t);
+                else sbigs.push_back(t);
+            }
+            if (!narrow.empty() && tiny.size() < 64) {
+                narrow.insert(narrow.end(), tiny.begin(), tiny.end());
+                tiny.clear();
+            }
+            for (const std::vector<int32_t>* group : {&tiny, &narrow}) {
+                if (group->empty()) continue;
+                Launch L{kLaunchSolveSmall, (int32_t)S.solve_small_list.size(), (int32_t)group->size(), lev, 0, 0, 0, 0, -1, 0};
+                for (int32_t t : *group) {
                     S.solve_small_list.push_back(t);
                     L.jb = std::max<int32_t>(L.jb, S.sn[t].w);  // widest supernode of the launch
-                } else {
-                    sbigs.push_back(t);
                 }
+                S.solve.push_back(L);
             }
-            L.count = (int32_t)S.solve_small_list.size() - L.first;
-            if (L.count > 0) S.solve.push_back(L);
         }
         if (!sbigs.empty()) {
             S.n_solve_wide += (int)sbigs.size();
@@ -723,8 +733,10 @@ void build_launches(Schedule& S, const uint8_t* active) {
                 Lc.count = (int32_t)S.solve_panels.size() - Lc.first;
                 S.solve.push_back(Lc);
                 for (int t : sbigs) {
-                    S.solve_wide_list.push_back(t);
-                    S.solve_wide_max_blocks = std::max(S.solve_wide_max_blocks, ceil_div(S.sn[t].w, kTile));
+                    for (int jb = 0; jb * kTile < S.sn[t].w; ++jb) {
+                        S.solve_wide_list.push_back(t);
+                        S.solve_wide_list.push_back(jb);
+                    }
                 }
             } else {
                 int maxnb = 0;

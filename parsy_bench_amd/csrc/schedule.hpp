@@ -46,6 +46,7 @@ constexpr int kTile = 64;             // tile edge of the tiled path / block-col
 constexpr int kSub = 32;              // per-wave sub-tile edge
 constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
 constexpr int kSmallMaxWidth = 64;
+constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solved by one wave each
 constexpr int kPanelRows = 128;       // TRSM row chunk per workgroup (staged in LDS)
 constexpr int kSolveRows = 256;       // solve row chunk per workgroup
 
@@ -197,8 +198,8 @@ struct Schedule {
     std::vector<int32_t> solve_small_list;
     std::vector<PanelDesc> solve_panels;
     std::vector<int32_t> solve_fix_list;  // wide supernodes solved by per-block-column launches
-    std::vector<int32_t> solve_wide_list; // wide supernodes solved by SOLVE_CHAIN
-    int solve_wide_max_blocks = 0;
+    std::vector<int32_t> solve_wide_list; // (supernode, block column) pairs of the wide supernodes solved by
+                                          // SOLVE_CHAIN: the diagonal blocks whose inverses a solve needs
     std::vector<Launch> solve;
 
     // backward solve L' x = y: levels from the root down, wide supernodes block column by block column

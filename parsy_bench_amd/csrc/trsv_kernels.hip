@@ -92,6 +92,11 @@ __device__ __forceinline__ void block_solve_apply16(const double* Dg, const doub
     }
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
 // An entry of x that earlier supernodes of the same launch may have updated with atomics (subtree launches: the
 // same workgroup, ordered by a fence + barrier): read at the L2, where the atomics were performed.
 __device__ __forceinline__ double ld_x(const double* p) {
@@ -165,6 +170,73 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
         }
     }
   }
+}
+
+// SOLVE_SMALL for supernodes of width <= 16 -- most supernodes of a nested-dissection ordering -- : one WAVE per
+// supernode (or per subtree of them: ranges != null, as k_solve_small), no LDS and no barrier.  Lane i holds row i
+// of the diagonal block; the substitution goes column by column with lane broadcasts (v_readlane: x_c becomes
+// wave-uniform); the rows below the block are one row per lane, their first 64 loaded before the substitution
+// starts, and are subtracted from x with atomics.  All loads of a supernode are in flight together: its latency
+// is one memory round trip instead of the three of the workgroup kernel.
+static constexpr int kTinyW = kTinyWidth;
+__global__ __launch_bounds__(64) void k_solve_tiny(const SnDesc* __restrict__ sn, const int32_t* __restrict__ list,
+                                                   const int32_t* __restrict__ ranges,
+                                                   const int32_t* __restrict__ rows, const double* __restrict__ L,
+                                                   double* __restrict__ x, int nrhs, int ldx) {
+    const int lane = threadIdx.x;
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+    for (int qsn = q_begin; qsn < q_end; ++qsn) {
+        // (subtree launch: the atomics of the supernodes before are performed before this one reads x)
+        if (qsn > q_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const SnDesc D = sn[list[qsn]];
+        const int r = D.r, w = D.w;
+        const double* __restrict__ G = L + D.px;
+        const int32_t* __restrict__ ri = rows + D.pi;
+        // every load is unconditional: lanes / columns past the block read its last row / column (never used)
+        const int il = min(lane, w - 1);
+        const int kb = min(w + lane, r - 1);   // first chunk of the rows below the block
+        double l[kTinyW], lb[kTinyW];
+#pragma unroll
+        for (int c = 0; c < kTinyW; ++c) {
+            const double* __restrict__ col = G + (int64_t)min(c, w - 1) * r;
+            l[c] = col[il];
+            lb[c] = col[kb];
+        }
+        const int row_b = ri[kb];
+        double diag = 1.0;
+#pragma unroll
+        for (int c = 0; c < kTinyW; ++c) diag = (lane == c && c < w) ? l[c] : diag;
+        const double rdiag = 1.0 / diag;   // (triangularSolve/BLAS.h:8 divides by the diagonal)
+        for (int q = blockIdx.y; q < nrhs; q += gridDim.y) {
+            double* __restrict__ xq = x + (int64_t)q * ldx;
+            double xi = lane < w ? ld_x(&xq[D.c0 + lane]) : 0.0;
+            double xc[kTinyW];   // the solved block, wave-uniform
+#pragma unroll
+            for (int c = 0; c < kTinyW; ++c) {
+                xc[c] = 0.0;
+                if (c < w) {
+                    xc[c] = readlane_f64(xi * rdiag, c);
+                    xi = (lane > c) ? fma(-l[c], xc[c], xi) : xi;
+                }
+            }
+            double xfin = 0.0;
+#pragma unroll
+            for (int c = 0; c < kTinyW; ++c) xfin = (lane == c) ? xc[c] : xfin;
+            if (lane < w) xq[D.c0 + lane] = xfin;
+            // rows below the block: the prefetched chunk, then the rest
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < kTinyW; ++c) acc = fma(lb[c], xc[c], acc);
+            if (w + lane < r) atomicAdd(&xq[row_b], -acc);
+            for (int k = w + 64 + lane; k < r; k += 64) {
+                double a2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < kTinyW; ++c) a2 = fma(G[(int64_t)min(c, w - 1) * r + k], xc[c], a2);
+                atomicAdd(&xq[ri[k]], -a2);
+            }
+        }
+    }
 }
 
 // SOLVE_SMALL for many right-hand sides (nrhs >= 16): up to 64 of them per pass over the panel, so that L is
@@ -332,6 +404,11 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
     // subtree launch: `first` counts (begin, end) pairs of solve_small_ranges, which index the whole list
     const int32_t* list = subtrees ? P.solve_small_list : P.solve_small_list + first;
     const int32_t* ranges = subtrees ? P.solve_small_ranges + 2 * first : nullptr;
+    if (nrhs < mrhs_min() && wmax <= kTinyW) {
+        hipLaunchKernelGGL(k_solve_tiny, dim3(count, std::min(kPassLanes, nrhs)), dim3(64), 0, stream, P.sn, list, ranges,
+                           P.rows, L, x, nrhs, ldx);
+        return;
+    }
     if (nrhs >= mrhs_min()) {
         if (wmax <= 16)
             hipLaunchKernelGGL(k_solve_small_mrhs<16>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
@@ -431,49 +508,122 @@ void launch_solve_panel(const DevicePattern& P, int first, int count, const doub
                        P.solve_panels + first, P.rows, L, x, xscratch, nrhs, ldx);
 }
 
-// DIAG_INVERSE: explicit inverses of the 64x64 diagonal blocks of the wide supernodes, one
-// 64-thread workgroup per block, one column per thread (forward substitution of L y = e_c).
-// Run once at the start of a solve; SOLVE_CHAIN then replaces the sequential 64-step
-// substitution on its critical path by a 64x64 matrix-vector product.  dinv holds one
-// column-major 64x64 lower-triangular block per scratch slot (identity padded).
+// DIAG_INVERSE: inverse of every 64x64 diagonal block of the wide supernodes (what the chain kernels multiply
+// by: x_jb = inv(L_jj) t).  One wave per block, in place in LDS, by halves:
+//     inv [A 0; B C] = [inv A, 0; -inv(C) B inv(A), inv C]
+// -- the four 16x16 diagonal sub-blocks by substitution (one column per lane), then the 16x16 and the 32x32
+// off-diagonal blocks as products on the matrix cores (v_mfma_f64_16x16x4_f64, operands from LDS): 16 block
+// products instead of a 64-step substitution whose longest column is a chain of two thousand dependent
+// multiply-adds.  dinv[(dslot + jb) * 4096 + c * 64 + i] = inv(L_jj)[i][c], zeros above the diagonal; a block
+// narrower than 64 is padded with an identity.
+__device__ __forceinline__ double4_s mm16(double4_s acc, const double* __restrict__ X, const double* __restrict__ Y,
+                                          int l15, int kq) {
+    // acc += X * Y for 16x16 blocks of the LDS matrix (column-major, ld kLdDiag); result layout: lane (l15, kq)
+    // holds column l15, rows kq + 4 v
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(4 * st + kq) * kLdDiag + l15], Y[l15 * kLdDiag + 4 * st + kq], acc,
+                                                   0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void put16(double* __restrict__ Z, double4_s acc, double sign, int l15, int kq) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Z[l15 * kLdDiag + kq + 4 * v] = sign * acc[v];
+}
+
 __global__ __launch_bounds__(64) void k_diag_inverse(const SnDesc* __restrict__ sn,
                                                      const int32_t* __restrict__ list,
                                                      const double* __restrict__ L,
                                                      double* __restrict__ dinv) {
-    __shared__ double Dg[kTile * kLdDiag];
-    const SnDesc D = sn[list[blockIdx.x]];
-    const int jb = blockIdx.y, c = threadIdx.x;
+    __shared__ double M[kTile * kLdDiag];
+    const SnDesc D = sn[list[2 * blockIdx.x]];   // one workgroup per (supernode, block column) pair of the list
+    const int jb = list[2 * blockIdx.x + 1], lane = threadIdx.x;
+    const int l15 = lane & 15, kq = lane >> 4;
     const int r = D.r, cb = jb * kTile, wbk = min(kTile, D.w - cb);
-    if (cb >= D.w) return;
     const double* __restrict__ G = L + D.px;
-    for (int e = c; e < kTile * kTile; e += 64) {
+    {
+        // column cc, row `lane`: all 64 loads in flight together (unconditional: clamped to the block, then masked)
+        double v[kTile];
+        const double* __restrict__ src = G + (int64_t)cb * r + cb + min(lane, wbk - 1);
+#pragma unroll
+        for (int cc = 0; cc < kTile; ++cc) v[cc] = src[(int64_t)min(cc, wbk - 1) * r];
+#pragma unroll
+        for (int cc = 0; cc < kTile; ++cc)
+            M[cc * kLdDiag + lane] = (cc < wbk && lane < wbk && lane >= cc) ? v[cc] : (lane == cc ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_wave_barrier();   // (one wave: its LDS operations complete in order)
+    auto blk = [&](int bi, int bj) { return M + (16 * bj) * kLdDiag + 16 * bi; };   // 16x16 block (bi, bj)
+    {
+        // the four diagonal sub-blocks: lane (b = kq, c = l15) forms column c of inv(L_bb) and writes it in place
+        double* __restrict__ B = blk(kq, kq);
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            double sacc = (rr == l15) ? -1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(B[k * kLdDiag + rr], y[k], sacc);
+            y[rr] = (rr >= l15) ? -sacc / B[rr * kLdDiag + rr] : 0.0;
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // every read of the sub-blocks precedes the in-place writes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) B[l15 * kLdDiag + rr] = y[rr];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double4_s zero = {0, 0, 0, 0};
+    // the two 32x32 diagonal blocks: block (b+1, b) := -inv(L_{b+1,b+1}) L_{b+1,b} inv(L_bb), b = 0, 2
+#pragma unroll
+    for (int b = 0; b < 4; b += 2) {
+        const double4_s t = mm16(zero, blk(b + 1, b), blk(b, b), l15, kq);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        put16(blk(b + 1, b), t, 1.0, l15, kq);
+        __builtin_amdgcn_wave_barrier();
+        const double4_s u = mm16(zero, blk(b + 1, b + 1), blk(b + 1, b), l15, kq);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        put16(blk(b + 1, b), u, -1.0, l15, kq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the 32x32 block below: X := -inv(C) B inv(A), A = blocks (0..1, 0..1), C = blocks (2..3, 2..3), both inverted
+    {
+        // T = B inv(A): T_i0 = B_i0 A00 + B_i1 A10, T_i1 = B_i1 A11  (i = 2, 3)
+        double4_s t20 = mm16(mm16(zero, blk(2, 0), blk(0, 0), l15, kq), blk(2, 1), blk(1, 0), l15, kq);
+        double4_s t30 = mm16(mm16(zero, blk(3, 0), blk(0, 0), l15, kq), blk(3, 1), blk(1, 0), l15, kq);
+        double4_s t21 = mm16(zero, blk(2, 1), blk(1, 1), l15, kq);
+        double4_s t31 = mm16(zero, blk(3, 1), blk(1, 1), l15, kq);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        put16(blk(2, 0), t20, 1.0, l15, kq);
+        put16(blk(3, 0), t30, 1.0, l15, kq);
+        put16(blk(2, 1), t21, 1.0, l15, kq);
+        put16(blk(3, 1), t31, 1.0, l15, kq);
+        __builtin_amdgcn_wave_barrier();
+        // X = -inv(C) T: X_2j = -C22 T_2j, X_3j = -(C32 T_2j + C33 T_3j)
+        double4_s x20 = mm16(zero, blk(2, 2), blk(2, 0), l15, kq);
+        double4_s x21 = mm16(zero, blk(2, 2), blk(2, 1), l15, kq);
+        double4_s x30 = mm16(mm16(zero, blk(3, 2), blk(2, 0), l15, kq), blk(3, 3), blk(3, 0), l15, kq);
+        double4_s x31 = mm16(mm16(zero, blk(3, 2), blk(2, 1), l15, kq), blk(3, 3), blk(3, 1), l15, kq);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        put16(blk(2, 0), x20, -1.0, l15, kq);
+        put16(blk(2, 1), x21, -1.0, l15, kq);
+        put16(blk(3, 0), x30, -1.0, l15, kq);
+        put16(blk(3, 1), x31, -1.0, l15, kq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    double* __restrict__ out = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile);
+    for (int e = lane; e < kTile * kTile; e += 64) {
         const int cc = e >> 6, i = e & 63;
-        double v = (i == cc) ? 1.0 : 0.0;
-        if (cc < wbk && i < wbk && i >= cc) v = G[(int64_t)(cb + cc) * r + cb + i];
-        Dg[cc * kLdDiag + i] = v;
+        out[e] = (i >= cc) ? M[cc * kLdDiag + i] : 0.0;
     }
-    __syncthreads();
-    // column c of the inverse: y[c] = 1/l_cc, y[i] = -(sum_{k=c}^{i-1} L[i][k] y[k]) / l_ii
-    double y[kTile];
-#pragma unroll
-    for (int i = 0; i < kTile; ++i) y[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < kTile; ++i) {
-        double sacc = (i == c) ? -1.0 : 0.0;
-#pragma unroll
-        for (int k2 = 0; k2 < i; ++k2) sacc = fma(Dg[k2 * kLdDiag + i], y[k2], sacc);
-        y[i] = (i >= c) ? -sacc / Dg[i * kLdDiag + i] : 0.0;
-    }
-    double* __restrict__ out = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile) + (int64_t)c * kTile;
-#pragma unroll
-    for (int i = 0; i < kTile; ++i) out[i] = y[i];
 }
 
-void launch_diag_inverse(const DevicePattern& P, int count, int max_blocks, const double* L, double* dinv,
-                         hipStream_t stream) {
+void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv, hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_diag_inverse, dim3(count, max_blocks), dim3(64), 0, stream, P.sn, P.solve_wide_list, L,
-                       dinv);
+    hipLaunchKernelGGL(k_diag_inverse, dim3(count), dim3(64), 0, stream, P.sn, P.solve_wide_list, L, dinv);
 }
 
 // SOLVE_CHAIN: the whole block-column chain of a wide supernode in ONE launch.  Workgroup c
