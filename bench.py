@@ -449,7 +449,7 @@ def main():
                 pmc = json.load(open(ROOT / "profiles" / f"r02_{args.workload}_pmc_traffic.json"))
                 if pmc.get("kernel_source_hash") == kernel_source_hash() and nrhs == 1:
                     ks = pmc["kernels"]
-                    fwd = [v for k, v in ks.items() if k.startswith(("k_diag_inverse", "k_solve_small", "k_solve_chain"))]
+                    fwd = [v for k, v in ks.items() if k.startswith(("k_diag_inverse", "k_solve_small", "k_solve_tiny", "k_solve_chain"))]
                     nsolves = ks["k_diag_inverse"]["launches_in_run"]   # one per forward solve
                     solve_traffic = sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in fwd) / max(nsolves, 1)
             except (OSError, ValueError, KeyError):
@@ -461,7 +461,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (solve_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms > 0 else 0.0,
                 "algorithmic_bytes_per_solve": solve_bytes, "traffic": solve_traffic,
-                "traffic_unit": "HBM-side bytes per forward solve (k_diag_inverse + k_solve_small + k_solve_chain, same PMC summary)",
+                "traffic_unit": "HBM-side bytes per forward solve (k_diag_inverse + k_solve_tiny + k_solve_small + k_solve_chain_w, same PMC summary)",
                 "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
             }
 

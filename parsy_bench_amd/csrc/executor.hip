@@ -258,7 +258,8 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
             case kLaunchBackBlock:
-                launch_bsolve_block(pl->dp, l.first, l.count, Lc, x, pl->xscratch, nrhs, ldx, l.fused, pl->epoch,
+                launch_bsolve_block(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx, l.fused,
+                                    l.early != 0, pl->epoch,
                                     l.fused == 1 ? l.jb : 0, pl->solve_wait_bias, stream);
                 break;
         }
@@ -306,7 +307,18 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
         pl->xscratch_len = need;
     }
+    if (!pl->S.solve_wide_list.empty() && !pl->dinv) {
+        const size_t bytes = (size_t)std::max<int64_t>(pl->S.n_dslots, 1) * kTile * kTile * sizeof(double);
+        PARSY_HIP(hipMalloc((void**)&pl->dinv, bytes));
+        pl->device_bytes += (int64_t)bytes;
+    }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+    // the chain launches hand x over through xscratch itself (armed: see solve_arm_handoff) and finish a block
+    // column with a product with its inverse diagonal block
+    if (!pl->S.solve_wide_list.empty()) {
+        PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
+        launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
+    }
     run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

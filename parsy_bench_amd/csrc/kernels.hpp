@@ -67,9 +67,9 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);
-void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int mode, int epoch0, int ticket, int wait_bias,
-                         hipStream_t stream);
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int epoch0, int ticket,
+                         int wait_bias, hipStream_t stream);
 void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
                      hipStream_t stream);
 void launch_copy_segments(double* dst, const double* src, const int64_t* dst_off, const int64_t* src_off,

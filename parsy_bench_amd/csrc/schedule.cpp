@@ -285,9 +285,13 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.solve_cost[t] = 2e3 + (double)S.sn[t].w * S.sn[t].r;
         }
         S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree);
+        // (the backward solve walks the same subtrees from their roots down)
+        S.bsolve_subtree = S.solve_subtree;
+        S.n_bsolve_subtrees = S.n_solve_subtrees;
     }
     if (S.chol_subtree.empty()) S.chol_subtree.assign(ns, -1);
     if (S.solve_subtree.empty()) S.solve_subtree.assign(ns, -1);
+    if (S.bsolve_subtree.empty()) S.bsolve_subtree.assign(ns, -1);
 
     // Updates that go through the BIG launches: wide descendants, and EVERY update of a split supernode's
     // pieces (what little reaches those from narrow descendants would otherwise be a TILES launch per
@@ -764,7 +768,28 @@ void build_launches(Schedule& S, const uint8_t* active) {
     // supernodes of a single block; when the chain would not be resident, one launch per block-column
     // index from the last one down.
     S.bsolve.clear();
-    auto in_level_launches = [&](int t) { return S.active[t] && S.solve_subtree[t] < 0; };
+    auto in_level_launches = [&](int t) { return S.active[t] && S.bsolve_subtree[t] < 0; };
+    // the supernodes of one block column of a level: the tiny ones (one wave each: Launch::early = 1) in a launch
+    // of their own when there are enough of them, the others one workgroup each
+    auto narrow_launches = [&](int lev) {
+        std::vector<int32_t> tiny, narrow;
+        for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+            const int t = S.levelSet[q];
+            if (!in_level_launches(t) || S.sn[t].w > kTile) continue;
+            (S.sn[t].w <= kTinyWidth ? tiny : narrow).push_back(t);
+        }
+        if (!narrow.empty() && tiny.size() < 64) {
+            narrow.insert(narrow.end(), tiny.begin(), tiny.end());
+            tiny.clear();
+        }
+        for (const std::vector<int32_t>* group : {&tiny, &narrow}) {
+            if (group->empty()) continue;
+            Launch Ln{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), (int32_t)group->size(), lev, 0, 0, 0, 0, -1,
+                      group == &tiny ? 1 : 0};
+            for (int32_t t : *group) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
+            S.bsolve.push_back(Ln);
+        }
+    };
     for (int lev = S.nlevels - 1; lev >= 0; --lev) {
         int maxnb = 0, wide_blocks = 0;
         for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
@@ -784,16 +809,10 @@ void build_launches(Schedule& S, const uint8_t* active) {
             }
             Lc.count = (int32_t)S.bsolve_blocks.size() - Lc.first;
             S.bsolve.push_back(Lc);
-            Launch Ln{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 0, 0, -1, 0};
-            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
-                const int t = S.levelSet[q];
-                if (in_level_launches(t) && ceil_div(S.sn[t].w, kTile) == 1) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
-            }
-            Ln.count = (int32_t)S.bsolve_blocks.size() - Ln.first;
-            if (Ln.count > 0) S.bsolve.push_back(Ln);
+            narrow_launches(lev);
             continue;
         }
-        for (int jb = maxnb - 1; jb >= 0; --jb) {
+        for (int jb = maxnb - 1; jb >= 1; --jb) {
             Launch Lb{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, jb, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
@@ -802,14 +821,24 @@ void build_launches(Schedule& S, const uint8_t* active) {
             Lb.count = (int32_t)S.bsolve_blocks.size() - Lb.first;
             if (Lb.count > 0) S.bsolve.push_back(Lb);
         }
+        if (maxnb > 1) {   // block column 0 of the wide supernodes (their other block columns: the launches above)
+            Launch Lb{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, 0, 0, 0, 0, -1, 0};
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (in_level_launches(t) && ceil_div(S.sn[t].w, kTile) > 1) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
+            }
+            Lb.count = (int32_t)S.bsolve_blocks.size() - Lb.first;
+            if (Lb.count > 0) S.bsolve.push_back(Lb);
+        }
+        narrow_launches(lev);
     }
-    if (S.n_solve_subtrees > 0) {
+    if (S.n_bsolve_subtrees > 0) {
         // the subtrees last: every ancestor outside them is final; inside, a workgroup walks from the subtree's
         // root down (the forward order reversed)
-        Launch L{kLaunchBackBlock, 0, 0, 0, 0, 0, 2, 0, -1, 0};
+        Launch L{kLaunchBackBlock, 0, 0, 0, 0, 0, 2, 0, -1, 1};   // (tiny supernodes: one wave per subtree)
         std::vector<int32_t> members;
         L.count = subtree_ranges(
-            S.solve_subtree, S.n_solve_subtrees, S.solve_cost,
+            S.bsolve_subtree, S.n_bsolve_subtrees, S.solve_cost,
             [&] {
                 for (size_t q = members.size(); q-- > 0;) S.bsolve_blocks.push_back(PanelDesc{members[q], 0, 0, 0});
                 members.clear();

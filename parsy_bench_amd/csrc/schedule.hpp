@@ -175,9 +175,11 @@ struct Schedule {
 
     // Subtrees walked by one workgroup each (PARSY_SUBTREES=0: none): per supernode its subtree or -1, and
     // the cost estimate the subtrees were cut by (launches start the expensive ones first)
-    std::vector<int32_t> chol_subtree, solve_subtree;
+    // (forward solve: subtrees of tiny supernodes, one wave each; backward solve: of all supernodes of one block
+    // column, one workgroup each)
+    std::vector<int32_t> chol_subtree, solve_subtree, bsolve_subtree;
     std::vector<double> chol_cost, solve_cost;
-    int n_chol_subtrees = 0, n_solve_subtrees = 0;
+    int n_chol_subtrees = 0, n_solve_subtrees = 0, n_bsolve_subtrees = 0;
     // (begin, end) pairs into small_list / solve_small_list / bsolve_blocks, one per workgroup of a subtree launch
     std::vector<int32_t> small_ranges, solve_small_ranges, bsolve_ranges;
 

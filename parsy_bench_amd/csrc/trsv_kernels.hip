@@ -1232,10 +1232,12 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            int nrhs, int ldx, int chain, int* __restrict__ flags,
                                                            int epoch0, int* __restrict__ info,
                                                            int* __restrict__ ticket, int wait_bias, int nblocks,
-                                                           int fstride, const int32_t* __restrict__ ranges) {
-    // chain != 0: every block column of the wide supernodes of a level is in this launch (all
-    // resident); block jb takes the x of blocks jb+1.. of its supernode as they are published
-    // (xscratch, 8-byte agent-scope atomics both sides + a flag per block and pass).
+                                                           int fstride, const int32_t* __restrict__ ranges,
+                                                           const double* __restrict__ dinv) {
+    // chain != 0: every block column of the wide supernodes of a level is in this launch; block jb takes the x
+    // of blocks jb+1.. of its supernode as they are published: as the data itself, through the armed buffer
+    // (xscratch: 8-byte agent-scope atomics both sides, a value is valid once it differs from kXArmed -- see
+    // k_solve_chain_w), and finishes with a product with the inverse diagonal block (DIAG_INVERSE).
     // ranges != null (subtree launch, chain == 0): task b is the run pds[ranges[2b] .. ranges[2b+1]) -- a subtree
     // of single-block supernodes from its root down; the workgroup reads its own earlier x (same CU, plain
     // stores and loads ordered by the barrier between two supernodes).
@@ -1262,14 +1264,16 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     const int32_t* __restrict__ ri = rows + D.pi;
     const int kbeg = cb + wbk;  // first panel row below the block
 
-    {   // diagonal block (identity padded) -> LDS
+    {   // diagonal block (identity padded) -> LDS; chain launch: its inverse instead (same layout)
         double dtmp[kTile * kTile / kThreads];
+        const double* __restrict__ inv_blk = chain ? dinv + (int64_t)(D.dslot + pd.jb) * (kTile * kTile) : nullptr;
 #pragma unroll
         for (int t = 0; t < kTile * kTile / kThreads; ++t) {
             const int e = t * kThreads + tid;
             const int c = e >> 6, i = e & 63;
             double v = (i == c) ? 1.0 : 0.0;
-            if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+            if (chain) v = inv_blk[e];
+            else if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
             dtmp[t] = v;
         }
 #pragma unroll
@@ -1280,9 +1284,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     }
     __syncthreads();
     // inverses of the 16x16 diagonal sub-blocks (stored transposed in the strict upper triangle)
-    if (tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
+    if (!chain && tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
     __syncthreads();
-    if (tid < kTile && (tid & ~15) < wbk) {
+    if (!chain && tid < kTile && (tid & ~15) < wbk) {
         const int b16 = tid & ~15, c = tid & 15;
         double y[16];
 #pragma unroll
@@ -1304,7 +1308,6 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     for (int pass = plane; pass * NQ < nrhs; pass += kPassLanes) {
         const int q0 = pass * NQ;
         const int nq = min(NQ, nrhs - q0);
-        const int epoch = epoch0 + pass / kPassLanes;   // round of this lane
         __syncthreads();
         for (int e = tid; e < kTile * NQ; e += kThreads) {
             const int c = e & 63, q = e >> 6;
@@ -1344,33 +1347,38 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                         const int c = wave + 4 * ci;
                         lv[ci] = (c < wbk && k < w) ? G[(int64_t)(cb + c) * r + k] : 0.0;
                     }
+                    // x of block I: every lane polls its own row's values (the data is the flag); bounded, and
+                    // one timeout (status word) ends every wait of the solve
                     const unsigned long long t0 = wall_clock64();
                     bool ok = true;
-                    // epochs only grow: a later pass may already have raised the flag; bounded, and one
-                    // timeout (status word) ends every wait of the solve
                     int spins = 0;
-                    while (__hip_atomic_load(&flags[D.dslot + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                               (epoch + wait_bias) < 0) {
+                    double xk[NQ];
+                    for (;;) {
+                        bool in = true;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            long long b = 0;
+                            if (q < nq && k < w)
+                                b = __hip_atomic_load(reinterpret_cast<const long long*>(
+                                                          &xscratch[(int64_t)(q0 + q) * ldx + D.c0 + k]),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            xk[q] = __longlong_as_double(b);
+                        }
+                        if (__all(in && wait_bias == 0)) break;
                         if ((++spins & 15) == 0 &&
                             (wall_clock64() - t0 > kSolveSpinTicks ||
                              __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
                             ok = false;
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (!ok) {
                         if (lane == 0) atomicMin(info, -1);
                         break;  // (the result is wrong and reported; nobody may hang)
                     }
-                    if (k < w) {
-                        double xk[NQ];
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-                            xk[q] = (q < nq) ? __hip_atomic_load(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + k],
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                             : 0.0;
+                    {
 #pragma unroll
                         for (int ci = 0; ci < kTile / 4; ++ci)
 #pragma unroll
@@ -1388,8 +1396,33 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 }
         }
         __syncthreads();
+        if (chain) {
+            // x_blk = inv(L_bb)' t as a product: x_c = sum_{k >= c} inv(L_bb)[k][c] t_k (column c of the inverse is
+            // contiguous in LDS)
+            double zv[(kTile * NQ + kThreads - 1) / kThreads];
+#pragma unroll
+            for (int u = 0; u < (kTile * NQ + kThreads - 1) / kThreads; ++u) {
+                const int e = u * kThreads + tid, c = e & 63, q = e >> 6;
+                double s0 = 0.0, s1 = 0.0;
+                if (e < kTile * NQ && q < nq) {
+                    for (int k = c; k + 1 < kTile; k += 2) {
+                        s0 = fma(Dg[c * kLdDiag + k], ts[k][q], s0);
+                        s1 = fma(Dg[c * kLdDiag + k + 1], ts[k + 1][q], s1);
+                    }
+                    if (((kTile - c) & 1) != 0) s0 = fma(Dg[c * kLdDiag + kTile - 1], ts[kTile - 1][q], s0);
+                }
+                zv[u] = s0 + s1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < (kTile * NQ + kThreads - 1) / kThreads; ++u) {
+                const int e = u * kThreads + tid;
+                if (e < kTile * NQ && (e >> 6) < nq) ts[e & 63][e >> 6] = zv[u];
+            }
+            __syncthreads();
+        }
         // x_blk = inv(L_bb)' t, 16 columns at a time from the last sub-block up
-        for (int b16 = ((wbk - 1) & ~15); b16 >= 0; b16 -= 16) {
+        for (int b16 = chain ? -1 : ((wbk - 1) & ~15); b16 >= 0; b16 -= 16) {
             const int i = tid & 15, q = tid >> 4;
             const bool act = q < nq;
             double zv = 0.0;
@@ -1422,35 +1455,105 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], ts[c][q], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (chain) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(&flags[D.dslot + pd.jb], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (chain launch: nothing else to do -- the values stored in the armed buffer are the publication)
     }
   }
 }
 
+// Backward solve of supernodes of width <= 16: one WAVE per supernode, or per subtree of them from its root down
+// (ranges != null), no LDS and no barrier -- the counterpart of k_solve_tiny.  The rows below the diagonal block
+// are one row per lane (their x is final: ancestors), every lane keeps its part of t_c = sum_k L[k][c] x_k for
+// the <= 16 columns and the parts are summed across the wave once, at the end (xor butterfly); lane c then holds
+// column c of the diagonal block and the transposed substitution goes from the last column up with lane
+// broadcasts (v_readlane).
+__global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ sn, const PanelDesc* __restrict__ pds,
+                                                    const int32_t* __restrict__ ranges,
+                                                    const int32_t* __restrict__ rows, const double* __restrict__ L,
+                                                    double* __restrict__ x, int nrhs, int ldx) {
+    const int lane = threadIdx.x;
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+    for (int qsn = q_begin; qsn < q_end; ++qsn) {
+        // (subtree launch: the x this wave stored for the supernode before -- an ancestor -- is read back below)
+        if (qsn > q_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const SnDesc D = sn[pds[qsn].sn];
+        const int r = D.r, w = D.w;
+        const double* __restrict__ G = L + D.px;
+        const int32_t* __restrict__ ri = rows + D.pi;
+        // lane c: column c of the diagonal block (rows 0..w-1); every lane: its row of the first 64 rows below
+        // (unconditional loads, clamped into the panel)
+        const int cl = min(lane, w - 1);
+        const int kb = min(w + lane, r - 1);
+        double lc[kTinyW], lb[kTinyW];
+#pragma unroll
+        for (int k = 0; k < kTinyW; ++k) {
+            lc[k] = G[(int64_t)cl * r + min(k, w - 1)];
+            lb[k] = G[(int64_t)min(k, w - 1) * r + kb];
+        }
+        const int row_b = ri[kb];
+        double diag = 1.0;
+#pragma unroll
+        for (int k = 0; k < kTinyW; ++k) diag = (lane == k && k < w) ? lc[k] : diag;
+        const double rdiag = 1.0 / diag;
+        for (int q = blockIdx.y; q < nrhs; q += gridDim.y) {
+            double* __restrict__ xq = x + (int64_t)q * ldx;
+            // parts of t over this lane's rows
+            double p[kTinyW];
+            const double xb = (w + lane < r) ? xq[row_b] : 0.0;
+#pragma unroll
+            for (int c = 0; c < kTinyW; ++c) p[c] = lb[c] * xb;
+            for (int k = w + 64 + lane; k < r; k += 64) {
+                const double xk = xq[ri[k]];
+#pragma unroll
+                for (int c = 0; c < kTinyW; ++c) p[c] = fma(G[(int64_t)min(c, w - 1) * r + k], xk, p[c]);
+            }
+            double t = lane < w ? xq[D.c0 + lane] : 0.0;
+#pragma unroll
+            for (int c = 0; c < kTinyW; ++c) {
+                double v = p[c];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                t = (lane == c && c < w) ? t - v : t;
+            }
+            // x_k = (t_k - sum_{j > k} L[j][k] x_j) / L[k][k], from the last column up: lane c holds L[k][c] = lc[k]
+            double xfin = 0.0;
+#pragma unroll
+            for (int k = kTinyW - 1; k >= 0; --k) {
+                if (k < w) {
+                    const double xk = readlane_f64(t * rdiag, k);
+                    t = (lane < k) ? fma(-lc[k], xk, t) : t;
+                    xfin = (lane == k) ? xk : xfin;
+                }
+            }
+            if (lane < w) xq[D.c0 + lane] = xfin;
+        }
+    }
+}
+
 // mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts
-// (begin, end) pairs of bsolve_ranges, which index the whole block list)
-void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, double* x,
-                         double* xscratch, int nrhs, int ldx, int mode, int epoch0, int ticket, int wait_bias,
-                         hipStream_t stream) {
+// (begin, end) pairs of bsolve_ranges, which index the whole block list); tiny: Launch::early
+void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int epoch0, int ticket,
+                         int wait_bias, hipStream_t stream) {
     if (count <= 0) return;
     const int chain = mode == 1;
     const PanelDesc* pds = mode == 2 ? P.bsolve_blocks : P.bsolve_blocks + first;
     const int32_t* ranges = mode == 2 ? P.bsolve_ranges + 2 * first : nullptr;
+    if (tiny) {   // supernodes of width <= kTinyWidth (a subtree launch or a level's launch of them): one wave each
+        hipLaunchKernelGGL(k_bsolve_tiny, dim3(count, std::min(kPassLanes, nrhs)), dim3(64), 0, stream, P.sn, pds, ranges,
+                           P.rows, L, x, nrhs, ldx);
+        return;
+    }
     const int lanes = nrhs == 1 ? 1 : std::min(kPassLanes, (nrhs + 3) / 4);
     const dim3 grid = chain ? dim3(count * lanes) : dim3(count, lanes);
     if (nrhs == 1)
         hipLaunchKernelGGL(k_bsolve_block<1>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
                            nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
-                           P.flag_stride, ranges);
+                           P.flag_stride, ranges, dinv);
     else
         hipLaunchKernelGGL(k_bsolve_block<4>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
                            nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
-                           P.flag_stride, ranges);
+                           P.flag_stride, ranges, dinv);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.
