@@ -1323,17 +1323,34 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 for (int q = 0; q < NQ; ++q) acc[ci][q] = 0.0;
             // rows below the supernode's own columns (ancestors: final before this launch); without
             // the chain also the rows of the later blocks (solved by earlier launches)
-            for (int k = (chain ? w : kbeg) + lane; k < r; k += 64) {
-                const int xr = (k < w) ? (D.c0 + k) : ri[k];
-                double xk[NQ];
+            // (kBackUnroll row chunks per trip, every load of a trip issued before its products: the row ids, the
+            // x they point to and the wave's 16 columns of L are three dependent-latency phases otherwise)
+            constexpr int kBackUnroll = NQ == 1 ? 4 : 2;
+            for (int k0 = (chain ? w : kbeg) + lane; k0 < r; k0 += 64 * kBackUnroll) {
+                int xr[kBackUnroll];
+                double lv[kBackUnroll][kTile / 4];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) xk[q] = (q < nq) ? x[(int64_t)(q0 + q) * ldx + xr] : 0.0;
+                for (int u = 0; u < kBackUnroll; ++u) {
+                    const int k = min(k0 + 64 * u, r - 1);   // (clamped: the chunks past the panel multiply by zero)
+                    xr[u] = (k < w) ? (D.c0 + k) : ri[k];
 #pragma unroll
-                for (int ci = 0; ci < kTile / 4; ++ci) {
-                    const int c = wave + 4 * ci;
-                    const double lv = (c < wbk) ? G[(int64_t)(cb + c) * r + k] : 0.0;
+                    for (int ci = 0; ci < kTile / 4; ++ci) {
+                        const int c = min(wave + 4 * ci, wbk - 1);
+                        lv[u][ci] = G[(int64_t)(cb + c) * r + k];
+                    }
+                }
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lv, xk[q], acc[ci][q]);
+                for (int u = 0; u < kBackUnroll; ++u) {
+                    double xk[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        xk[q] = (q < nq && k0 + 64 * u < r) ? x[(int64_t)(q0 + q) * ldx + xr[u]] : 0.0;
+#pragma unroll
+                    for (int ci = 0; ci < kTile / 4; ++ci) {
+                        const double lvv = (wave + 4 * ci < wbk) ? lv[u][ci] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[ci][q] = fma(lvv, xk[q], acc[ci][q]);
+                    }
                 }
             }
             if (chain) {

@@ -207,9 +207,17 @@ def _check_small(api, oracle, A, perm, nrhs=2):
     Ad = A.to_dense()[np.ix_(sym.Perm, sym.Perm)]
     assert np.abs(Ld @ Ld.T - Ad).max() <= RESID_TOL * np.abs(Ad).max()
     rng = np.random.default_rng(7)
-    B = rng.standard_normal((sym.n, nrhs))
-    X, _ = plan.solve(lv, B)
-    assert np.abs(Ld @ X - B).max() <= 1e-10 * max(1.0, np.abs(X).max())
+    # forward and backward solves with one right-hand side (the wave kernels), with `nrhs` and with a block of 17
+    # (the many-right-hand-side kernels), against the dense factor
+    for q in sorted({1, nrhs, 17}):
+        B = rng.standard_normal((sym.n, q))
+        X, _ = plan.solve(lv, B if q > 1 else B[:, 0])
+        X = X.reshape(sym.n, -1)
+        assert plan.solve_status() == 0
+        assert np.abs(Ld @ X - B).max() <= 1e-10 * max(1.0, np.abs(X).max()), f"forward, nrhs={q}"
+        Xb, _ = plan.solve2(lv, B, forward=False)
+        assert plan.solve_status() == 0
+        assert np.abs(Ld.T @ Xb - B).max() <= 1e-10 * max(1.0, np.abs(Xb).max()), f"backward, nrhs={q}"
     return sym
 
 
