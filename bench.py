@@ -449,9 +449,12 @@ def main():
                 pmc = json.load(open(ROOT / "profiles" / f"r02_{args.workload}_pmc_traffic.json"))
                 if pmc.get("kernel_source_hash") == kernel_source_hash() and nrhs == 1:
                     ks = pmc["kernels"]
-                    fwd = [v for k, v in ks.items() if k.startswith(("k_diag_inverse", "k_solve_small", "k_solve_tiny", "k_solve_chain"))]
-                    nsolves = ks["k_diag_inverse"]["launches_in_run"]   # one per forward solve
-                    solve_traffic = sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in fwd) / max(nsolves, 1)
+                    # the profiled program runs as many forward (and backward) solves as factorizations; the inverse
+                    # diagonal blocks are formed once per solve of either kind
+                    fwd = [v for k, v in ks.items() if k.startswith(("k_solve_small", "k_solve_tiny", "k_solve_chain"))]
+                    nsolves = pmc["factorizations_in_the_profiled_run"]
+                    solve_traffic = (sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in fwd) / max(nsolves, 1)
+                                     + ks["k_diag_inverse"]["hbm_bytes_per_launch"])
             except (OSError, ValueError, KeyError):
                 pass
             solve_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
