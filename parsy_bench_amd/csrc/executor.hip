@@ -49,6 +49,7 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
     if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
     if (upload(pl, S.bsolve_blocks, pl->dp.bsolve_blocks, true)) return -1;
+    if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
@@ -258,6 +259,11 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
             case kLaunchBackBlock:
+                if (l.fused == 1 && nrhs == 1) {   // one right-hand side: the wave dataflow over block-column pairs
+                    launch_bsolve_chain_w(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, l.jb,
+                                          pl->solve_wait_bias, stream);
+                    break;
+                }
                 launch_bsolve_block(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx, l.fused,
                                     l.early != 0, pl->epoch,
                                     l.fused == 1 ? l.jb : 0, pl->solve_wait_bias, stream);

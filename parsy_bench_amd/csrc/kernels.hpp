@@ -33,6 +33,7 @@ struct DevicePattern {           // device copies of Schedule arrays
     const PanelDesc* solve_panels = nullptr;
     const int32_t* solve_fix_list = nullptr;
     const int32_t* solve_wide_list = nullptr;   // (supernode, block column) pairs: diagonal blocks to invert
+    const PanelDesc* bsolve_pairs = nullptr;   // backward chain launches, one right-hand side: block-column pairs
     const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
@@ -67,6 +68,8 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);
+void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                           double* x, double* xscratch, int ticket, int wait_bias, hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                          double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int epoch0, int ticket,
                          int wait_bias, hipStream_t stream);

@@ -551,6 +551,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.solve_small_ranges.clear();
     S.bsolve_ranges.clear();
     S.bsolve_blocks.clear();
+    S.bsolve_pairs.clear();
     for (int lev = 0; lev < S.cnlevels && !S.solve_only; ++lev) {
         level_begin.push_back(S.chol.size());
         bigs.clear();
@@ -800,14 +801,18 @@ void build_launches(Schedule& S, const uint8_t* active) {
             if (nbc > 1) wide_blocks += nbc;
         }
         if (wide_blocks > 0 && wide_blocks <= max_chain) {
-            Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, S.n_solve_chain_launches++, 0, 1, 0, -1, 0};
+            Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, S.n_solve_chain_launches++,
+                      (int32_t)S.bsolve_pairs.size(), 1, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 const int nbc = ceil_div(S.sn[t].w, kTile);
                 if (!S.active[t] || nbc < 2) continue;
                 for (int jb = nbc - 1; jb >= 0; --jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
+                for (int jb = nbc - 1; jb >= 0; jb -= kBackGroup)
+                    S.bsolve_pairs.push_back(PanelDesc{t, jb, std::min(kBackGroup, jb + 1), 0});
             }
             Lc.count = (int32_t)S.bsolve_blocks.size() - Lc.first;
+            Lc.wait_level = (int32_t)S.bsolve_pairs.size() - Lc.lds_bytes;
             S.bsolve.push_back(Lc);
             narrow_launches(lev);
             continue;

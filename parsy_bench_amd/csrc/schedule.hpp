@@ -46,6 +46,7 @@ constexpr int kTile = 64;             // tile edge of the tiled path / block-col
 constexpr int kSub = 32;              // per-wave sub-tile edge
 constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
 constexpr int kSmallMaxWidth = 64;
+constexpr int kBackGroup = 2;         // backward chain, one right-hand side: block columns per workgroup
 constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solved by one wave each
 constexpr int kPanelRows = 128;       // TRSM row chunk per workgroup (staged in LDS)
 constexpr int kSolveRows = 256;       // solve row chunk per workgroup
@@ -114,11 +115,12 @@ struct Launch {
     int32_t first, count;  // range in the kind's descriptor array
     int32_t level;         // etree level of the targets; side launches: level whose main-stream launches wait for it
     int32_t jb;            // SMALL: stage size; CHAIN: index of its ticket counter; SOLVE_PANEL / BACK: block column
-    int32_t lds_bytes;     // dynamic LDS (SMALL)
+    int32_t lds_bytes;     // dynamic LDS (SMALL); BACK chain launch: first entry of its workgroups in bsolve_pairs
     int32_t fused;         // SOLVE_PANEL / BACK: 1 = chain launch of the whole level; SMALL, SOLVE_SMALL, BACK:
                            // 2 = subtree launch (first / count: (begin, end) pairs in the kind's range array)
     int32_t side;          // 1: runs on the plan's side stream (TILES), 0: main stream
-    int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only)
+    int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only);
+                           // BACK chain launch: number of its entries in bsolve_pairs
     int32_t early;         // TILES: always 1 (kept for the launch dumps)
 };
 
@@ -205,6 +207,9 @@ struct Schedule {
     std::vector<Launch> solve;
 
     // backward solve L' x = y: levels from the root down, wide supernodes block column by block column
+    std::vector<PanelDesc> bsolve_pairs;   // chain launches, one right-hand side: (supernode, highest block column,
+                                           // blocks = 1 .. kBackGroup) per workgroup, from a supernode's last block
+                                           // column up
     std::vector<PanelDesc> bsolve_blocks;
     std::vector<Launch> bsolve;
 

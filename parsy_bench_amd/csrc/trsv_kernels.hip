@@ -1547,6 +1547,207 @@ __global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ s
     }
 }
 
+// Backward chain for ONE right-hand side: the counterpart of k_solve_chain_w.  A workgroup = eight waves = up to
+// kBackGroup (2) consecutive block columns of a wide supernode (the highest one first), taken by ticket from a list
+// that runs from the last block column of a supernode to its first; four waves share a block column, 16 columns
+// each, lanes along the rows (coalesced), 16 running sums per lane:
+//     t_c = sum_k L[k][c] x_k   over the rows k below the block.
+// First the rows below the supernode's own columns (x final: ancestors), then the supernode's later block
+// columns from the last one up, each as soon as its x is there -- through the armed buffer (the data is the
+// flag: lane k polls the value of row k), or through LDS when it is a higher block of this workgroup; the loads
+// of four 64-row pieces are in flight before the first wait.  (More block columns per workgroup would keep more of
+// the diagonal-to-diagonal hand-offs in LDS, but a block column's rows are streamed by its own waves only, and
+// the number of CUs that stream is what bounds the launches of few, wide supernodes: four per workgroup measured
+// 16.1 vs 7.6 ms on the Flan-class input.)  Then the sums are added up across the wave, the waves' columns meet
+// in LDS, and the first wave of the
+// block forms x_blk = inv(L_bb)' (y - t) as a product with the inverse diagonal block (DIAG_INVERSE; staged in LDS
+// when the wave starts) and publishes it (LDS for the blocks below it in this workgroup, armed buffer + x for
+// everybody else).  No workgroup barrier after the start, every wait bounded.
+static constexpr int kBackBlocks = kBackGroup;            // block columns per workgroup
+static constexpr int kBackWaves = 8 / kBackBlocks;        // waves per block column
+static constexpr int kBackCols = kTile / kBackWaves;      // columns per wave
+static constexpr int kBackAhead = 64 / kBackCols;         // 64-row pieces whose loads are issued before the first wait
+__global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDesc* __restrict__ sn,
+                                                                     const PanelDesc* __restrict__ groups,
+                                                                     const int32_t* __restrict__ rows,
+                                                                     const double* __restrict__ L,
+                                                                     const double* __restrict__ dinv,
+                                                                     double* __restrict__ x, double* __restrict__ xscratch,
+                                                                     int* __restrict__ info, int* __restrict__ ticket,
+                                                                     int wait_bias) {
+    __shared__ double s_inv[kBackBlocks][kInvPacked + 1];   // column c of the inverse from row c on (as k_solve_chain_w)
+    __shared__ double s_t[kBackBlocks][kTile];              // t of a block: its waves' column sums
+    __shared__ double s_pub[kBackBlocks][kTile];            // x of a block, for the blocks below it in this workgroup
+    __shared__ int s_sums_in[kBackBlocks], s_ready[kBackBlocks];
+    __shared__ int s_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = wave / kBackWaves, qw = wave % kBackWaves;   // block of the group (0: the highest), wave of the block
+    if (threadIdx.x == 0) s_task = atomicAdd(ticket, 1);
+    if (threadIdx.x < kBackBlocks) {
+        s_sums_in[threadIdx.x] = 0;
+        s_ready[threadIdx.x] = 0;
+    }
+    __syncthreads();   // (the only one)
+    const PanelDesc pd = groups[s_task];    // jb: the highest block column; row0: blocks of this workgroup (1..4)
+    if (b >= pd.row0) return;
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w;
+    const int jb = pd.jb - b, cb = jb * kTile, wbk = min(kTile, w - cb);
+    const int nbc = (w + kTile - 1) / kTile;
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    auto gave_up = [&](unsigned long long t0, int& spins) {
+        if ((++spins & 15) != 0) return false;
+        return wall_clock64() - t0 > kSolveSpinTicks ||
+               __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0;
+    };
+    auto wait_lds = [&](int* flag, int want) {
+        const unsigned long long t0 = wall_clock64();
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want || wait_bias != 0) {
+            if (gave_up(t0, spins)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return true;
+    };
+    auto inv_at = [&](int c) { return lane >= c ? c * kTile - c * (c - 1) / 2 + (lane - c) : kInvPacked; };
+    if (qw == 0) {
+        // inverse diagonal block -> LDS: lane = row, column c of the inverse from row c on
+        const double* __restrict__ src = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile);
+        double tmp[kTile];
+#pragma unroll
+        for (int c = 0; c < kTile; ++c) tmp[c] = src[c * kTile + lane];
+#pragma unroll
+        for (int c = 0; c < kTile; ++c) s_inv[b][inv_at(c)] = tmp[c];
+    }
+    // this wave's columns (clamped into the block: the sums of columns past it are not used); wave-uniform pointers,
+    // every load unconditional
+    const double* __restrict__ colp[kBackCols];
+#pragma unroll
+    for (int ci = 0; ci < kBackCols; ++ci) colp[ci] = G + (int64_t)(cb + min(kBackCols * qw + ci, wbk - 1)) * r;
+    double acc[kBackCols];
+#pragma unroll
+    for (int ci = 0; ci < kBackCols; ++ci) acc[ci] = 0.0;
+    double lv[kBackAhead][kBackCols];
+    auto load_piece = [&](int u, int k) {
+#pragma unroll
+        for (int ci = 0; ci < kBackCols; ++ci) lv[u][ci] = colp[ci][k];
+    };
+    // ---- rows below the supernode's own columns: x is final
+    for (int k0 = w + lane; k0 < r; k0 += 64 * kBackAhead) {
+        int xr[kBackAhead];
+#pragma unroll
+        for (int u = 0; u < kBackAhead; ++u) {
+            const int k = min(k0 + 64 * u, r - 1);
+            xr[u] = ri[k];
+            load_piece(u, k);
+        }
+#pragma unroll
+        for (int u = 0; u < kBackAhead; ++u) {
+            const double xk = (k0 + 64 * u < r) ? x[xr[u]] : 0.0;
+#pragma unroll
+            for (int ci = 0; ci < kBackCols; ++ci) acc[ci] = fma(lv[u][ci], xk, acc[ci]);
+        }
+    }
+    // ---- the later block columns of the supernode, last one first
+    for (int I0 = nbc - 1; I0 > jb; I0 -= kBackAhead) {
+#pragma unroll
+        for (int u = 0; u < kBackAhead; ++u)   // (pieces past jb + 1: loaded again, not used)
+            load_piece(u, min(max(I0 - u, jb + 1) * kTile + lane, w - 1));
+#pragma unroll
+        for (int u = 0; u < kBackAhead; ++u) {
+            const int I = I0 - u;
+            if (I <= jb) break;
+            const int k = I * kTile + lane;
+            double xk = 0.0;
+            if (I <= pd.jb) {
+                // a higher block of this workgroup: LDS
+                if (!wait_lds(&s_ready[pd.jb - I], 1)) {
+                    if (lane == 0) atomicMin(info, -1);   // (the result is wrong and reported; nobody may hang)
+                    return;
+                }
+                xk = s_pub[pd.jb - I][lane];
+            } else {
+                const long long* __restrict__ src = reinterpret_cast<const long long*>(xscratch + D.c0) + k;
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                long long bits = 0;
+                for (;;) {
+                    bits = k < w ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    if (__all(bits != kXArmed && wait_bias == 0)) break;
+                    if (gave_up(t0, spins)) {
+                        if (lane == 0) atomicMin(info, -1);
+                        return;
+                    }
+                    if (I <= pd.jb + 2) __builtin_amdgcn_s_sleep(1);   // (the blocks right above: the critical path)
+                    else __builtin_amdgcn_s_sleep(8);
+                }
+                xk = __longlong_as_double(bits);
+            }
+            if (k >= w) xk = 0.0;
+#pragma unroll
+            for (int ci = 0; ci < kBackCols; ++ci) acc[ci] = fma(lv[u][ci], xk, acc[ci]);
+        }
+    }
+    // ---- column sums across the wave (xor butterflies, one per column: they overlap; a butterfly that halves the
+    // columns a lane carries per step -- 17 exchanges instead of 96 -- measured slower: 7.98 vs 7.58 ms), then the
+    // block's waves meet in LDS
+#pragma unroll
+    for (int ci = 0; ci < kBackCols; ++ci) {
+        double v = acc[ci];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        acc[ci] = v;
+    }
+    if (lane < kBackCols) {
+        double v = 0.0;
+#pragma unroll
+        for (int ci = 0; ci < kBackCols; ++ci) v = (lane == ci) ? acc[ci] : v;
+        s_t[b][kBackCols * qw + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_fetch_add(&s_sums_in[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (qw != 0) return;
+    if (!wait_lds(&s_sums_in[b], kTile / kBackCols)) {
+        if (lane == 0) atomicMin(info, -1);
+        return;
+    }
+    // ---- x_blk = inv(L_bb)' (y - t): x_c = sum_{k >= c} inv(L_bb)[k][c] (y_k - t_k); lane c walks its column of
+    // the packed inverse
+    const double tk = (lane < wbk) ? x[D.c0 + cb + lane] - s_t[b][lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    s_t[b][lane] = tk;
+    __builtin_amdgcn_wave_barrier();
+    double s0 = 0.0, s1 = 0.0;
+    {
+        // column `lane` of the inverse: rows lane..63 are contiguous from lane*64 - lane(lane-1)/2
+        const double* __restrict__ col = s_inv[b] + lane * kTile - lane * (lane - 1) / 2 - lane;   // col[k], k >= lane
+        for (int k = lane; k + 1 < kTile; k += 2) {
+            s0 = fma(col[k], s_t[b][k], s0);
+            s1 = fma(col[k + 1], s_t[b][k + 1], s1);
+        }
+        if (((kTile - lane) & 1) != 0) s0 = fma(col[kTile - 1], s_t[b][kTile - 1], s0);
+    }
+    const double xi = (lane < wbk) ? s0 + s1 : 0.0;
+    if (b + 1 < pd.row0) {
+        s_pub[b][lane] = xi;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&s_ready[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (lane < wbk) {
+        __hip_atomic_store(&xscratch[D.c0 + cb + lane], xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x[D.c0 + cb + lane] = xi;
+    }
+}
+
+void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                           double* x, double* xscratch, int ticket, int wait_bias, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_bsolve_chain_w, dim3(count), dim3(kChainThreads), 0, stream, P.sn, P.bsolve_pairs + first,
+                       P.rows, L, dinv, x, xscratch, P.sinfo, P.stickets + ticket, wait_bias);
+}
+
 // mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts
 // (begin, end) pairs of bsolve_ranges, which index the whole block list); tiny: Launch::early
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
