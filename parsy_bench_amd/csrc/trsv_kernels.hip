@@ -1229,10 +1229,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            const int32_t* __restrict__ rows,
                                                            const double* __restrict__ L,
                                                            double* __restrict__ x, double* __restrict__ xscratch,
-                                                           int nrhs, int ldx, int chain, int* __restrict__ flags,
-                                                           int epoch0, int* __restrict__ info,
+                                                           int nrhs, int ldx, int chain, int* __restrict__ info,
                                                            int* __restrict__ ticket, int wait_bias, int nblocks,
-                                                           int fstride, const int32_t* __restrict__ ranges,
+                                                           const int32_t* __restrict__ ranges,
                                                            const double* __restrict__ dinv) {
     // chain != 0: every block column of the wide supernodes of a level is in this launch; block jb takes the x
     // of blocks jb+1.. of its supernode as they are published: as the data itself, through the armed buffer
@@ -1249,10 +1248,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
     if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
     __syncthreads();
-    // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on (one set of flags per lane)
+    // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on
     const int plane = s_task / nblocks;
     const int task = s_task - plane * nblocks;
-    flags += (int64_t)plane * fstride;
     const int q_begin = ranges ? ranges[2 * task] : task;
     const int q_end = ranges ? ranges[2 * task + 1] : q_begin + 1;
   for (int qsn = q_begin; qsn < q_end; ++qsn) {
@@ -1751,7 +1749,7 @@ void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const d
 // mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts
 // (begin, end) pairs of bsolve_ranges, which index the whole block list); tiny: Launch::early
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int epoch0, int ticket,
+                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int ticket,
                          int wait_bias, hipStream_t stream) {
     if (count <= 0) return;
     const int chain = mode == 1;
@@ -1766,12 +1764,10 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
     const dim3 grid = chain ? dim3(count * lanes) : dim3(count, lanes);
     if (nrhs == 1)
         hipLaunchKernelGGL(k_bsolve_block<1>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
-                           nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
-                           P.flag_stride, ranges, dinv);
+                           nrhs, ldx, chain, P.sinfo, P.stickets + ticket, wait_bias, count, ranges, dinv);
     else
         hipLaunchKernelGGL(k_bsolve_block<4>, grid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
-                           nrhs, ldx, chain, P.flags, epoch0, P.sinfo, P.stickets + ticket, wait_bias, count,
-                           P.flag_stride, ranges, dinv);
+                           nrhs, ldx, chain, P.sinfo, P.stickets + ticket, wait_bias, count, ranges, dinv);
 }
 
 // SOLVE_FIXUP: solved blocks of the wide supernodes go from scratch into x.

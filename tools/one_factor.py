@@ -1,4 +1,5 @@
-"""Minimal driver for profiling: N factorizations (+ optional solves) of a workload, device-resident."""
+"""Minimal driver for profiling: N factorizations (+ optional solves) of a workload, device-resident.
+Usage: one_factor.py WORKLOAD [FACTORIZATIONS [SOLVES [NRHS]]]"""
 import sys
 from pathlib import Path
 import numpy as np
@@ -19,13 +20,14 @@ for _ in range(reps):
 torch.cuda.synchronize()
 print("status", plan.status(), "ms", plan.last_factor_ms())
 nsolve = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+nrhs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 if nsolve:
-    x = torch.ones(sym.n, dtype=torch.float64, device=dev)
+    x = torch.ones(sym.n * nrhs, dtype=torch.float64, device=dev)
     for _ in range(nsolve):
-        plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+        plan.solve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0)
         torch.cuda.synchronize()
     print("forward solve ms", plan.last_solve_ms())
     for _ in range(nsolve):
-        plan.backsolve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
+        plan.backsolve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0)
         torch.cuda.synchronize()
     print("backward solve ms", plan.last_solve_ms())
