@@ -113,6 +113,11 @@ void parsy_dropin_reset(void);
 /* ------------------------------------------------------------------------ */
 
 typedef struct parsy_plan parsy_plan;
+/* A plan owns scratch that its launches share (tile flags and ticket counters of the factorization; inverse
+ * diagonal blocks, the hand-off vector and ticket counters of the solves): calls on ONE plan must be issued on
+ * one stream, or be separated by the caller (events / synchronisation) -- one factorization or solve of a plan in
+ * flight at a time.  Independent work in flight takes one plan each (plans of the same pattern are cheap next to
+ * the factor: DESIGN.md, `throughput_in_flight`).  Calls are serialised on the host by a per-plan mutex. */
 
 /* Sizes and work counts of a plan (all exact, from the pattern). */
 typedef struct parsy_plan_info {
