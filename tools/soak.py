@@ -10,7 +10,9 @@ import torch
 from parsy_bench_amd import api, inspector as I, matrices as M
 dev = torch.device("cuda", 0)
 bad = 0
-for name, reps in (("mid3d", 1500), ("lap30", 600), ("nd24k", 600)):
+FACTOR_REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+SOLVE_REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+for name, reps in (("mid3d", 2 * FACTOR_REPS), ("lap30", FACTOR_REPS), ("nd24k", FACTOR_REPS)):
     A, perm = M.workload(name)
     sym = I.analyze(A, perm)
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
@@ -40,32 +42,43 @@ for name, reps in (("mid3d", 1500), ("lap30", 600), ("nd24k", 600)):
             stat += st != 0
         print(f"{name:6s} {mode:14s}: {reps} rounds, {mism} factor mismatches, {stat} bad status, {time.time() - t0:.1f} s", flush=True)
         bad += mism + stat
-# the solve chains (forward: flags + published x blocks, atomics on shared rows -> equal to rounding;
-# backward: fixed order -> bitwise)
-for name, reps in (("lap30", 1000), ("nd24k", 1000)):
+# the solves (forward: atomics on shared rows -> equal to rounding; backward: fixed order -> bitwise), with one
+# right-hand side (wave kernels, armed hand-off buffer) and with five (workgroup kernels, flags); lap30 a second
+# time with subtree launches forced
+import os
+for name, reps, subtrees in (("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS // 2, "2"), ("nd24k", SOLVE_REPS, None),
+                             ("parabolic_fem", SOLVE_REPS // 2, None)):
     A, perm = M.workload(name)
     sym = I.analyze(A, perm)
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    if subtrees is not None:
+        os.environ["PARSY_SUBTREES"] = subtrees
     plan = api.Plan(sym, 0)
+    os.environ.pop("PARSY_SUBTREES", None)
     L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
     plan.factor_device(values.data_ptr(), L.data_ptr(), 0)
     torch.cuda.synchronize()
     rng = np.random.default_rng(3)
-    b = torch.from_numpy(rng.standard_normal(sym.n)).to(dev)
-    x = b.clone(); plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0); torch.cuda.synchronize()
-    xf = x.clone()
-    y = b.clone(); plan.backsolve_device(L.data_ptr(), y.data_ptr(), 1, sym.n, 0); torch.cuda.synchronize()
-    yb = y.clone()
-    torch.cuda.synchronize()
-    worst = 0.0; bmis = 0; stat = 0
-    for i in range(reps):
-        x.copy_(b); plan.solve_device(L.data_ptr(), x.data_ptr(), 1, sym.n, 0)
-        y.copy_(b); plan.backsolve_device(L.data_ptr(), y.data_ptr(), 1, sym.n, 0)
+    for nrhs in (1, 5):
+        b = torch.from_numpy(rng.standard_normal(sym.n * nrhs)).to(dev)
+        x = b.clone(); plan.solve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0); torch.cuda.synchronize()
+        xf = x.clone()
+        y = b.clone(); plan.backsolve_device(L.data_ptr(), y.data_ptr(), nrhs, sym.n, 0); torch.cuda.synchronize()
+        yb = y.clone()
         torch.cuda.synchronize()
-        worst = max(worst, float((x - xf).abs().max() / xf.abs().max()))
-        bmis += not bool(torch.equal(y, yb))
-        stat += plan.status() != 0
-    print(f"{name:6s} solves: {reps} rounds, forward max rel deviation {worst:.2e}, backward mismatches {bmis}, bad status {stat}", flush=True)
-    bad += bmis + stat + (worst > 1e-12)
+        worst = 0.0; bmis = 0; stat = 0
+        n_rounds = reps if nrhs == 1 else reps // 5
+        for i in range(n_rounds):
+            x.copy_(b); plan.solve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0)
+            torch.cuda.synchronize()
+            stat += plan.solve_status() != 0
+            y.copy_(b); plan.backsolve_device(L.data_ptr(), y.data_ptr(), nrhs, sym.n, 0)
+            torch.cuda.synchronize()
+            stat += plan.solve_status() != 0
+            worst = max(worst, float((x - xf).abs().max() / xf.abs().max()))
+            bmis += not bool(torch.equal(y, yb))
+        print(f"{name:13s} subtrees {subtrees or 'auto':4s} nrhs {nrhs}: {n_rounds} rounds, forward max rel deviation {worst:.2e}, "
+              f"backward mismatches {bmis}, bad status {stat}", flush=True)
+        bad += bmis + stat + (worst > 1e-12)
 print("SOAK", "OK" if bad == 0 else "FAILED")
 sys.exit(1 if bad else 0)
