@@ -439,7 +439,22 @@ def test_flan_class_size_on_device(api):
         panel = L[int(sym.p[c0]): int(sym.p[c0]) + int(w[sn] * r[sn])].view(int(w[sn]), int(r[sn]))
         t[c0:c1] = panel @ x[rows[rs]]
     assert float((t - 1.0).abs().max()) <= 1e-8
-    assert plan.status() == 0
+    assert plan.status() == 0 and plan.solve_status() == 0
+    # and the factor itself against the ORIGINAL matrix: x = P' L'^-1 L^-1 P b, residual of A x = b on the host
+    # (north_star: 1e-10 relative) -- an oracle-independent check of factorization + both solves at full size
+    rng = np.random.default_rng(5)
+    bh = rng.standard_normal(sym.n)
+    perm_t = torch.from_numpy(sym.Perm.astype(np.int64)).to(dev)
+    z = torch.from_numpy(bh).to(dev)[perm_t].contiguous()
+    plan.solve_device(L.data_ptr(), z.data_ptr(), 1, sym.n, 0)
+    plan.backsolve_device(L.data_ptr(), z.data_ptr(), 1, sym.n, 0)
+    torch.cuda.synchronize()
+    assert plan.solve_status() == 0
+    xh = np.empty(sym.n)
+    xh[sym.Perm] = z.cpu().numpy()
+    As = A.to_scipy()
+    res = As @ xh - bh
+    assert np.abs(res).max() <= RESID_TOL * (abs(As).max() * np.abs(xh).max() + np.abs(bh).max())
 
 
 def test_levels_with_hundreds_of_walkers(api, oracle):
