@@ -265,7 +265,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                     break;
                 }
                 launch_bsolve_block(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx, l.fused,
-                                    l.early != 0,
+                                    l.early,
                                     l.fused == 1 ? l.jb : 0, pl->solve_wait_bias, stream);
                 break;
         }

@@ -71,7 +71,7 @@ void launch_diag_inverse(const DevicePattern& P, int count, const double* L, dou
 void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                            double* x, double* xscratch, int ticket, int wait_bias, hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int ticket,
+                         double* x, double* xscratch, int nrhs, int ldx, int mode, int tiny, int ticket,
                          int wait_bias, hipStream_t stream);
 void launch_rhs_ones(const DevicePattern& P, int nsuper, int max_rows, const double* L, double* b,
                      hipStream_t stream);

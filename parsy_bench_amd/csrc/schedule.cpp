@@ -703,6 +703,7 @@ void build_launches(Schedule& S, const uint8_t* active) {
         {
             // supernodes of one block column: the tiny ones (width <= kTinyWidth: one wave each) in a launch of
             // their own when there are enough of them, the others one workgroup each
+            // (forward: the second width class of the one-wave kernel measured no faster than the workgroup kernel)
             std::vector<int32_t> tiny, narrow;
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
@@ -773,20 +774,27 @@ void build_launches(Schedule& S, const uint8_t* active) {
     // the supernodes of one block column of a level: the tiny ones (one wave each: Launch::early = 1) in a launch
     // of their own when there are enough of them, the others one workgroup each
     auto narrow_launches = [&](int lev) {
-        std::vector<int32_t> tiny, narrow;
+        std::vector<int32_t> tiny, tiny2, narrow;
         for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
             const int t = S.levelSet[q];
             if (!in_level_launches(t) || S.sn[t].w > kTile) continue;
-            (S.sn[t].w <= kTinyWidth ? tiny : narrow).push_back(t);
+            (S.sn[t].w <= kTinyWidth ? tiny : S.sn[t].w <= kTinyWidth2 ? tiny2 : narrow).push_back(t);
         }
-        if (!narrow.empty() && tiny.size() < 64) {
-            narrow.insert(narrow.end(), tiny.begin(), tiny.end());
+        // (a group too small for a launch of its own joins the next wider one; the second width class of the
+        // one-wave kernel pays from a few hundred supernodes on: Flan-class backward solve 7.60 -> 7.32 ms, but
+        // +6 % on the nd24k-class input with an extra launch per level)
+        if (tiny2.size() < 512 && !narrow.empty()) {
+            narrow.insert(narrow.end(), tiny2.begin(), tiny2.end());
+            tiny2.clear();
+        }
+        if (tiny.size() < 64 && !(tiny2.empty() && narrow.empty())) {
+            (tiny2.empty() ? narrow : tiny2).insert((tiny2.empty() ? narrow : tiny2).end(), tiny.begin(), tiny.end());
             tiny.clear();
         }
-        for (const std::vector<int32_t>* group : {&tiny, &narrow}) {
+        for (const std::vector<int32_t>* group : {&tiny, &tiny2, &narrow}) {
             if (group->empty()) continue;
             Launch Ln{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), (int32_t)group->size(), lev, 0, 0, 0, 0, -1,
-                      group == &tiny ? 1 : 0};
+                      group == &tiny ? 1 : group == &tiny2 ? 2 : 0};
             for (int32_t t : *group) S.bsolve_blocks.push_back(PanelDesc{t, 0, 0, 0});
             S.bsolve.push_back(Ln);
         }

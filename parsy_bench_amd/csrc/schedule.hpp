@@ -47,7 +47,9 @@ constexpr int kSub = 32;              // per-wave sub-tile edge
 constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
 constexpr int kSmallMaxWidth = 64;
 constexpr int kBackGroup = 2;         // backward chain, one right-hand side: block columns per workgroup
-constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solved by one wave each
+constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solved by one wave each (and walked in
+                                      // subtrees); kTinyWidth2: second width class of the one-wave kernels
+constexpr int kTinyWidth2 = 32;
 constexpr int kPanelRows = 128;       // TRSM row chunk per workgroup (staged in LDS)
 constexpr int kSolveRows = 256;       // solve row chunk per workgroup
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small(const SnDesc* __restri
 // wave-uniform); the rows below the block are one row per lane, their first 64 loaded before the substitution
 // starts, and are subtracted from x with atomics.  All loads of a supernode are in flight together: its latency
 // is one memory round trip instead of the three of the workgroup kernel.
-static constexpr int kTinyW = kTinyWidth;
+template <int kTinyW>   // width class of the launch (kTinyWidth; the backward kernel also has kTinyWidth2)
 __global__ __launch_bounds__(64) void k_solve_tiny(const SnDesc* __restrict__ sn, const int32_t* __restrict__ list,
                                                    const int32_t* __restrict__ ranges,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ L,
@@ -404,9 +404,9 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
     // subtree launch: `first` counts (begin, end) pairs of solve_small_ranges, which index the whole list
     const int32_t* list = subtrees ? P.solve_small_list : P.solve_small_list + first;
     const int32_t* ranges = subtrees ? P.solve_small_ranges + 2 * first : nullptr;
-    if (nrhs < mrhs_min() && wmax <= kTinyW) {
-        hipLaunchKernelGGL(k_solve_tiny, dim3(count, std::min(kPassLanes, nrhs)), dim3(64), 0, stream, P.sn, list, ranges,
-                           P.rows, L, x, nrhs, ldx);
+    if (nrhs < mrhs_min() && wmax <= kTinyWidth) {   // one wave per supernode (or per subtree of them)
+        hipLaunchKernelGGL(k_solve_tiny<kTinyWidth>, dim3(count, std::min(kPassLanes, nrhs)), dim3(64), 0, stream, P.sn,
+                           list, ranges, P.rows, L, x, nrhs, ldx);
         return;
     }
     if (nrhs >= mrhs_min()) {
@@ -1481,6 +1481,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
 // the <= 16 columns and the parts are summed across the wave once, at the end (xor butterfly); lane c then holds
 // column c of the diagonal block and the transposed substitution goes from the last column up with lane
 // broadcasts (v_readlane).
+template <int kTinyW>   // width class of the launch: kTinyWidth (16) or kTinyWidth2 (32)
 __global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ sn, const PanelDesc* __restrict__ pds,
                                                     const int32_t* __restrict__ ranges,
                                                     const int32_t* __restrict__ rows, const double* __restrict__ L,
@@ -1747,17 +1748,22 @@ void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const d
 }
 
 // mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts
-// (begin, end) pairs of bsolve_ranges, which index the whole block list); tiny: Launch::early
+// (begin, end) pairs of bsolve_ranges, which index the whole block list); tiny: Launch::early (0 | width class 1 | 2)
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                         double* x, double* xscratch, int nrhs, int ldx, int mode, bool tiny, int ticket,
+                         double* x, double* xscratch, int nrhs, int ldx, int mode, int tiny, int ticket,
                          int wait_bias, hipStream_t stream) {
     if (count <= 0) return;
     const int chain = mode == 1;
     const PanelDesc* pds = mode == 2 ? P.bsolve_blocks : P.bsolve_blocks + first;
     const int32_t* ranges = mode == 2 ? P.bsolve_ranges + 2 * first : nullptr;
-    if (tiny) {   // supernodes of width <= kTinyWidth (a subtree launch or a level's launch of them): one wave each
-        hipLaunchKernelGGL(k_bsolve_tiny, dim3(count, std::min(kPassLanes, nrhs)), dim3(64), 0, stream, P.sn, pds, ranges,
-                           P.rows, L, x, nrhs, ldx);
+    if (tiny) {   // width class kTinyWidth (1) or kTinyWidth2 (2), a subtree launch or a level's launch: one wave each
+        const dim3 grid(count, std::min(kPassLanes, nrhs));
+        if (tiny == 1)
+            hipLaunchKernelGGL(k_bsolve_tiny<kTinyWidth>, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs,
+                               ldx);
+        else
+            hipLaunchKernelGGL(k_bsolve_tiny<kTinyWidth2>, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs,
+                               ldx);
         return;
     }
     const int lanes = nrhs == 1 ? 1 : std::min(kPassLanes, (nrhs + 3) / 4);
