@@ -187,6 +187,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # every rank takes part in one collective before the first point-to-point exchange (only some ranks take
+        # part in those: with RCCL the first call on a group must be made by all of its ranks)
+        t_init = torch.zeros(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t_init)
     local_rank = dev_index
 
     from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
