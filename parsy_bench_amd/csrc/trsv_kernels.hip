@@ -1223,6 +1223,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 // earlier launches):   t = y_blk - L(below, blk)' x(below),   x_blk = inv(L_bb)' t.
 // The product runs one wave per column with lanes along the (contiguous) rows.
 // ---------------------------------------------------------------------------
+static constexpr int kLdRedB = 65;   // row stride of a wave's reduction buffer (doubles): conflict-free both ways
 template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restrict__ sn,
                                                            const PanelDesc* __restrict__ pds,
@@ -1243,6 +1244,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     __shared__ double Dg[kTile * kLdDiag];
     __shared__ double invd[kTile];
     __shared__ double ts[kTile][NQ];
+    __shared__ double s_red[kThreads / 64][(kTile / 4) * kLdRedB];   // per wave: the lanes' parts of its 16 column sums
     __shared__ int s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
@@ -1401,14 +1403,27 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                     }
                 }
             }
+            // column sums across the wave through LDS (as k_bsolve_chain_w: the lanes park their 16 parts, lane
+            // (ci, g) adds up 16 of them, two exchanges finish the column), one right-hand side after the other
 #pragma unroll
-            for (int ci = 0; ci < kTile / 4; ++ci)
+            for (int q = 0; q < NQ; ++q) {
+                double* __restrict__ red = s_red[wave];
+                __builtin_amdgcn_wave_barrier();   // (the parts of the right-hand side before are consumed)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    double v = acc[ci][q];
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                    if (lane == 0) ts[wave + 4 * ci][q] -= v;  // each (column, q) has one writer
+                for (int ci = 0; ci < kTile / 4; ++ci) red[ci * kLdRedB + lane] = acc[ci][q];
+                __builtin_amdgcn_wave_barrier();
+                const int ci = lane & 15, g = lane >> 4;
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    v0 += red[ci * kLdRedB + 16 * g + i];
+                    v1 += red[ci * kLdRedB + 16 * g + i + 1];
                 }
+                double v = v0 + v1;
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g == 0) ts[wave + 4 * ci][q] -= v;  // each (column, q) has one writer
+            }
         }
         __syncthreads();
         if (chain) {
@@ -1486,6 +1501,7 @@ __global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ s
                                                     const int32_t* __restrict__ ranges,
                                                     const int32_t* __restrict__ rows, const double* __restrict__ L,
                                                     double* __restrict__ x, int nrhs, int ldx) {
+    __shared__ double s_red[kTinyW * kLdRedB];   // the lanes' parts of the column sums
     const int lane = threadIdx.x;
     const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
     const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
@@ -1524,12 +1540,25 @@ __global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ s
                 for (int c = 0; c < kTinyW; ++c) p[c] = fma(G[(int64_t)min(c, w - 1) * r + k], xk, p[c]);
             }
             double t = lane < w ? xq[D.c0 + lane] : 0.0;
+            {
+                // column sums across the wave through LDS: lane (c, g) adds up 64 / kGroups of the lanes' parts of
+                // column c, the exchanges over g finish it
+                constexpr int kGroups = 64 / kTinyW, kPer = 64 / kGroups;
+                __builtin_amdgcn_wave_barrier();   // (the parts of the right-hand side / supernode before are consumed)
 #pragma unroll
-            for (int c = 0; c < kTinyW; ++c) {
-                double v = p[c];
+                for (int c = 0; c < kTinyW; ++c) s_red[c * kLdRedB + lane] = p[c];
+                __builtin_amdgcn_wave_barrier();
+                const int c = lane % kTinyW, g = lane / kTinyW;
+                double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                t = (lane == c && c < w) ? t - v : t;
+                for (int i = 0; i < kPer; i += 2) {
+                    v0 += s_red[c * kLdRedB + kPer * g + i];
+                    v1 += s_red[c * kLdRedB + kPer * g + i + 1];
+                }
+                double v = v0 + v1;
+#pragma unroll
+                for (int off = kTinyW; off < 64; off <<= 1) v += __shfl_xor(v, off);
+                t = (lane < w) ? t - v : t;   // (lane c < kTinyW holds column c's sum: g == 0)
             }
             // x_k = (t_k - sum_{j > k} L[j][k] x_j) / L[k][k], from the last column up: lane c holds L[k][c] = lc[k]
             double xfin = 0.0;
@@ -1566,6 +1595,7 @@ static constexpr int kBackBlocks = kBackGroup;            // block columns per w
 static constexpr int kBackWaves = 8 / kBackBlocks;        // waves per block column
 static constexpr int kBackCols = kTile / kBackWaves;      // columns per wave
 static constexpr int kBackAhead = 64 / kBackCols;         // 64-row pieces whose loads are issued before the first wait
+static constexpr int kLdRed = 65;                         // row stride of a wave's reduction buffer (doubles)
 __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDesc* __restrict__ sn,
                                                                      const PanelDesc* __restrict__ groups,
                                                                      const int32_t* __restrict__ rows,
@@ -1577,6 +1607,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
     __shared__ double s_inv[kBackBlocks][kInvPacked + 1];   // column c of the inverse from row c on (as k_solve_chain_w)
     __shared__ double s_t[kBackBlocks][kTile];              // t of a block: its waves' column sums
     __shared__ double s_pub[kBackBlocks][kTile];            // x of a block, for the blocks below it in this workgroup
+    __shared__ double s_red[kChainThreads / 64][kBackCols * kLdRed];   // per wave: the lanes' parts of the column sums
     __shared__ int s_sums_in[kBackBlocks], s_ready[kBackBlocks];
     __shared__ int s_task;
     const int lane = threadIdx.x & 63;
@@ -1689,21 +1720,28 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
             for (int ci = 0; ci < kBackCols; ++ci) acc[ci] = fma(lv[u][ci], xk, acc[ci]);
         }
     }
-    // ---- column sums across the wave (xor butterflies, one per column: they overlap; a butterfly that halves the
-    // columns a lane carries per step -- 17 exchanges instead of 96 -- measured slower: 7.98 vs 7.58 ms), then the
-    // block's waves meet in LDS
+    // ---- column sums across the wave, through LDS: every lane parks its kBackCols parts, lane (c, g) adds up the
+    // parts of 64 / (64 / kBackCols) rows for column c, two exchanges finish the column (16 xor butterflies of six
+    // steps each took about 1 us of every step of the chain; a butterfly that halves the columns a lane carries
+    // per step -- 17 exchanges -- measured slower still); then the block's waves meet in LDS
+    {
+        constexpr int kGroups = 64 / kBackCols;      // row groups a column's 64 parts are split into
+        constexpr int kPer = 64 / kGroups;           // parts per group (= kBackCols)
+        double* __restrict__ red = s_red[wave];
 #pragma unroll
-    for (int ci = 0; ci < kBackCols; ++ci) {
-        double v = acc[ci];
+        for (int ci = 0; ci < kBackCols; ++ci) red[ci * kLdRed + lane] = acc[ci];
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane % kBackCols, g = lane / kBackCols;
+        double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        acc[ci] = v;
-    }
-    if (lane < kBackCols) {
-        double v = 0.0;
+        for (int i = 0; i < kPer; i += 2) {
+            v0 += red[c * kLdRed + kPer * g + i];
+            v1 += red[c * kLdRed + kPer * g + i + 1];
+        }
+        double v = v0 + v1;
 #pragma unroll
-        for (int ci = 0; ci < kBackCols; ++ci) v = (lane == ci) ? acc[ci] : v;
-        s_t[b][kBackCols * qw + lane] = v;
+        for (int off = kBackCols; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if (g == 0) s_t[b][kBackCols * qw + c] = v;
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_fetch_add(&s_sums_in[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
