@@ -167,9 +167,11 @@ int parsy_plan_set_active(parsy_plan* plan, const uint8_t* mask);
  * returns the number of tiles that would never be finished -- 0 means the schedule cannot
  * deadlock at that residency -- or -1 for a bad argument.  The kernel runs 2 workgroups per CU. */
 long long parsy_plan_chain_check(const parsy_plan* plan, int slots);
-/* Host-side consistency check of the factorization's schedule (pieces, levels, windows of the update entries,
- * exact cover of every (target, descendant) update, launch order): number of violations, 0 = consistent
- * (parsy_last_error describes the first one).  For tests and for callers that build plans from their own arrays. */
+/* Host-side consistency check of the plan's schedules -- factorization: pieces, levels, windows of the update
+ * entries, exact cover of every (target, descendant) update, subtree launches, launch order; solves: every active
+ * supernode / chunk / block column solved exactly once in each direction, subtree runs in order, width classes,
+ * the backward chain's groups --: number of violations, 0 = consistent (parsy_last_error describes the first
+ * one).  For tests and for callers that build plans from their own arrays. */
 long long parsy_plan_check(const parsy_plan* plan);
 
 /* Numeric factorization, everything on the device.

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 
@@ -938,12 +939,142 @@ int64_t simulate_chain(const Schedule& S, int slots) {
     return stuck;
 }
 
+// The launches of both solves: every active supernode of one block column is solved exactly once in each direction
+// (subtree runs in index order forward, reversed backward; a member's ancestors inside the run), every 256-row
+// chunk / block column of an active wide supernode appears once, the backward chain's groups cover a supernode's
+// block columns from the last one down, a level's launches come after (forward) / before (backward) the levels
+// below it.
+static void check_solve_launches(const Schedule& S, const std::function<void(const std::string&)>& fail) {
+    const int ns = S.nsuper;
+    std::vector<int> level_of(ns, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) level_of[S.levelSet[q]] = l;
+    // ---- forward
+    {
+        std::vector<int> seen(ns, 0);
+        std::vector<int64_t> chunks(ns, 0);
+        int last_level = -1;
+        for (const Launch& l : S.solve) {
+            if (l.kind == kLaunchSolveSmall) {
+                if (l.fused == 2) {
+                    for (int b = l.first; b < l.first + l.count; ++b) {
+                        const int32_t q0 = S.solve_small_ranges[2 * (size_t)b], q1 = S.solve_small_ranges[2 * (size_t)b + 1];
+                        if (q0 < 0 || q1 <= q0 || q1 > (int32_t)S.solve_small_list.size()) {
+                            fail("forward subtree launch: bad range " + std::to_string(b));
+                            continue;
+                        }
+                        for (int32_t q = q0; q < q1; ++q) {
+                            const int t = S.solve_small_list[q];
+                            seen[t]++;
+                            if (q > q0 && t <= S.solve_small_list[q - 1]) fail("forward subtree run is not in index order");
+                            if (S.sn[t].w > l.jb) fail("forward subtree launch: supernode wider than the launch's width class");
+                        }
+                    }
+                } else {
+                    if (l.level < last_level) fail("forward solve launches go down a level");
+                    last_level = l.level;
+                    for (int q = l.first; q < l.first + l.count; ++q) {
+                        const int t = S.solve_small_list[q];
+                        seen[t]++;
+                        if (level_of[t] != l.level) fail("forward launch holds a supernode of another level");
+                        if (S.sn[t].w > l.jb || S.sn[t].w > kTile) fail("forward launch: supernode wider than its width class");
+                    }
+                }
+            } else if (l.kind == kLaunchSolvePanel) {
+                if (l.level < last_level) fail("forward solve launches go down a level");
+                last_level = l.level;
+                for (int q = l.first; q < l.first + l.count; ++q) {
+                    const PanelDesc& pd = S.solve_panels[q];
+                    if (pd.sn < 0 || pd.sn >= ns || S.sn[pd.sn].w <= kTile || level_of[pd.sn] != l.level)
+                        fail("forward chain launch: bad chunk descriptor " + std::to_string(q));
+                    else if (l.fused) {
+                        if (pd.row0 != pd.jb * kSolveRows || pd.row0 >= S.sn[pd.sn].r) fail("forward chain launch: bad chunk rows");
+                        chunks[pd.sn]++;
+                    }
+                }
+            }
+        }
+        for (int t = 0; t < ns; ++t) {
+            const bool narrow = S.sn[t].w <= kTile;
+            if (narrow && seen[t] != (S.active[t] ? 1 : 0))
+                fail("supernode " + std::to_string(t) + " is in " + std::to_string(seen[t]) + " forward launches");
+            if (!narrow && S.solve_fix_list.empty() && chunks[t] != (S.active[t] ? ceil_div(S.sn[t].r, kSolveRows) : 0))
+                fail("wide supernode " + std::to_string(t) + ": " + std::to_string(chunks[t]) + " forward chunks");
+        }
+    }
+    // ---- backward
+    {
+        std::vector<int> seen(ns, 0);
+        std::vector<int64_t> blocks(ns, 0), grouped(ns, 0);
+        for (const Launch& l : S.bsolve) {
+            if (l.kind != kLaunchBackBlock) continue;
+            if (l.fused == 2) {
+                for (int b = l.first; b < l.first + l.count; ++b) {
+                    const int32_t q0 = S.bsolve_ranges[2 * (size_t)b], q1 = S.bsolve_ranges[2 * (size_t)b + 1];
+                    if (q0 < 0 || q1 <= q0 || q1 > (int32_t)S.bsolve_blocks.size()) {
+                        fail("backward subtree launch: bad range " + std::to_string(b));
+                        continue;
+                    }
+                    for (int32_t q = q0; q < q1; ++q) {
+                        const int t = S.bsolve_blocks[q].sn;
+                        seen[t]++;
+                        if (q > q0 && t >= S.bsolve_blocks[q - 1].sn) fail("backward subtree run is not in reverse index order");
+                        if (S.sn[t].w > kTinyWidth) fail("backward subtree launch: supernode wider than the one-wave kernel");
+                    }
+                }
+                continue;
+            }
+            for (int q = l.first; q < l.first + l.count; ++q) {
+                const PanelDesc& pd = S.bsolve_blocks[q];
+                if (pd.sn < 0 || pd.sn >= ns || pd.jb < 0 || pd.jb * kTile >= S.sn[pd.sn].w || level_of[pd.sn] != l.level) {
+                    fail("backward launch: bad block descriptor " + std::to_string(q));
+                    continue;
+                }
+                if (S.sn[pd.sn].w <= kTile) {
+                    seen[pd.sn]++;
+                    if (l.early == 1 && S.sn[pd.sn].w > kTinyWidth) fail("backward launch: supernode wider than its width class");
+                    if (l.early == 2 && S.sn[pd.sn].w > kTinyWidth2) fail("backward launch: supernode wider than its width class");
+                } else {
+                    blocks[pd.sn]++;
+                }
+            }
+            if (l.fused == 1) {
+                // the groups of the one-right-hand-side kernel: the same block columns, last one first
+                int prev_sn = -1, next_jb = -1;
+                for (int g = l.lds_bytes; g < l.lds_bytes + l.wait_level; ++g) {
+                    const PanelDesc& pd = S.bsolve_pairs[(size_t)g];
+                    if (pd.sn != prev_sn) {
+                        if (prev_sn >= 0 && next_jb != -1) fail("backward groups of supernode " + std::to_string(prev_sn) + " stop early");
+                        prev_sn = pd.sn;
+                        next_jb = ceil_div(S.sn[pd.sn].w, kTile) - 1;
+                    }
+                    if (pd.jb != next_jb || pd.row0 < 1 || pd.row0 > kBackGroup || pd.row0 > pd.jb + 1)
+                        fail("backward group " + std::to_string(g) + " does not continue its supernode's block columns");
+                    grouped[pd.sn] += pd.row0;
+                    next_jb = pd.jb - pd.row0;
+                }
+                if (prev_sn >= 0 && next_jb != -1) fail("backward groups of supernode " + std::to_string(prev_sn) + " stop early");
+            }
+        }
+        for (int t = 0; t < ns; ++t) {
+            const int nbc = ceil_div(S.sn[t].w, kTile);
+            if (nbc == 1 && seen[t] != (S.active[t] ? 1 : 0))
+                fail("supernode " + std::to_string(t) + " is in " + std::to_string(seen[t]) + " backward launches");
+            if (nbc > 1 && blocks[t] != (S.active[t] ? nbc : 0))
+                fail("wide supernode " + std::to_string(t) + ": " + std::to_string(blocks[t]) + " backward blocks");
+            if (nbc > 1 && S.active[t] && !S.bsolve_pairs.empty() && grouped[t] != nbc)
+                fail("wide supernode " + std::to_string(t) + ": groups cover " + std::to_string(grouped[t]) + " block columns");
+        }
+    }
+}
+
 int64_t check_schedule(const Schedule& S, std::string& what) {
     int64_t bad = 0;
     auto fail = [&](const std::string& msg) {
         if (bad++ == 0) what = msg;
     };
-    if (S.solve_only) return 0;
+    check_solve_launches(S, fail);
+    if (S.solve_only) return bad;
     const int nc = (int)S.csn.size();
     // ---- pieces tile their supernode; levels respect the chain-extended etree
     for (int t = 0; t < S.nsuper; ++t) {

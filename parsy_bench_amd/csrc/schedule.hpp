@@ -242,8 +242,10 @@ void build_launches(Schedule& S, const uint8_t* active);
 // residency).  Host only; used by the tests and available to callers that want to check a plan.
 int64_t simulate_chain(const Schedule& S, int slots);
 // Host-side consistency check of the Cholesky view: levels of sources and targets, windows of the wave and BIG
-// entries, exact cover of every update by its entries (flop identity), order of the launch sequence.  Returns the
-// number of violations (0 = consistent) and describes the first one in `what`.
+// entries, exact cover of every update by its entries (flop identity), order of the launch sequence -- and of the
+// launches of both solves (every active supernode / chunk / block column exactly once, subtree runs in order,
+// width classes, the backward chain's groups).  Returns the number of violations (0 = consistent) and describes
+// the first one in `what`.
 int64_t check_schedule(const Schedule& S, std::string& what);
 constexpr int kSmallMaxUpdates = 8;   // supernodes with more updates go the tiled way (MFMA streams, parallel tiles)
 inline bool is_small(const SnDesc& d) {

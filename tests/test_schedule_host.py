@@ -205,3 +205,28 @@ def test_subtree_launches_replace_the_narrow_levels(name, monkeypatch):
             assert pi.solve_subtree_supernodes <= int(m.sum())
     finally:
         N.lib().parsy_plan_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["small3d", "mid3d", "lap30"])
+def test_solve_launches_are_consistent(name, monkeypatch):
+    """parsy_plan_check also walks the launches of both solves: every active supernode of one block column is solved
+    exactly once forward and backward, every chunk / block column of a wide one appears once, subtree runs are in
+    (reverse) index order, width classes hold, the backward chain's groups cover a supernode's block columns -- for the
+    default plan, with subtrees forced, in the per-block-column fallback form and for the shards of a 2-way cut."""
+    A, perm, sym = problem(name)
+    for env in ({}, {"PARSY_SUBTREES": "2"}, {"PARSY_SUBTREES": "0"}, {"PARSY_FORCE_UNFUSED": "1"}):
+        for k in ("PARSY_SUBTREES", "PARSY_FORCE_UNFUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h, info = host_plan(sym)
+        try:
+            assert N.lib().parsy_plan_check(h) == 0, (env, N.last_error())
+            from parsy_bench_amd import multigpu as MG
+            cut = MG.cut_subtrees(sym, 2)
+            for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+                m = np.ascontiguousarray(mask, dtype=np.uint8)
+                assert N.lib().parsy_plan_set_active(h, N.ptr(m)) == 0, N.last_error()
+                assert N.lib().parsy_plan_check(h) == 0, (env, N.last_error())
+        finally:
+            N.lib().parsy_plan_destroy(h)
