@@ -117,7 +117,8 @@ typedef struct parsy_plan parsy_plan;
  * diagonal blocks, the hand-off vector and ticket counters of the solves): calls on ONE plan must be issued on
  * one stream, or be separated by the caller (events / synchronisation) -- one factorization or solve of a plan in
  * flight at a time.  Independent work in flight takes one plan each (plans of the same pattern are cheap next to
- * the factor: DESIGN.md, `throughput_in_flight`).  Calls are serialised on the host by a per-plan mutex. */
+ * the factor: DESIGN.md, `throughput_in_flight`).  The drop-in operators of section 1 hold a per-plan mutex across
+ * a call; the plan API itself is not thread-safe per plan (two host threads must not use one plan at once). */
 
 /* Sizes and work counts of a plan (all exact, from the pattern). */
 typedef struct parsy_plan_info {
@@ -190,6 +191,58 @@ int parsy_factor_device_ex(parsy_plan* plan, const double* d_values, double* d_l
 /* After the stream has been synchronised: 0 = factor ok, k > 0 = first
  * non-positive pivot seen at (1-based) column k, as LAPACK's dpotrf info. */
 int parsy_factor_status(parsy_plan* plan);
+
+/* ---- Level-by-level factorization and the pieces of the Cholesky view -------------------------------
+ * The factorization runs on the "Cholesky view" of the pattern: the supernodes, with the very wide ones
+ * cut into pieces (column ranges of one panel) that are factored one after the other; its etree levels are the
+ * wavefronts of cholesky_left_par_waveFront (Parallel_PB_Cholesky_wavefront.h:28-45: one level at a time).
+ * A caller that has work of its own between two levels -- the exchange step of a multi-device run -- enqueues
+ * the levels one by one:  parsy_factor_begin, parsy_factor_level(0 .. chol_levels-1, ascending, no gaps),
+ * parsy_factor_end; parsy_factor_device is exactly that sequence.  Everything is asynchronous on `stream`. */
+int parsy_factor_begin(parsy_plan* plan, const double* d_values, double* d_lValues, void* stream, int flags);
+int parsy_factor_level(parsy_plan* plan, int level, double* d_lValues, void* stream);
+int parsy_factor_end(parsy_plan* plan, void* stream);
+/* The pieces (n_pieces of parsy_plan_info; any output array may be NULL): supernode, level in the Cholesky
+ * view, first column, width, rows (from the piece's diagonal down), and the range [value_begin, value_end) of
+ * lValues that holds the piece's columns (column-major with the leading dimension of its supernode). Returns
+ * the number of pieces. */
+int parsy_plan_pieces(const parsy_plan* plan, int32_t* supernode, int32_t* level, int32_t* col0, int32_t* width,
+                      int32_t* rows, int64_t* value_begin, int64_t* value_end);
+/* As parsy_plan_set_active for the factorization, at the granularity of pieces (one byte per piece); the
+ * solves keep the supernode mask.  NULL restores "all". */
+int parsy_plan_set_active_pieces(parsy_plan* plan, const uint8_t* piece_mask);
+
+/* ---- Distribution of one factorization over the devices of a node (host logic) -----------------------
+ * Below a cut whole etree subtrees go to one rank each (independent: a target only reads its descendants,
+ * common/Reach.h:122-135 -- the independence of the reference's w-partitions, InspectionLevel_06.h:196-217;
+ * packed heaviest first, cf. common/TreeUtils.h:217-255); above it the pieces are dealt over the ranks level
+ * by level.  The owner of a piece applies every update into it; after a level is complete each of its pieces
+ * travels to the ranks that own a target it updates (only the rows those targets read).  The messages are
+ * lists of (offset, length) segments of lValues, the same on the sending and the receiving side. */
+typedef struct parsy_dist parsy_dist;
+typedef struct parsy_dist_info {
+    int32_t nranks, nlevels, n_pieces, n_subtrees, n_root_pieces, n_messages;
+    int64_t exchange_elements;        /* doubles that travel per factorization, all messages */
+    double total_cost, root_cost;     /* flops: whole job / pieces above the cut */
+    double max_rank_cost;             /* the most loaded rank */
+    double lockstep_cost;             /* sum over levels of the most loaded rank of that level */
+} parsy_dist_info;
+/* block: consecutive pieces of one split supernode that stay on one rank (<= 0: default 1). The plan may be a
+ * host-only one (device < 0). */
+parsy_dist* parsy_dist_create(const parsy_plan* plan, int nranks, int block);
+void parsy_dist_destroy(parsy_dist* dist);
+int parsy_dist_get_info(const parsy_dist* dist, parsy_dist_info* info);
+/* owner[n_pieces]; rank_cost[nranks]; level_cost[nlevels * nranks] (any may be NULL) */
+int parsy_dist_get(const parsy_dist* dist, int32_t* owner, double* rank_cost, double* level_cost);
+/* Messages that follow level `level`: their number; message `index` of them (borrowed pointers, valid until
+ * the dist is destroyed): sender, receiver, number of segments, elements of the packed buffer, and per segment
+ * its offset in lValues, its length and its offset in the packed buffer. */
+int parsy_dist_level_messages(const parsy_dist* dist, int level);
+int parsy_dist_message(const parsy_dist* dist, int level, int index, int32_t* src, int32_t* dst, int64_t* nseg,
+                       int64_t* total, const int64_t** off, const int32_t** len, const int64_t** packed);
+/* Host-side consistency check (every update across ranks finds its source rows delivered right after the
+ * source's level; subtrees walked by one workgroup stay on one rank): number of violations. */
+long long parsy_dist_check(const parsy_plan* plan, const parsy_dist* dist);
 
 /* Forward solve L X = B in place, X is n x nrhs column-major with leading
  * dimension ldx (device pointers). Asynchronous on `stream`. */
@@ -303,6 +356,31 @@ int parsy_grid_nested_dissection(int nx, int ny, int nz, int leaf, int* perm);
  * on the graph with level-structure separators (the reference calls METIS, cholesky/LSparsity.h:
  * not in this build).  leaf <= 0 picks the default (64).  perm[new] = old, n entries.  0 on success. */
 int parsy_order_nd(int n, const int* Ap, const int* Ai, int leaf, int* perm);
+
+/* ------------------------------------------------------------------------ */
+/* 5. One process, several devices: the distributed factorization            */
+/* ------------------------------------------------------------------------ */
+
+/* The distribution of section 2 run by ONE process that drives every device (the drivers' path; bench.py runs the
+ * same distribution with one process per GPU and RCCL point-to-point messages).
+ * `devices` lists one HIP device per rank; a device may appear more than once (several ranks share it: how the
+ * path is exercised on a node with fewer GPUs).  Every rank keeps its own lValues; finished pieces travel as
+ * device-to-device copies (peer access over xGMI between different devices) of exactly the segments of the
+ * parsy_dist messages, ordered by events.  values: host, nnz(A2) doubles. */
+typedef struct parsy_mg parsy_mg;
+parsy_mg* parsy_mg_create(const parsy_symbolic* sym, int nranks, const int* devices, int block);
+void parsy_mg_destroy(parsy_mg* mg);
+int parsy_mg_set_values(parsy_mg* mg, const double* values);
+/* Enqueue one distributed factorization on every rank's stream and wait for it; seconds (may be NULL) = wall
+ * time from the first enqueue to the last rank's completion.  Returns 0, or the factorization status of the
+ * first rank that reports one (> 0: non-positive pivot column, < 0: error). */
+int parsy_mg_factor(parsy_mg* mg, double* seconds);
+/* Per rank: device milliseconds of its last factorization (hipEvents on its stream). rank_ms[nranks]. */
+int parsy_mg_rank_ms(parsy_mg* mg, double* rank_ms);
+/* Collect the factor on the host: every piece from its owner (lValues: xsize doubles). */
+int parsy_mg_gather_host(parsy_mg* mg, double* lValues);
+const parsy_dist* parsy_mg_dist(const parsy_mg* mg);
+parsy_plan* parsy_mg_plan(parsy_mg* mg, int rank);
 
 #ifdef __cplusplus
 }

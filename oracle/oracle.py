@@ -252,3 +252,29 @@ def bind_system_blas() -> str:
 
 def unbind_blas() -> None:
     lib().oracle_bind_blas(None, None, None, None)
+
+
+def ref_hlevel(A, perm, cost: int = 4, level: int = 0, final: int = 2, nrelax=(4, 16, 48),
+               zrelax=(0.8, 0.1, 0.05)):
+    """H-level schedule (nLevels, levelPtr, parPtr, partition) of the REFERENCE's own LBC partitioner
+    (getCoarseLevelSet_6, cholesky/InspectionLevel_06.h, through oracle/_ref) for the parameters of
+    scripts/eval.sh: costParam, levelParam, finalSeqNode.  Only where oracle/_ref was built."""
+    R = ref()
+    Ap = np.ascontiguousarray(A.Ap, np.int32)
+    Ai = np.ascontiguousarray(A.Ai, np.int32)
+    Ax = np.ascontiguousarray(A.Ax)
+    pm = np.ascontiguousarray(perm, np.int32)
+    nr = np.array(nrelax, np.int32)
+    zr = np.array(zrelax, np.float64)
+    h = R.ref_analyze(A.n, P(Ap), P(Ai), P(Ax), P(pm), P(nr), P(zr), cost, level, final)
+    if not h:
+        raise RuntimeError("ref_analyze failed")
+    out = {}
+    for name in ("levelPtr", "parPtr", "partition"):
+        n = R.ref_get_int(h, name.encode(), None)
+        a = np.zeros(max(int(n), 1), np.int32)
+        R.ref_get_int(h, name.encode(), P(a))
+        out[name] = a[: int(n)]
+    sc = np.zeros(9, np.int64)
+    R.ref_get_scalars(h, P(sc))
+    return int(sc[6]), out["levelPtr"], out["parPtr"], out["partition"]

@@ -74,7 +74,24 @@ EXPORTED_SYMBOLS = [
     "parsy_grid_nested_dissection", "parsy_order_nd", "parsy_plan_profile", "parsy_plan_profile_collect",
     "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve2_host",
     "parsy_rhs_ones_device", "parsy_solve_status", "parsy_copy_segments_device", "parsy_plan_check",
+    "parsy_factor_begin", "parsy_factor_level", "parsy_factor_end", "parsy_plan_pieces",
+    "parsy_plan_set_active_pieces", "parsy_dist_create", "parsy_dist_destroy", "parsy_dist_get_info",
+    "parsy_dist_get", "parsy_dist_level_messages", "parsy_dist_message", "parsy_dist_check",
+    "parsy_mg_create", "parsy_mg_destroy", "parsy_mg_set_values", "parsy_mg_factor", "parsy_mg_rank_ms",
+    "parsy_mg_gather_host", "parsy_mg_dist", "parsy_mg_plan",
 ]
+
+
+class DistInfo(C.Structure):
+    _fields_ = [
+        ("nranks", C.c_int32), ("nlevels", C.c_int32), ("n_pieces", C.c_int32), ("n_subtrees", C.c_int32),
+        ("n_root_pieces", C.c_int32), ("n_messages", C.c_int32), ("exchange_elements", C.c_int64),
+        ("total_cost", C.c_double), ("root_cost", C.c_double), ("max_rank_cost", C.c_double),
+        ("lockstep_cost", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 def _declare(lib):
@@ -109,6 +126,32 @@ def _declare(lib):
     lib.parsy_rhs_ones_device.argtypes = [vp, vp, vp, vp]
     lib.parsy_solve_status.argtypes = [vp]
     lib.parsy_copy_segments_device.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp]
+    lib.parsy_factor_begin.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.parsy_factor_level.argtypes = [vp, C.c_int, vp, vp]
+    lib.parsy_factor_end.argtypes = [vp, vp]
+    lib.parsy_plan_pieces.argtypes = [vp] + [vp] * 7
+    lib.parsy_plan_set_active_pieces.argtypes = [vp, vp]
+    lib.parsy_dist_create.restype = vp
+    lib.parsy_dist_create.argtypes = [vp, C.c_int, C.c_int]
+    lib.parsy_dist_destroy.argtypes = [vp]
+    lib.parsy_dist_get_info.argtypes = [vp, C.POINTER(DistInfo)]
+    lib.parsy_dist_get.argtypes = [vp, vp, vp, vp]
+    lib.parsy_dist_level_messages.argtypes = [vp, C.c_int]
+    lib.parsy_dist_message.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, c_i64_p, c_i64_p,
+                                       C.POINTER(c_i64_p), C.POINTER(c_int_p), C.POINTER(c_i64_p)]
+    lib.parsy_dist_check.argtypes = [vp, vp]
+    lib.parsy_dist_check.restype = C.c_longlong
+    lib.parsy_mg_create.restype = vp
+    lib.parsy_mg_create.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.parsy_mg_destroy.argtypes = [vp]
+    lib.parsy_mg_set_values.argtypes = [vp, vp]
+    lib.parsy_mg_factor.argtypes = [vp, vp]
+    lib.parsy_mg_rank_ms.argtypes = [vp, vp]
+    lib.parsy_mg_gather_host.argtypes = [vp, vp]
+    lib.parsy_mg_dist.restype = vp
+    lib.parsy_mg_dist.argtypes = [vp]
+    lib.parsy_mg_plan.restype = vp
+    lib.parsy_mg_plan.argtypes = [vp, C.c_int]
     lib.parsy_factor_host.argtypes = [vp, vp, vp, vp]
     lib.parsy_solve_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.parsy_last_factor_ms.restype = C.c_double

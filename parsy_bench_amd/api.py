@@ -238,6 +238,36 @@ class Plan:
         if N.lib().parsy_solve_device(self._h, d_lValues, d_x, nrhs, ldx, stream) != 0:
             raise RuntimeError("parsy_solve_device failed: " + N.last_error())
 
+    # level by level (the steps of a multi-device run; parsy_factor_device is exactly this sequence) ----
+    def factor_begin(self, d_values: int, d_lValues: int, stream: int = 0, init: bool = True) -> None:
+        if N.lib().parsy_factor_begin(self._h, d_values, d_lValues, stream, 0 if init else 1) != 0:
+            raise RuntimeError("parsy_factor_begin failed: " + N.last_error())
+
+    def factor_level(self, level: int, d_lValues: int, stream: int = 0) -> None:
+        if N.lib().parsy_factor_level(self._h, level, d_lValues, stream) != 0:
+            raise RuntimeError("parsy_factor_level failed: " + N.last_error())
+
+    def factor_end(self, stream: int = 0) -> None:
+        if N.lib().parsy_factor_end(self._h, stream) != 0:
+            raise RuntimeError("parsy_factor_end failed: " + N.last_error())
+
+    def pieces(self) -> dict:
+        """The pieces of the Cholesky view: supernode, level, col0, width, rows, value_begin, value_end."""
+        n = int(N.lib().parsy_plan_pieces(self._h, *([None] * 7)))
+        out = {k: np.zeros(n, dtype=np.int32) for k in ("supernode", "level", "col0", "width", "rows")}
+        out.update({k: np.zeros(n, dtype=np.int64) for k in ("value_begin", "value_end")})
+        N.lib().parsy_plan_pieces(self._h, *[N.ptr(out[k]) for k in (
+            "supernode", "level", "col0", "width", "rows", "value_begin", "value_end")])
+        return out
+
+    def set_active_pieces(self, mask) -> None:
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if N.lib().parsy_plan_set_active_pieces(self._h, N.ptr(m)) != 0:
+            raise RuntimeError(N.last_error())
+
+    def check(self) -> int:
+        return int(N.lib().parsy_plan_check(self._h))
+
     def last_factor_ms(self) -> float:
         return float(N.lib().parsy_last_factor_ms(self._h))
 
@@ -258,3 +288,111 @@ class Plan:
         N.lib().parsy_plan_profile_get(self._h, N.ptr(ms), N.ptr(cnt), C.byref(runs))
         return {"runs": runs.value, "ms": dict(zip(KIND_NAMES, ms.tolist())),
                 "launches": dict(zip(KIND_NAMES, cnt.tolist()))}
+
+
+# ---------------------------------------------------------------------------
+# distribution of one factorization over the devices of a node
+# ---------------------------------------------------------------------------
+class Dist:
+    """Ownership of the pieces and the messages that follow every level (parsy_dist; host logic)."""
+
+    def __init__(self, plan: "Plan", nranks: int, block: int = 1, _borrowed=None):
+        self._own = _borrowed is None
+        self._h = _borrowed or N.lib().parsy_dist_create(plan._h, nranks, block)
+        if not self._h:
+            raise RuntimeError("parsy_dist_create failed: " + N.last_error())
+        di = N.DistInfo()
+        N.lib().parsy_dist_get_info(self._h, C.byref(di))
+        self.info = di.as_dict()
+        self.nranks, self.nlevels = di.nranks, di.nlevels
+        self.owner = np.zeros(di.n_pieces, dtype=np.int32)
+        self.rank_cost = np.zeros(di.nranks)
+        self.level_cost = np.zeros((di.nlevels, di.nranks))
+        N.lib().parsy_dist_get(self._h, N.ptr(self.owner), N.ptr(self.rank_cost), N.ptr(self.level_cost))
+
+    def close(self):
+        h, self._h = self._h, None
+        if h and self._own:
+            N.lib().parsy_dist_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, plan: "Plan") -> int:
+        return int(N.lib().parsy_dist_check(plan._h, self._h))
+
+    def mask(self, rank: int) -> np.ndarray:
+        return (self.owner == rank).astype(np.uint8)
+
+    def messages(self, level: int, rank: int | None = None):
+        """The messages that follow `level` (those `rank` sends or receives when given):
+        (src, dst, off int64[], len int32[], packed int64[], total)."""
+        lib = N.lib()
+        out = []
+        for k in range(max(int(lib.parsy_dist_level_messages(self._h, level)), 0)):
+            src, dst = C.c_int32(0), C.c_int32(0)
+            nseg, total = C.c_int64(0), C.c_int64(0)
+            off, ln, pk = N.c_i64_p(), N.c_int_p(), N.c_i64_p()
+            if lib.parsy_dist_message(self._h, level, k, C.byref(src), C.byref(dst), C.byref(nseg), C.byref(total),
+                                      C.byref(off), C.byref(ln), C.byref(pk)) != 0:
+                raise RuntimeError(N.last_error())
+            if rank is not None and rank not in (src.value, dst.value):
+                continue
+            out.append((src.value, dst.value, N.view_array(off, nseg.value, np.int64),
+                        N.view_array(ln, nseg.value, np.int32), N.view_array(pk, nseg.value, np.int64), total.value))
+        return out
+
+
+class MultiDevice:
+    """One process driving several devices (parsy_mg): `devices` lists one HIP device per rank and may
+    repeat a device (several ranks share it)."""
+
+    def __init__(self, sym, devices, block: int = 1):
+        if not getattr(sym, "_handle", None):
+            raise RuntimeError("MultiDevice needs an inspector result (parsy_symbolic)")
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        self.sym = sym
+        self.nranks = len(dv)
+        self._h = N.lib().parsy_mg_create(sym._handle, len(dv), N.ptr(dv), block)
+        if not self._h:
+            raise RuntimeError("parsy_mg_create failed: " + N.last_error())
+        self.dist = Dist(None, len(dv), _borrowed=N.lib().parsy_mg_dist(self._h))
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            self.dist._h = None
+            N.lib().parsy_mg_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_values(self, values) -> None:
+        v = _f64(values)
+        if N.lib().parsy_mg_set_values(self._h, N.ptr(v)) != 0:
+            raise RuntimeError("parsy_mg_set_values failed: " + N.last_error())
+
+    def factor(self):
+        """One distributed factorization; returns (status, wall seconds)."""
+        sec = C.c_double(0)
+        st = int(N.lib().parsy_mg_factor(self._h, C.byref(sec)))
+        if st < 0:
+            raise RuntimeError("parsy_mg_factor failed: " + N.last_error())
+        return st, sec.value
+
+    def rank_ms(self) -> np.ndarray:
+        out = np.zeros(self.nranks)
+        N.lib().parsy_mg_rank_ms(self._h, N.ptr(out))
+        return out
+
+    def gather(self) -> np.ndarray:
+        lv = np.zeros(int(self.sym.xsize), dtype=np.float64)
+        if N.lib().parsy_mg_gather_host(self._h, N.ptr(lv)) != 0:
+            raise RuntimeError("parsy_mg_gather_host failed: " + N.last_error())
+        return lv

@@ -18,8 +18,8 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libparsy_amd.so"
 OBJ = PKG / "build"
 
-HOST_SOURCES = ["inspector.cpp", "gen.cpp", "ordering.cpp", "capi_host.cpp", "schedule.cpp"]
-HIP_SOURCES = ["executor.hip", "chol_kernels.hip", "trsv_kernels.hip", "capi_exec.hip"]
+HOST_SOURCES = ["inspector.cpp", "gen.cpp", "ordering.cpp", "capi_host.cpp", "schedule.cpp", "dist.cpp", "capi_dist.cpp"]
+HIP_SOURCES = ["executor.hip", "chol_kernels.hip", "trsv_kernels.hip", "capi_exec.hip", "mg.hip"]
 ARCH = "gfx950"
 
 

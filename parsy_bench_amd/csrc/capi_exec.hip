@@ -12,6 +12,7 @@
 
 #include "../../include/parsy_amd.h"
 #include "errors.hpp"
+#include "dist.hpp"
 #include "executor.hpp"
 #include "inspector.hpp"
 
@@ -343,6 +344,61 @@ int parsy_plan_set_active(parsy_plan* pl, const uint8_t* mask) {
     if (!pl) return -1;
     parsy::build_launches(pl->S, mask);
     return parsy::plan_upload_launches(pl);
+}
+
+int parsy_plan_set_active_pieces(parsy_plan* pl, const uint8_t* piece_mask) {
+    if (!pl) return -1;
+    std::vector<uint8_t> sn_mask;   // the solves keep the supernode mask they had
+    const uint8_t* keep = nullptr;
+    if (!pl->S.active.empty()) {
+        sn_mask = pl->S.active;
+        keep = sn_mask.data();
+    }
+    parsy::build_launches(pl->S, keep, piece_mask);
+    return parsy::plan_upload_launches(pl);
+}
+
+int parsy_plan_pieces(const parsy_plan* pl, int32_t* supernode, int32_t* level, int32_t* col0, int32_t* width,
+                      int32_t* rows, int64_t* value_begin, int64_t* value_end) {
+    if (!pl) return -1;
+    const parsy::Schedule& S = pl->S;
+    const int nc = (int)S.csn.size();
+    for (int p = 0; p < nc; ++p) {
+        const parsy::SnDesc& C = S.csn[(size_t)p];
+        const parsy::SnDesc& R = S.sn[(size_t)S.csn_real[(size_t)p]];
+        if (supernode) supernode[p] = S.csn_real[(size_t)p];
+        if (level) level[p] = S.level_of.empty() ? 0 : S.level_of[(size_t)p];
+        if (col0) col0[p] = C.c0;
+        if (width) width[p] = C.w;
+        if (rows) rows[p] = C.r;
+        if (value_begin) value_begin[p] = R.px + (int64_t)C.rbias * R.r;
+        if (value_end) value_end[p] = R.px + (int64_t)(C.rbias + C.w) * R.r;
+    }
+    return nc;
+}
+
+int parsy_factor_begin(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream, int flags) {
+    if (!pl || !d_values || !d_lValues) {
+        set_last_error("parsy_factor_begin: null argument");
+        return -1;
+    }
+    return parsy::plan_factor_begin(pl, d_values, d_lValues, (hipStream_t)stream, (flags & PARSY_FACTOR_NO_INIT) == 0);
+}
+
+int parsy_factor_level(parsy_plan* pl, int level, double* d_lValues, void* stream) {
+    if (!pl || !d_lValues) {
+        set_last_error("parsy_factor_level: null argument");
+        return -1;
+    }
+    return parsy::plan_factor_levels(pl, level, level + 1, d_lValues, (hipStream_t)stream);
+}
+
+int parsy_factor_end(parsy_plan* pl, void* stream) {
+    if (!pl) {
+        set_last_error("parsy_factor_end: null plan");
+        return -1;
+    }
+    return parsy::plan_factor_end(pl, (hipStream_t)stream);
 }
 
 int parsy_factor_device(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream) {

@@ -1387,8 +1387,10 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         }
         v_kend = kend;
         lk += kBK;
+#ifndef PARSY_BIGABL_NOLOAD   // (diagnostic build: every chunk re-reads the entry's first one -- cache hits)
         l_pr += (int64_t)kBK * LE.ld;
         l_pc += (int64_t)kBK * LE.ld;
+#endif
         if (lk >= LE.K) {
             lk = 0;
             ++le;
@@ -1447,6 +1449,12 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             for (int f = 0; f < 4; ++f) rv[f] = Rb[(4 * ks + kq) * kBLd + 16 * f];
 #pragma unroll
             for (int f = 0; f < 2; ++f) cv[f] = Cb[(4 * ks + kq) * kBLd + 16 * f];
+#ifdef PARSY_BIGABL_NOMFMA    // (diagnostic build: operands are read from LDS and dropped)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[f]));
+#pragma unroll
+            for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(cv[f]));
+#else
 #pragma unroll
             for (int fc = 0; fc < 2; ++fc) {
                 if (fc < nfc) {
@@ -1456,12 +1464,23 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
                             acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 0);
                 }
             }
+#endif
         }
     };
     // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
     // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C), 8 loads of a lane at a time
     auto epilogue = [&](const WaveEntry& E, int nfr, int nfc) {
         if (nfr == 0) return;
+#ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no read-modify-write of the tile)
+#pragma unroll
+        for (int fc = 0; fc < 2; ++fc)
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) {
+                asm volatile("" ::"v"(acc[fc][fr]));
+                acc[fc][fr] = double4_t{0, 0, 0, 0};
+            }
+        return;
+#endif
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const bool ident = (E.mn >> 16) != 0;
         int prow[4];
@@ -1532,7 +1551,9 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             }
         }
         if (!have_next) break;
+#ifndef PARSY_BIGABL_NOBARRIER   // (diagnostic build: waves race through the staged chunks -- wrong results)
         __syncthreads();
+#endif
     }
 }
 

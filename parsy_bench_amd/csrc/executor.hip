@@ -7,8 +7,11 @@
 #include <stdexcept>
 
 #include "errors.hpp"
+#include "plan_fwd.hpp"
 
 namespace parsy {
+
+const Schedule& plan_schedule(const parsy_plan* plan) { return plan->S; }
 
 #define PARSY_HIP(call)                                                                      \
     do {                                                                                     \
@@ -199,20 +202,31 @@ static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& c
     ++cursor;
 }
 
-static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double* L, const double* Lc,
-                         double* x, int nrhs, int ldx, hipStream_t stream) {
-    size_t cursor = 0;
+// Enqueue the launches seq[i0, i1).  The state that orders the two streams (which level-completion events have been
+// recorded, which side launches are in flight, the profiling cursor) lives in the plan, so that a factorization can
+// be enqueued level by level (parsy_factor_level) with the caller's own work -- the exchange step of a
+// multi-device run -- in between: run_begin() resets it, run_end() closes the profiling record.
+static void run_begin(parsy_plan* pl) {
+    pl->run_cursor = 0;
+    pl->run_next_level_event = 0;
+    pl->run_early_seen.assign(pl->ev_early_done.size(), 0);
+}
+
+static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0, size_t i1, double* L,
+                      const double* Lc, double* x, int nrhs, int ldx, hipStream_t stream) {
+    size_t& cursor = pl->run_cursor;
     // TILES_EARLY launches go to the side stream (unless profiling / disabled): they wait for the
     // completion event of the level two below their targets and run beside the main stream's
     // block-column chain; the matching TILES (late) launch waits for them.
     const bool overlap = pl->overlap && !pl->profile && pl->side_stream != nullptr;
-    int next_level_event = 0;  // ev_level_done[k] recorded for all k < next_level_event
-    std::vector<char> early_seen(pl->ev_early_done.size(), 0);
+    int& next_level_event = pl->run_next_level_event;  // ev_level_done[k] recorded for all k < next_level_event
+    std::vector<char>& early_seen = pl->run_early_seen;
     auto record_levels_below = [&](int level) {
         for (; next_level_event < level && next_level_event < (int)pl->ev_level_done.size(); ++next_level_event)
             (void)hipEventRecord(pl->ev_level_done[next_level_event], stream);
     };
-    for (const Launch& l : seq) {
+    for (size_t li = i0; li < i1; ++li) {
+        const Launch& l = seq[li];
         const bool on_side = overlap && l.side;
         if (!on_side) {
             // everything enqueued so far on the main stream belongs to levels < l.level
@@ -270,8 +284,18 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
                 break;
         }
     }
-    profile_mark(pl, -1, stream, cursor);
-    if (pl->profile) pl->pev_kind.resize(cursor);
+}
+
+static void run_end(parsy_plan* pl, hipStream_t stream) {
+    profile_mark(pl, -1, stream, pl->run_cursor);
+    if (pl->profile) pl->pev_kind.resize(pl->run_cursor);
+}
+
+static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double* L, const double* Lc,
+                         double* x, int nrhs, int ldx, hipStream_t stream) {
+    run_begin(pl);
+    run_range(pl, seq, 0, seq.size(), L, Lc, x, nrhs, ldx, stream);
+    run_end(pl, stream);
 }
 
 // Start of a forward / backward solve: a fresh epoch range for its passes (flags of earlier solves go
@@ -349,7 +373,7 @@ int plan_collect_profile(parsy_plan* pl) {
     return 0;
 }
 
-int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream, bool init) {
+int plan_factor_begin(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream, bool init) {
     if (pl->device < 0) {
         set_last_error("parsy_factor: plan was built without a device (device < 0)");
         return -1;
@@ -374,11 +398,61 @@ int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t
     PARSY_HIP(hipMemsetAsync(pl->dp.tickets, 0, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int), stream));
     if (init) launch_scatter_a(d_values, pl->dp.a_dst, d_L, S.nnzA, stream);
     PARSY_HIP(hipEventRecord(pl->ev_init, stream));
-    run_launches(pl, S.chol, d_L, d_L, nullptr, 0, 0, stream);
+    run_begin(pl);
+    pl->factor_open = true;
+    pl->factor_next_level = 0;
+    return 0;
+}
+
+// The launches of levels [level0, level1) of the Cholesky view (levels must be passed in ascending order and
+// without gaps: each step may enqueue side-stream launches that wait for the completion of the step before it).
+int plan_factor_levels(parsy_plan* pl, int level0, int level1, double* d_L, hipStream_t stream) {
+    const Schedule& S = pl->S;
+    if (!pl->factor_open) {
+        set_last_error("parsy_factor_level: no factorization is open (call parsy_factor_begin first)");
+        return -1;
+    }
+    if (level0 != pl->factor_next_level || level1 < level0 || level1 > S.cnlevels) {
+        set_last_error("parsy_factor_level: levels must be enqueued in ascending order without gaps");
+        return -1;
+    }
+    if (level1 > level0)
+        run_range(pl, S.chol, S.chol_level_begin[(size_t)level0], S.chol_level_begin[(size_t)level1], d_L, d_L, nullptr,
+                  0, 0, stream);
+    pl->factor_next_level = level1;
+    PARSY_HIP(hipGetLastError());
+    return 0;
+}
+
+int plan_factor_end(parsy_plan* pl, hipStream_t stream) {
+    if (!pl->factor_open) {
+        set_last_error("parsy_factor_end: no factorization is open");
+        return -1;
+    }
+    if (pl->factor_next_level != pl->S.cnlevels) {
+        set_last_error("parsy_factor_end: not every level has been enqueued");
+        return -1;
+    }
+    run_end(pl, stream);
+    // the side stream's last launches belong to this factorization: the caller's stream waits for them
+    if (pl->overlap && !pl->profile && pl->side_stream != nullptr) {
+        for (size_t k = pl->run_early_seen.size(); k-- > 0;)
+            if (pl->run_early_seen[k]) {
+                (void)hipStreamWaitEvent(stream, pl->ev_early_done[k], 0);
+                break;
+            }
+    }
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_f1, stream));
     pl->have_f = true;
+    pl->factor_open = false;
     return 0;
+}
+
+int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream, bool init) {
+    if (plan_factor_begin(pl, d_values, d_L, stream, init) != 0) return -1;
+    if (plan_factor_levels(pl, 0, pl->S.cnlevels, d_L, stream) != 0) return -1;
+    return plan_factor_end(pl, stream);
 }
 
 int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx,

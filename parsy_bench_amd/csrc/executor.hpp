@@ -42,6 +42,14 @@ struct parsy_plan {
     std::vector<hipEvent_t> ev_level_done, ev_early_done;
     bool overlap = true;      // PARSY_NO_OVERLAP=1 (or profiling) runs everything on the caller's stream
 
+    // state of the launch sequence being enqueued (executor.hip run_range): persistent so that a factorization
+    // can be enqueued level by level
+    size_t run_cursor = 0;
+    int run_next_level_event = 0;
+    std::vector<char> run_early_seen;
+    bool factor_open = false;
+    int factor_next_level = 0;
+
     hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     bool have_f = false, have_s = false;
 
@@ -63,6 +71,9 @@ void plan_free(parsy_plan* plan);
 int plan_upload_launches(parsy_plan* plan);
 int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream,
                 bool init = true);
+int plan_factor_begin(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream, bool init);
+int plan_factor_levels(parsy_plan* plan, int level0, int level1, double* d_L, hipStream_t stream);
+int plan_factor_end(parsy_plan* plan, hipStream_t stream);
 int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
                hipStream_t stream);
 int plan_backsolve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream);

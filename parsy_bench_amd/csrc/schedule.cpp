@@ -145,6 +145,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     S.push_group = std::max(1, env_int("PARSY_PUSH_GROUP", kPushGroup));
 
     std::vector<int> tree(P.sparent, P.sparent + ns);
+    S.sparent = tree;
     level_sets(tree, S.levelPtr, S.levelSet);
     S.nlevels = (int)S.levelPtr.size() - 1;
 
@@ -482,7 +483,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     build_launches(S, active);
 }
 
-void build_launches(Schedule& S, const uint8_t* active) {
+void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pieces) {
     const int ns = S.nsuper;
     // PARSY_FORCE_UNFUSED=1 schedules the solve's fallback form everywhere (per-block-column
     // launches): the path taken when a chain launch would not be resident.  Used by the tests.
@@ -493,6 +494,12 @@ void build_launches(Schedule& S, const uint8_t* active) {
     S.n_solve_chain_launches = 0;
     S.active.assign(ns, 1);
     if (active) S.active.assign(active, active + ns);
+    // the factorization goes by PIECES of the Cholesky view (a multi-device run deals the pieces of a split
+    // supernode to different devices); without a piece mask a piece is active with its supernode
+    const int npieces = (int)S.csn.size();
+    S.active_piece.assign((size_t)npieces, 1);
+    for (int t = 0; t < npieces; ++t)
+        S.active_piece[t] = active_pieces ? (active_pieces[t] != 0) : S.active[S.csn_real[t]];
     S.small_list.clear();
     S.tiles.clear();
     S.n_chain_launches = 0;
@@ -516,24 +523,105 @@ void build_launches(Schedule& S, const uint8_t* active) {
     // BIG tasks of every (source level, kind), active targets only, heaviest first
     std::vector<std::vector<const Schedule::BigTask*>> big_next(S.cnlevels), big_push(S.cnlevels);
     for (const Schedule::BigTask& b : S.big_all)
-        if (S.active[S.csn_real[b.sn]]) (b.next ? big_next : big_push)[b.src_level].push_back(&b);
+        if (S.active_piece[b.sn]) (b.next ? big_next : big_push)[b.src_level].push_back(&b);
+    // Order of a BIG launch's tasks.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on the
+    // XCD of every block b + 8k; observed placement, used for speed only) and each XCD has its own L2, so
+    // tiles that read the same rows of a source should share an XCD at the same time: the tasks are grouped
+    // into g x g super-tiles of one target's tile grid (g row windows + g column windows of the source feed
+    // g*g tasks), the groups are dealt to 8 sequences -- heaviest group first, each to the least loaded
+    // sequence -- and sequence x fills the positions 8s + x (shorter sequences are padded with empty tasks,
+    // which return at once).  Small launches keep the plain heaviest-first order.  PARSY_BIG_GROUP=g
+    // (0: never group).
+    const int big_group = env_int("PARSY_BIG_GROUP", kBigGroup);
     auto emit_big = [&](std::vector<const Schedule::BigTask*>& v, Launch L) {
         if (v.empty()) return L;
-        std::stable_sort(v.begin(), v.end(),
-                         [](const Schedule::BigTask* a, const Schedule::BigTask* b) { return a->weight > b->weight; });
         L.first = (int32_t)S.big_tasks.size();
-        for (const Schedule::BigTask* b : v) S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
-        L.count = (int32_t)v.size();
+        auto by_weight = [](const Schedule::BigTask* a, const Schedule::BigTask* b) { return a->weight > b->weight; };
+        // group edge: as large as leaves every XCD at least kBigGroupsPerXcd groups to balance with
+        int g = big_group;
+        while (g > 1 && (int64_t)v.size() < (int64_t)8 * kBigGroupsPerXcd * g * g) g /= 2;
+        if (g <= 1) {
+            std::stable_sort(v.begin(), v.end(), by_weight);
+            for (const Schedule::BigTask* b : v) S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
+            L.count = (int32_t)v.size();
+            return L;
+        }
+        struct Group { int64_t key, weight; int32_t maxw; std::vector<const Schedule::BigTask*> tasks; };
+        std::vector<const Schedule::BigTask*> seq[8];
+        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto least = [&] {
+            int x = 0;
+            for (int q = 1; q < 8; ++q)
+                if (load[q] < load[x]) x = q;
+            return x;
+        };
+        // the bulk goes in g x g groups; the lightest kBigTailGroups groups are dealt again at half the edge
+        // (and so on down to single tasks), so that the sequences end together
+        std::vector<const Schedule::BigTask*> rest(v);
+        for (; !rest.empty(); g /= 2) {
+            if (g <= 1) {
+                std::stable_sort(rest.begin(), rest.end(), by_weight);
+                for (const Schedule::BigTask* b : rest) {
+                    const int x = least();
+                    seq[x].push_back(b);
+                    load[x] += b->weight;
+                }
+                break;
+            }
+            std::vector<std::pair<int64_t, const Schedule::BigTask*>> keyed;
+            keyed.reserve(rest.size());
+            for (const Schedule::BigTask* b : rest) {
+                const int64_t gi = b->row0 / (kBigTile * g), gj = b->col0 / (kBigTile * g);
+                keyed.push_back({((int64_t)b->sn << 32) | (gj << 16) | gi, b});
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            std::vector<Group> groups;
+            for (const auto& kb : keyed) {
+                if (groups.empty() || groups.back().key != kb.first) groups.push_back(Group{kb.first, 0, 0, {}});
+                Group& G = groups.back();
+                G.tasks.push_back(kb.second);
+                G.weight += kb.second->weight;
+                G.maxw = std::max(G.maxw, kb.second->weight);
+            }
+            std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {
+                return a.maxw != b.maxw ? a.maxw > b.maxw : a.weight > b.weight;
+            });
+            const size_t bulk = groups.size() > (size_t)kBigTailGroups ? groups.size() - kBigTailGroups : 0;
+            rest.clear();
+            for (size_t q = 0; q < groups.size(); ++q) {
+                Group& G = groups[q];
+                if (q >= bulk) {
+                    rest.insert(rest.end(), G.tasks.begin(), G.tasks.end());
+                    continue;
+                }
+                const int x = least();
+                std::stable_sort(G.tasks.begin(), G.tasks.end(), by_weight);
+                seq[x].insert(seq[x].end(), G.tasks.begin(), G.tasks.end());
+                load[x] += G.weight;
+            }
+        }
+        size_t len = 0;
+        for (int x = 0; x < 8; ++x) len = std::max(len, seq[x].size());
+        for (size_t s = 0; s < len; ++s)
+            for (int x = 0; x < 8; ++x) {
+                if (s < seq[x].size()) {
+                    const Schedule::BigTask* b = seq[x][s];
+                    S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
+                } else {
+                    S.big_tasks.push_back(TileDesc{0, 0, 0, 0, 0, 0});  // padding: no entries
+                }
+            }
+        L.count = (int32_t)(8 * len);
         return L;
     };
     // The active supernodes of every subtree in index order (descendants first), subtrees by falling cost:
     // fn(supernode) appends to the kind's list; returns the (begin, end) pairs of the list positions.
     auto subtree_ranges = [&](const std::vector<int32_t>& subtree, int count, const std::vector<double>& cost,
-                              auto&& position, auto&& append, std::vector<int32_t>& ranges) {
+                              auto&& position, auto&& append, std::vector<int32_t>& ranges, bool chol = false) {
         std::vector<std::vector<int32_t>> members((size_t)count);
         std::vector<double> total((size_t)count, 0.0);
         for (int t = 0; t < ns; ++t)
-            if (subtree[t] >= 0 && S.active[t]) {
+            if (subtree[t] >= 0 && (chol ? S.active_piece[S.piece0[t]] : S.active[t])) {
                 members[(size_t)subtree[t]].push_back(t);
                 total[(size_t)subtree[t]] += cost[t];
             }
@@ -569,14 +657,14 @@ void build_launches(Schedule& S, const uint8_t* active) {
                     for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
                         L.jb = std::max<int32_t>(L.jb, std::min<int64_t>((int64_t)S.upd[u].m * S.upd[u].K, 2048));
                 },
-                S.small_ranges);
+                S.small_ranges, true);
             if (L.count > 0) S.chol.push_back(L);
         }
         {
             Launch L{kLaunchSmall, (int32_t)S.small_list.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.clevelPtr[lev]; q < S.clevelPtr[lev + 1]; ++q) {
                 const int t = S.clevelSet[q];
-                if (!S.active[S.csn_real[t]] || S.chol_subtree[S.csn_real[t]] >= 0) continue;
+                if (!S.active_piece[t] || S.chol_subtree[S.csn_real[t]] >= 0) continue;
                 const SnDesc& T = S.csn[t];
                 if (is_small(T)) {
                     S.small_list.push_back(t);
@@ -675,18 +763,23 @@ void build_launches(Schedule& S, const uint8_t* active) {
     }
     // splice the side launches in front of the level before the one that waits for them (stable: PUSH
     // before TILES of the same level)
+    // chol_level_begin[lev]: where level lev's launches start in S.chol (its side launches first) -- the steps
+    // of a factorization that is run level by level (parsy_factor_level)
+    S.chol_level_begin.assign(level_begin.begin(), level_begin.end());
     if (!early_launches.empty()) {
         std::vector<Launch> merged;
         size_t e = 0;
         std::stable_sort(early_launches.begin(), early_launches.end(),
                          [](const Launch& a, const Launch& b) { return a.level < b.level; });
         for (int lev = 0; lev < S.cnlevels; ++lev) {
+            S.chol_level_begin[(size_t)lev] = merged.size();
             while (e < early_launches.size() && early_launches[e].level - 1 <= lev) merged.push_back(early_launches[e++]);
             const size_t b0 = level_begin[lev], b1 = lev + 1 < S.cnlevels ? level_begin[lev + 1] : S.chol.size();
             merged.insert(merged.end(), S.chol.begin() + b0, S.chol.begin() + b1);
         }
         S.chol.swap(merged);
     }
+    S.chol_level_begin.push_back(S.chol.size());
     for (int lev = 0; lev < S.nlevels; ++lev) {
         sbigs.clear();
         // ---- forward solve ----------------------------------------------------------
@@ -1147,6 +1240,39 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             covered[(size_t)u] += entry_flops(E, E.ia == E.ja);
         }
     }
+    {
+        // the BIG launches hold every task of an active target exactly once, under its (source level, kind);
+        // padding tasks (XCD sequences of unequal length) have no entries
+        std::vector<int64_t> e0s;
+        for (const Launch& l : S.chol) {
+            if (l.kind != kLaunchBig) continue;
+            for (int q = l.first; q < l.first + l.count; ++q) {
+                const TileDesc& td = S.big_tasks[(size_t)q];
+                if (td.wp >= td.sp) {
+                    if (td.wp != td.sp) fail("BIG launch task " + std::to_string(q) + " has a negative entry range");
+                    continue;
+                }
+                auto it = std::lower_bound(S.big_all.begin(), S.big_all.end(), td.wp,
+                                           [](const Schedule::BigTask& b, int64_t e) { return b.e0 < e; });
+                if (it == S.big_all.end() || it->e0 != td.wp || it->e1 != td.sp || it->sn != td.sn ||
+                    it->row0 != td.row0 || it->col0 != td.col0) {
+                    fail("BIG launch task " + std::to_string(q) + " is not a task of the plan");
+                    continue;
+                }
+                const bool side = l.side != 0;
+                if (side == (it->next != 0) || (side ? l.wait_level : l.level - 1) != it->src_level)
+                    fail("BIG launch task " + std::to_string(q) + " runs in the launch of another source level");
+                e0s.push_back(td.wp);
+            }
+        }
+        std::sort(e0s.begin(), e0s.end());
+        if (std::adjacent_find(e0s.begin(), e0s.end()) != e0s.end()) fail("a BIG task is launched twice");
+        int64_t want = 0;
+        for (const Schedule::BigTask& b : S.big_all)
+            if (S.active_piece[b.sn]) ++want;
+        if ((int64_t)e0s.size() != want)
+            fail("BIG launches hold " + std::to_string(e0s.size()) + " tasks, the active targets have " + std::to_string(want));
+    }
     for (int t = 0; t < nc; ++t) {
         const SnDesc& T = S.csn[t];
         if (is_small(T)) continue;
@@ -1190,7 +1316,7 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             }
         }
         for (int t = 0; t < nc; ++t)
-            if (seen[t] != ((is_small(S.csn[t]) && S.active[S.csn_real[t]]) ? 1 : 0))
+            if (seen[t] != ((is_small(S.csn[t]) && S.active_piece[t]) ? 1 : 0))
                 fail("SMALL supernode " + std::to_string(t) + " is in " + std::to_string(seen[t]) + " launches");
     }
     // ---- launch sequence: a side launch comes before the main-stream launches of the level that waits for it and

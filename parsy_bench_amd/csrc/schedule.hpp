@@ -137,6 +137,9 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
+constexpr int kBigGroup = 8;               // BIG launches: edge of the super-tiles whose tasks share an XCD (PARSY_BIG_GROUP)
+constexpr int kBigGroupsPerXcd = 2;        // ... used only where every XCD gets at least this many of them
+constexpr int kBigTailGroups = 16;         // ... the lightest groups are dealt again at half the edge
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
@@ -159,6 +162,7 @@ struct Schedule {
     double inner_flops = 0;        // in-supernode SYRK/GEMM flops of the tiled path (CHAIN launches)
 
     std::vector<SnDesc> sn;          // the supernodes of the pattern (solve launches)
+    std::vector<int> sparent;        // supernodal etree (-1: root), postordered
     // Cholesky view: the same supernodes, the very wide ones cut into pieces (column ranges) that are
     // factored one after the other like a chain of supernodes -- a piece's panel is a window of the
     // supernode's panel (ld, rbias), the pieces to its left update it like descendants (identity row
@@ -215,7 +219,9 @@ struct Schedule {
     std::vector<PanelDesc> bsolve_blocks;
     std::vector<Launch> bsolve;
 
-    std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches
+    std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)
+    std::vector<uint8_t> active_piece; // per piece of the Cholesky view, 1 = factored by the launches
+    std::vector<size_t> chol_level_begin;  // cnlevels + 1: first launch of every level's step in `chol`
     std::vector<int> levelPtr, levelSet;  // etree level sets the launches follow
     std::vector<int64_t> split_ranges;    // split tiles: per part 4 x (begin, end) into wave_entries
     std::vector<int64_t> tile_split;      // per (tiled supernode, J, I) as tile_w / 2: index into split_desc or -1
@@ -235,7 +241,7 @@ struct Schedule {
 void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const int* A2i,
                     const uint8_t* active, Schedule& out, int compute_units = 0);
 // Recompute only the launch lists for a new active set.
-void build_launches(Schedule& S, const uint8_t* active);
+void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pieces = nullptr);
 // Dry run of the CHAIN launches' hand-off protocol with `slots` resident workgroups (tickets in start
 // order, a workgroup leaves when its tile is published, a walker when its supernode is done):
 // returns the number of tiles that are never finished (0 = the schedule cannot deadlock at that
