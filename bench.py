@@ -15,9 +15,10 @@ single-GPU configuration; the SuiteSparse file itself cannot be fetched offline)
 27-point stencil 116^3, geometric nested dissection, n = 1 560 896, 19.4 GB of lValues.
 The nd24k-class (configs[1]) and parabolic_fem-class (configs[3]: solves with 1 / 8 / 64
 right-hand sides) inputs are measured after it and reported as extra objects, never as
-`value`.  N > 1: the same matrix, etree subtrees sharded over the ranks, ONE exchange
-step (RCCL point-to-point gather of the subtree panels onto rank 0), root part on rank 0
--- strong scaling, as north_star describes it.
+`value`.  N > 1: the same matrix, ONE factorization over the ranks (strong scaling, as north_star
+describes it): etree subtrees below a cut on one rank each, the pieces of the separators above it
+dealt over all ranks, finished pieces sent point to point (RCCL over xGMI) after every level to
+the ranks that read them (csrc/dist.cpp, multigpu.py).
 
 PyTorch is plumbing here: device buffers, the HIP stream, torch.distributed.  All
 numerics run in libparsy_amd.so through its C ABI.
@@ -354,32 +355,38 @@ def main():
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
     L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
 
-    cut = None
-    plan_root = None
-    px = None
+    DF = engine = pieces = D = None
     if world > 1:
-        cut = MG.cut_subtrees(sym, world)
-        px = MG.PackedExchange(sym, cut)
-        plan.set_active(cut.mask(rank))
+        # the library's distribution (parsy_dist): subtrees below a cut on one rank each, the pieces above it dealt
+        # over the ranks; after every level the finished pieces travel to the ranks that read them (RCCL point to point)
+        D = api.Dist(plan, world, int(os.environ.get("PARSY_DIST_BLOCK", "1")))
+        if D.check(plan) != 0:
+            raise SystemExit("the distribution is inconsistent: " + str(D.check(plan)))
+        pieces = plan.pieces()
+        plan.set_active_pieces(D.mask(rank))
+        DF = MG.DistributedFactorization(D, rank, dist, dev, stage_on_host=(backend != "nccl"))
+        engine = MG.PlanEngine(plan, values.data_ptr())
         if rank == 0:
-            plan_root = api.Plan(sym, local_rank)
-            plan_root.set_active(cut.root_mask())
-            log(f"[bench] subtree cut: {len(cut.subtrees)} subtrees, {len(cut.root_nodes)} root-part "
-                f"supernodes, rank cost share {np.round(cut.rank_cost / cut.cost.sum(), 3).tolist()}, "
-                f"root share {cut.cost[cut.root_nodes].sum() / cut.cost.sum():.3f}; exchange "
-                f"{px.packed_elements * 8 / 1e9:.2f} GB packed of {px.full_elements * 8 / 1e9:.2f} GB of panels")
+            i = D.info
+            log(f"[bench] distribution over {world} ranks: {i['n_subtrees']} subtrees below the cut, {i['n_root_pieces']} "
+                f"pieces above it ({i['root_cost'] / i['total_cost']:.3f} of the flops), rank shares "
+                f"{np.round(D.rank_cost / D.rank_cost.sum(), 3).tolist()}, {i['n_messages']} messages, "
+                f"{i['exchange_elements'] * 8 / 1e9:.2f} GB travel per factorization")
 
     def factor_step():
-        plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
-        if world > 1:
-            # the ONE exchange step: the panel rows the root part reads, packed, point to point onto rank 0
-            px.run(L, rank, dist, stream, stage_on_host=(backend != "nccl"))
-            if rank == 0:
-                plan_root.factor_device(values.data_ptr(), L.data_ptr(), stream, init=False)
+        if world == 1:
+            plan.factor_device(values.data_ptr(), L.data_ptr(), stream)
+        else:
+            DF.factor(engine, L, stream)
 
     # ---- factorizations ------------------------------------------------------------
     dt_f = timed(factor_step, args.warmup, args.steps)
-    status = plan.status() if world == 1 else (plan_root.status() if rank == 0 else 0)
+    status = plan.status()
+    if world > 1:   # every rank factors its own pieces: the first failing pivot / error of any rank
+        t = torch.tensor([float(status if status > 0 else (1 << 40) if status == 0 else -1)], dtype=torch.float64,
+                         device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        status = 0 if t.item() >= float(1 << 40) else int(t.item())
     if status != 0:
         raise SystemExit(f"factorization failed: status {status} (> 0: non-positive pivot at that column; "
                          f"< 0: a hand-off wait inside a launch timed out)")
@@ -409,7 +416,7 @@ def main():
     # after the timed factorizations the factor is distributed (subtree panels on their owners, root part on
     # rank 0): collect the rest on rank 0 for the single-GPU solves below (not timed: not part of a factorization)
     if world > 1:
-        MG.gather_to_root(L, cut, sym, rank, dist, stage_on_host=(backend != "nccl"))
+        MG.gather_factor(L, pieces, D.owner, rank, dist, stage_on_host=(backend != "nccl"))
     # ---- forward / backward solves (rank 0 holds the whole factor) -------------------------
     dt_s = dt_b = solve_err = back_err = None
     nrhs = args.nrhs
@@ -474,8 +481,10 @@ def main():
             "etree_levels": sym.nlevels, "cholesky_view": {k: info[k] for k in (
                 "n_pieces", "chol_levels", "piece_width", "big_min_k", "big_tasks", "big_entries")},
             "launches_per_factorization": info["chol_launches"],
-            "parallelism": "1 GPU" if world == 1 else (f"etree subtrees over {world} GPUs, one packed point-to-point "
-                                                       f"exchange of the rows the root part reads, root part on rank 0"),
+            "parallelism": "1 GPU" if world == 1 else (
+                f"{world} GPUs: etree subtrees below a cut on one rank each, the pieces of the separators above it dealt "
+                f"over all ranks; after every level of the Cholesky view the finished pieces travel point to point "
+                f"(RCCL) to the ranks that read them"),
         },
         "gflops_F": sym.flops_colcount / (dt_f / args.steps) / 1e9,
         "solves_per_sec": (args.steps * nrhs / dt_s) if dt_s else None,

@@ -232,8 +232,10 @@ typedef struct parsy_dist_info {
 parsy_dist* parsy_dist_create(const parsy_plan* plan, int nranks, int block);
 void parsy_dist_destroy(parsy_dist* dist);
 int parsy_dist_get_info(const parsy_dist* dist, parsy_dist_info* info);
-/* owner[n_pieces]; rank_cost[nranks]; level_cost[nlevels * nranks] (any may be NULL) */
-int parsy_dist_get(const parsy_dist* dist, int32_t* owner, double* rank_cost, double* level_cost);
+/* owner[n_pieces]; in_subtree[n_pieces] (1: the piece lies below the cut, in a subtree that went to one rank as a
+ * whole; 0: above it); rank_cost[nranks]; level_cost[nlevels * nranks] (any may be NULL) */
+int parsy_dist_get(const parsy_dist* dist, int32_t* owner, uint8_t* in_subtree, double* rank_cost,
+                   double* level_cost);
 /* Messages that follow level `level`: their number; message `index` of them (borrowed pointers, valid until
  * the dist is destroyed): sender, receiver, number of segments, elements of the packed buffer, and per segment
  * its offset in lValues, its length and its offset in the packed buffer. */
@@ -294,6 +296,10 @@ double parsy_last_solve_ms(parsy_plan* plan);
 int parsy_plan_profile(parsy_plan* plan, int enable);
 int parsy_plan_profile_collect(parsy_plan* plan);
 int parsy_plan_profile_get(parsy_plan* plan, double* kind_ms, int* kind_launches, int* runs);
+/* The factorization launches of the collected runs per level of the Cholesky view: accumulated ms of the launches
+ * that run on the caller's stream (main_ms[chol_levels]) and of those that belong to the plan's side stream
+ * (side_ms[level] = the side launches whose targets start at that level).  Returns chol_levels. */
+int parsy_plan_profile_levels(parsy_plan* plan, double* main_ms, double* side_ms);
 
 /* Thread-local message of the last failing call. */
 const char* parsy_last_error(void);
@@ -375,6 +381,12 @@ int parsy_mg_set_values(parsy_mg* mg, const double* values);
  * time from the first enqueue to the last rank's completion.  Returns 0, or the factorization status of the
  * first rank that reports one (> 0: non-positive pivot column, < 0: error). */
 int parsy_mg_factor(parsy_mg* mg, double* seconds);
+/* One factorization with every launch timed by itself: the ranks take turns (a rank's step of a level runs alone
+ * on its device, also when ranks share one), per-launch hipEvents as parsy_plan_profile.  main_ms / side_ms:
+ * nranks x chol_levels (row = rank) ms of the main-stream and side-stream launches per level; copy_ms: nranks x
+ * chol_levels ms of the copies a rank receives after a level.  What a rank would spend on a device of its own,
+ * for the model of DESIGN.md section 6.  Returns as parsy_mg_factor. */
+int parsy_mg_profile(parsy_mg* mg, double* main_ms, double* side_ms, double* copy_ms);
 /* Per rank: device milliseconds of its last factorization (hipEvents on its stream). rank_ms[nranks]. */
 int parsy_mg_rank_ms(parsy_mg* mg, double* rank_ms);
 /* Collect the factor on the host: every piece from its owner (lValues: xsize doubles). */

@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "parsy_plan_set_active_pieces", "parsy_dist_create", "parsy_dist_destroy", "parsy_dist_get_info",
     "parsy_dist_get", "parsy_dist_level_messages", "parsy_dist_message", "parsy_dist_check",
     "parsy_mg_create", "parsy_mg_destroy", "parsy_mg_set_values", "parsy_mg_factor", "parsy_mg_rank_ms",
-    "parsy_mg_gather_host", "parsy_mg_dist", "parsy_mg_plan",
+    "parsy_mg_gather_host", "parsy_mg_dist", "parsy_mg_plan", "parsy_mg_profile", "parsy_plan_profile_levels",
 ]
 
 
@@ -135,7 +135,7 @@ def _declare(lib):
     lib.parsy_dist_create.argtypes = [vp, C.c_int, C.c_int]
     lib.parsy_dist_destroy.argtypes = [vp]
     lib.parsy_dist_get_info.argtypes = [vp, C.POINTER(DistInfo)]
-    lib.parsy_dist_get.argtypes = [vp, vp, vp, vp]
+    lib.parsy_dist_get.argtypes = [vp, vp, vp, vp, vp]
     lib.parsy_dist_level_messages.argtypes = [vp, C.c_int]
     lib.parsy_dist_message.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, c_i64_p, c_i64_p,
                                        C.POINTER(c_i64_p), C.POINTER(c_int_p), C.POINTER(c_i64_p)]
@@ -147,6 +147,8 @@ def _declare(lib):
     lib.parsy_mg_set_values.argtypes = [vp, vp]
     lib.parsy_mg_factor.argtypes = [vp, vp]
     lib.parsy_mg_rank_ms.argtypes = [vp, vp]
+    lib.parsy_mg_profile.argtypes = [vp, vp, vp, vp]
+    lib.parsy_plan_profile_levels.argtypes = [vp, vp, vp]
     lib.parsy_mg_gather_host.argtypes = [vp, vp]
     lib.parsy_mg_dist.restype = vp
     lib.parsy_mg_dist.argtypes = [vp]

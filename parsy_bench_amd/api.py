@@ -306,9 +306,11 @@ class Dist:
         self.info = di.as_dict()
         self.nranks, self.nlevels = di.nranks, di.nlevels
         self.owner = np.zeros(di.n_pieces, dtype=np.int32)
+        self.in_subtree = np.zeros(di.n_pieces, dtype=np.uint8)
         self.rank_cost = np.zeros(di.nranks)
         self.level_cost = np.zeros((di.nlevels, di.nranks))
-        N.lib().parsy_dist_get(self._h, N.ptr(self.owner), N.ptr(self.rank_cost), N.ptr(self.level_cost))
+        N.lib().parsy_dist_get(self._h, N.ptr(self.owner), N.ptr(self.in_subtree), N.ptr(self.rank_cost),
+                               N.ptr(self.level_cost))
 
     def close(self):
         h, self._h = self._h, None
@@ -385,6 +387,16 @@ class MultiDevice:
         if st < 0:
             raise RuntimeError("parsy_mg_factor failed: " + N.last_error())
         return st, sec.value
+
+    def profile(self):
+        """One factorization with the ranks taking turns (every step alone on its device) and every launch timed:
+        (status, main_ms, side_ms, copy_ms), each nranks x levels."""
+        shape = (self.nranks, self.dist.nlevels)
+        main, side, copy = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+        st = int(N.lib().parsy_mg_profile(self._h, N.ptr(main), N.ptr(side), N.ptr(copy)))
+        if st < 0:
+            raise RuntimeError("parsy_mg_profile failed: " + N.last_error())
+        return st, main, side, copy
 
     def rank_ms(self) -> np.ndarray:
         out = np.zeros(self.nranks)

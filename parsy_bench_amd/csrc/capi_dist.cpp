@@ -54,10 +54,12 @@ int parsy_dist_get_info(const parsy_dist* dist, parsy_dist_info* o) {
     return 0;
 }
 
-int parsy_dist_get(const parsy_dist* dist, int32_t* owner, double* rank_cost, double* level_cost) {
+int parsy_dist_get(const parsy_dist* dist, int32_t* owner, uint8_t* in_subtree, double* rank_cost,
+                   double* level_cost) {
     if (!dist) return -1;
     const parsy::Dist& D = dist->D;
     if (owner) std::copy(D.owner.begin(), D.owner.end(), owner);
+    if (in_subtree) std::copy(D.in_subtree.begin(), D.in_subtree.end(), in_subtree);
     if (rank_cost) std::copy(D.rank_cost.begin(), D.rank_cost.end(), rank_cost);
     if (level_cost) std::copy(D.level_cost.begin(), D.level_cost.end(), level_cost);
     return 0;

@@ -465,6 +465,7 @@ int parsy_plan_profile(parsy_plan* pl, int enable) {
     if (enable == 2) {  // reset the accumulators
         for (int k = 0; k < 10; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
         pl->profiled_runs = 0;
+        pl->level_ms.clear();
     }
     return 0;
 }
@@ -479,6 +480,17 @@ int parsy_plan_profile_get(parsy_plan* pl, double* kind_ms, int* kind_launches, 
     }
     if (runs) *runs = pl->profiled_runs;
     return 0;
+}
+
+int parsy_plan_profile_levels(parsy_plan* pl, double* main_ms, double* side_ms) {
+    if (!pl) return -1;
+    const int nl = pl->S.cnlevels;
+    for (int l = 0; l < nl; ++l) {
+        const size_t a = (size_t)l << 1, b = a | 1;
+        if (main_ms) main_ms[l] = a < pl->level_ms.size() ? pl->level_ms[a] : 0.0;
+        if (side_ms) side_ms[l] = b < pl->level_ms.size() ? pl->level_ms[b] : 0.0;
+    }
+    return nl;
 }
 
 int parsy_factor_host(parsy_plan* pl, const double* values, double* lValues, double* seconds) {

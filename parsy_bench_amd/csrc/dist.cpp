@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <queue>
 #include <stdexcept>
 
@@ -83,8 +84,11 @@ void build_dist(const Schedule& S, int nranks, int block, Dist& D) {
         return *std::max_element(load.begin(), load.end());
     };
     const double share = D.total_cost / nranks;
+    // PARSY_DIST_MIN_SUBTREES=k: keep opening until there are at least k subtrees (diagnostics, tests: a deeper cut)
+    int min_subtrees = nranks;
+    if (const char* e = std::getenv("PARSY_DIST_MIN_SUBTREES")) min_subtrees = std::max(nranks, std::atoi(e));
     while (nranks > 1 && !heap.empty()) {
-        if ((int)heap.size() >= nranks && packed_max(heap) <= share) break;
+        if ((int)heap.size() >= min_subtrees && packed_max(heap) <= share) break;
         const int s = heap.top().second;
         if (children[(size_t)s].empty() || S.chol_subtree[(size_t)s] >= 0) break;
         if ((int)heap.size() >= 64 * nranks) break;

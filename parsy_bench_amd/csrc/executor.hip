@@ -189,8 +189,10 @@ void plan_free(parsy_plan* pl) {
     delete pl;
 }
 
-static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& cursor) {
+static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& cursor, int level = -1, int side = 0) {
     if (!pl->profile) return;
+    if (cursor >= pl->pev_level.size()) pl->pev_level.resize(cursor + 1, 0);
+    pl->pev_level[cursor] = level >= 0 ? (level << 1) | (side & 1) : -1;
     if (cursor >= pl->pev.size()) {
         hipEvent_t e;
         (void)hipEventCreate(&e);
@@ -241,7 +243,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                 if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
             }
         }
-        profile_mark(pl, l.kind, stream, cursor);
+        profile_mark(pl, l.kind, stream, cursor, l.level, l.side);
         switch (l.kind) {
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, l.fused == 2, L, stream); break;
             case kLaunchTiles:
@@ -368,6 +370,12 @@ int plan_collect_profile(parsy_plan* pl) {
             pl->kind_ms[k] += ms;
             pl->kind_launches[k] += 1;
         }
+        // factorization launches also per level of the Cholesky view and stream (main / side)
+        if (k >= 0 && k <= kLaunchBig && i < pl->pev_level.size() && pl->pev_level[i] >= 0) {
+            const size_t slot = (size_t)pl->pev_level[i];
+            if (pl->level_ms.size() <= slot) pl->level_ms.resize(slot + 1, 0.0);
+            pl->level_ms[slot] += ms;
+        }
     }
     pl->profiled_runs += 1;
     return 0;
@@ -419,6 +427,8 @@ int plan_factor_levels(parsy_plan* pl, int level0, int level1, double* d_L, hipS
     if (level1 > level0)
         run_range(pl, S.chol, S.chol_level_begin[(size_t)level0], S.chol_level_begin[(size_t)level1], d_L, d_L, nullptr,
                   0, 0, stream);
+    // (profiling: what the caller does between two steps is not a launch's time)
+    profile_mark(pl, -1, stream, pl->run_cursor);
     pl->factor_next_level = level1;
     PARSY_HIP(hipGetLastError());
     return 0;

@@ -57,6 +57,8 @@ struct parsy_plan {
     bool profile = false;
     std::vector<hipEvent_t> pev;
     std::vector<int> pev_kind;
+    std::vector<int> pev_level;     // per mark: level << 1 | side of a factorization launch (-1: other)
+    std::vector<double> level_ms;   // accumulated ms per (level << 1 | side)
     double kind_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int kind_launches[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int profiled_runs = 0;

@@ -258,6 +258,70 @@ int parsy_mg_factor(parsy_mg* mg, double* seconds) {
     return 0;
 }
 
+int parsy_mg_profile(parsy_mg* mg, double* main_ms, double* side_ms, double* copy_ms) {
+    if (!mg || !mg->have_values) {
+        set_last_error("parsy_mg_profile: null handle or no values (parsy_mg_set_values first)");
+        return -1;
+    }
+    const parsy::Dist& D = parsy_dist_cxx(mg->dist);
+    const int nr = mg->nranks, nl = D.nlevels;
+    if (copy_ms) std::fill(copy_ms, copy_ms + (size_t)nr * nl, 0.0);
+    std::vector<hipEvent_t> c0((size_t)nr), c1((size_t)nr);
+    for (int r = 0; r < nr; ++r) {
+        MG_HIP(hipSetDevice(mg->device[(size_t)r]), -1);
+        MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
+        MG_HIP(hipEventCreate(&c0[(size_t)r]), -1);
+        MG_HIP(hipEventCreate(&c1[(size_t)r]), -1);
+        parsy_plan_profile(mg->plan[(size_t)r], 2);
+        if (parsy::plan_factor_begin(mg->plan[(size_t)r], mg->values[(size_t)r], mg->L[(size_t)r], mg->stream[(size_t)r], true) != 0)
+            return -1;
+        MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
+    }
+    for (int lev = 0; lev < nl; ++lev) {
+        for (int r = 0; r < nr; ++r) {   // one rank at a time: its step has the device to itself
+            MG_HIP(hipSetDevice(mg->device[(size_t)r]), -1);
+            if (parsy::plan_factor_levels(mg->plan[(size_t)r], lev, lev + 1, mg->L[(size_t)r], mg->stream[(size_t)r]) != 0)
+                return -1;
+            MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
+        }
+        for (int r = 0; r < nr; ++r) {   // the copies a rank receives, timed as one block
+            bool any = false;
+            MG_HIP(hipSetDevice(mg->device[(size_t)r]), -1);
+            for (int64_t m = D.level_msg0[(size_t)lev]; m < D.level_msg0[(size_t)lev + 1]; ++m) {
+                const parsy::DistMessage& M = D.msgs[(size_t)m];
+                if (M.dst != r) continue;
+                if (!any) MG_HIP(hipEventRecord(c0[(size_t)r], mg->stream[(size_t)r]), -1);
+                any = true;
+                parsy::launch_copy_segments(mg->L[(size_t)M.dst], mg->L[(size_t)M.src], mg->dmsg[(size_t)m].off,
+                                            mg->dmsg[(size_t)m].off, mg->dmsg[(size_t)m].len, (int64_t)M.off.size(),
+                                            mg->stream[(size_t)r]);
+            }
+            if (any) {
+                MG_HIP(hipEventRecord(c1[(size_t)r], mg->stream[(size_t)r]), -1);
+                MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
+                float ms = 0;
+                MG_HIP(hipEventElapsedTime(&ms, c0[(size_t)r], c1[(size_t)r]), -1);
+                if (copy_ms) copy_ms[(size_t)r * nl + lev] = ms;
+            }
+        }
+    }
+    int status = 0;
+    for (int r = 0; r < nr; ++r) {
+        MG_HIP(hipSetDevice(mg->device[(size_t)r]), -1);
+        if (parsy::plan_factor_end(mg->plan[(size_t)r], mg->stream[(size_t)r]) != 0) return -1;
+        MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
+        parsy_plan_profile_collect(mg->plan[(size_t)r]);
+        parsy_plan_profile_levels(mg->plan[(size_t)r], main_ms ? main_ms + (size_t)r * nl : nullptr,
+                                  side_ms ? side_ms + (size_t)r * nl : nullptr);
+        parsy_plan_profile(mg->plan[(size_t)r], 0);
+        (void)hipEventDestroy(c0[(size_t)r]);
+        (void)hipEventDestroy(c1[(size_t)r]);
+        const int st = parsy_factor_status(mg->plan[(size_t)r]);
+        if (st != 0 && status == 0) status = st;
+    }
+    return status;
+}
+
 int parsy_mg_rank_ms(parsy_mg* mg, double* rank_ms) {
     if (!mg || !rank_ms) return -1;
     for (int r = 0; r < mg->nranks; ++r) {

@@ -39,6 +39,19 @@ def problem(name):
 _CACHE = {}
 
 
+def shard_masks(sym, nranks):
+    """Supernode masks of an nranks-way distribution (parsy_dist on a host-only plan): one mask per rank -- the
+    supernodes whose first piece the rank owns -- for the tests that restrict a plan's launches to a shard."""
+    import numpy as np
+    from parsy_bench_amd import api
+    plan = api.Plan(sym, -1)
+    D = api.Dist(plan, nranks)
+    pieces = plan.pieces()
+    first = np.concatenate([[True], np.diff(pieces["supernode"]) != 0])
+    own = D.owner[first]
+    return [(own == r).astype(np.uint8) for r in range(nranks)]
+
+
 @pytest.fixture(scope="module")
 def api():
     """The product's Python binding; the -m gpu tier fails loudly without a device."""

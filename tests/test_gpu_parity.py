@@ -284,63 +284,83 @@ def test_new_values_same_pattern(api, oracle):
 
 
 # ---------------------------------------------------------------------------
-# subtree shards on one device (what two ranks do, minus the wire)
+# the distributed factorization, N ranks sharing this one device (parsy_mg: what a node does, with
+# device-to-device copies in place of xGMI peer copies)
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name,nranks", [("lap30", 2), ("lap30", 4), ("flan", 8)])
-def test_sharded_factorization_on_one_device(api, oracle, name, nranks):
-    """What N ranks do, minus the wire: every "rank" factors its subtrees into its own buffer, the rows the
-    root part reads are packed (multigpu.PackedExchange's segments, the library's copy kernel) and unpacked
-    into rank 0's buffer, rank 0 factors the root part.  The root-part panels must equal the unsharded
-    factorization bit for bit -- also for the Flan-class input (BASELINE configs[4]'s cut over 8 ranks;
-    BIG launches and pieces active), which is too large for the CPU checker."""
-    import torch
-    from parsy_bench_amd import inspector as I, matrices as M, multigpu as MG
-    if name == "flan":
-        A, perm = M.workload(name)
-        sym = I.analyze(A, perm)
-    else:
-        A, perm, sym = problem(name)
-    cut = MG.cut_subtrees(sym, nranks)
-    px = MG.PackedExchange(sym, cut)
-    assert 0 < px.packed_elements < px.full_elements
-    dev = torch.device("cuda", 0)
-    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
-    Lfull = torch.zeros(int(sym.xsize), dtype=torch.float64, device=dev)
-    Lr = torch.empty_like(Lfull)
+@pytest.mark.parametrize("name,nranks,block,env", [
+    ("mid3d", 2, 1, {}), ("lap30", 4, 1, {}),
+    ("lap30", 4, 1, {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "32"}),
+    ("lap30", 3, 2, {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "32", "PARSY_SUBTREES": "2"}),
+    ("mid3d", 6, 1, {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16", "PARSY_DIST_MIN_SUBTREES": "16"}),
+    ("nd24k", 4, 1, {}),
+])
+def test_distributed_factorization_on_one_device(api, oracle, monkeypatch, name, nranks, block, env):
+    """Subtrees below the cut on one rank each, the pieces above it dealt over the ranks (split supernodes: their
+    pieces on different ranks), finished pieces copied to the ranks that read them after every level: the factor
+    collected from the owners equals the single-plan factor BIT FOR BIT, and the oracle to rounding."""
+    from parsy_bench_amd import inspector as I
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A, perm, sym = problem(name)
     plan = api.Plan(sym, 0)
-    # each "rank" factors its subtrees into the scratch buffer; the tails of its panels are packed and
-    # unpacked into rank 0's buffer (rank 0's own subtrees are already there)
-    for rk in range(nranks):
-        plan.set_active(cut.mask(rk))
-        plan.factor_device(values.data_ptr(), (Lfull if rk == 0 else Lr).data_ptr(), 0)
-        torch.cuda.synchronize()
-        assert plan.status() == 0
-        if rk == 0:
-            continue
-        for k, (owner, src, ln, off, total) in enumerate(px.items):
-            if owner != rk or total == 0:
-                continue
-            buf = torch.empty(total, dtype=torch.float64, device=dev)
-            px._copy(buf, Lr, off, src, ln, k, 0)
-            px._copy(Lfull, buf, src, off, ln, k, 0)
-        torch.cuda.synchronize()
-    plan.set_active(cut.root_mask())
-    plan.factor_device(values.data_ptr(), Lfull.data_ptr(), 0, init=False)
+    ref, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    mg = api.MultiDevice(sym, [0] * nranks, block)
+    try:
+        info = mg.dist.info
+        assert info["n_subtrees"] >= nranks and info["n_messages"] > 0
+        if "PARSY_PIECE_WIDTH" in env:
+            assert plan.info["n_pieces"] > sym.nsuper
+        mg.set_values(sym.A2x)
+        for _ in range(2):          # (twice: epochs, flags and tickets of the shards are reusable)
+            st, _ = mg.factor()
+            assert st == 0
+            got = mg.gather()
+            assert np.array_equal(got, ref)
+        above = np.where(mg.dist.in_subtree == 0)[0]
+        if len(above) >= 2:
+            assert len(set(mg.dist.owner[above].tolist())) >= 2
+        # the profiled form (ranks take turns, every launch timed) computes the same factor
+        st, main, side, copy = mg.profile()
+        assert st == 0 and np.array_equal(mg.gather(), ref)
+        assert main.shape == (nranks, plan.info["chol_levels"]) and (main.sum(axis=1) > 0).all()
+    finally:
+        mg.close()
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok and np.abs(ref - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+def test_distributed_flan_class_factorization_on_one_device(api):
+    """BASELINE configs[4] at full size, 8 ranks sharing this device (8 x 19.4 GB of lValues): BIG launches and
+    pieces active, the top separator's 40 pieces dealt over all ranks, 45 GB of pieces copied between the ranks'
+    buffers.  Checked bit for bit against the single-plan factor on the device (the input is too large for the CPU
+    checker; the single-plan factor is what the size-independent tests below check)."""
+    import torch
+    from parsy_bench_amd import inspector as I, matrices as M
+    A, perm = M.workload("flan")
+    sym = I.analyze(A, perm)
+    dev = torch.device("cuda", 0)
+    plan = api.Plan(sym, 0)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    Lref = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    plan.factor_device(values.data_ptr(), Lref.data_ptr(), 0)
     torch.cuda.synchronize()
     assert plan.status() == 0
-    plan.set_active(None)
-    plan.factor_device(values.data_ptr(), Lr.data_ptr(), 0)   # unsharded, same plan
-    torch.cuda.synchronize()
-    assert plan.status() == 0
-    for s in cut.root_nodes:                                   # sharding does not change a single bit
-        a, b = int(sym.p[sym.super[s]]), int(sym.p[sym.super[s + 1]])
-        assert bool(torch.equal(Lfull[a:b], Lr[a:b]))
-    for owner, a, b in cut.slices(sym):                        # rank 0's own subtrees too
-        if owner == 0:
-            assert bool(torch.equal(Lfull[a:b], Lr[a:b]))
-    if name != "flan":
-        ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
-        assert np.abs(Lr.cpu().numpy() - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+    del plan
+    mg = api.MultiDevice(sym, [0] * 8)
+    try:
+        D = mg.dist
+        assert D.rank_cost.max() / D.rank_cost.sum() <= 1.05 / 8
+        mg.set_values(sym.A2x)
+        st, _ = mg.factor()
+        assert st == 0
+        # collected from the owners (19.4 GB through the host), compared on the device in slices
+        got = mg.gather()
+        for a in range(0, len(got), 1 << 27):
+            b = min(len(got), a + (1 << 27))
+            assert bool(torch.equal(torch.from_numpy(got[a:b]).to(dev), Lref[a:b]))
+    finally:
+        mg.close()
 
 
 # ---------------------------------------------------------------------------

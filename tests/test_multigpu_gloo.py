@@ -1,8 +1,9 @@
-"""The N > 1 path on CPU: two gloo ranks shard the etree subtrees (multigpu.cut_subtrees),
-factor their shares, run the ONE exchange step (multigpu.gather_to_root over
-torch.distributed) and rank 0 finishes the root part.  The numeric work is done by the CPU
-oracle here (no GPU in this tier); partitioning, masks, slices and the exchange are the
-product's code and are what is under test.  Result: bitwise the single-process factor.
+"""The N > 1 path on CPU: gloo ranks run the library's distribution (parsy_dist: subtree cut + the pieces above it
+dealt over the ranks) level by level, with the fan-out messages of multigpu.DistributedFactorization over
+torch.distributed in between.  The numeric work of a level is done by the CPU oracle here (no GPU in this tier);
+ownership, messages, packing, the point-to-point exchange and the final gather are the product's code and are
+what is under test.  Result: bitwise the single-process factor, with the part above the cut factored by more than
+one rank.
 """
 import os
 import sys
@@ -14,7 +15,9 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _rank_main(rank, world, port, name, out_dir):
+def _rank_main(rank, world, port, name, out_dir, min_subtrees):
+    if min_subtrees:
+        os.environ["PARSY_DIST_MIN_SUBTREES"] = str(min_subtrees)
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,71 +25,94 @@ def _rank_main(rank, world, port, name, out_dir):
     import torch
     import torch.distributed as dist
     import oracle as O
-    from parsy_bench_amd import inspector as I, matrices as M, multigpu as MG
+    from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     A, perm = M.workload(name)
     sym = I.analyze(A, perm)
-    cut = MG.cut_subtrees(sym, world)
+    plan = api.Plan(sym, -1)              # host schedule only: pieces, levels, update lists
+    pieces = plan.pieces()
+    assert len(pieces["supernode"]) == sym.nsuper, "the oracle factors whole supernodes: no split ones in this test"
+    D = api.Dist(plan, world)
+    assert D.check(plan) == 0
+    a = dict(c=sym.A2p, r=sym.A2i, v=np.ascontiguousarray(sym.A2x), lC=sym.p, lR=sym.s, Li=sym.i_ptr,
+             bs=sym.super, aT=sym.sParent, cT=sym.A1p, rT=sym.A1i, c2s=sym.col2Sup)
+    a = {k: np.ascontiguousarray(v) for k, v in a.items()}
 
-    def factor_subset(mask, lvalues):
-        """Oracle run restricted to the masked supernodes, level by level (no root phase)."""
-        lev_lists = []
-        for l in range(sym.nlevels):
-            members = [int(s) for s in sym.levelSet[sym.levelPtr[l]: sym.levelPtr[l + 1]] if mask[s]]
-            lev_lists.append(members)
-        partition = np.array([s for lst in lev_lists for s in lst], dtype=np.int32)
-        parPtr = np.arange(len(partition) + 1, dtype=np.int32)
-        levelPtr = np.concatenate([[0], np.cumsum([len(l) for l in lev_lists]), [len(partition)]]).astype(np.int32)
-        nl = sym.nlevels + 1  # an empty last l-level: nothing runs in the sequential root phase
-        timing = np.zeros(16)
-        a = dict(c=sym.A2p, r=sym.A2i, v=np.ascontiguousarray(sym.A2x), lC=sym.p, lR=sym.s, Li=sym.i_ptr,
-                 bs=sym.super, aT=sym.sParent, cT=sym.A1p, rT=sym.A1i, c2s=sym.col2Sup)
-        a = {k: np.ascontiguousarray(v) for k, v in a.items()}
-        ok = O.lib().oracle_cholesky_left_par_05(
-            sym.n, O.P(a["c"]), O.P(a["r"]), O.P(a["v"]), O.P(a["lC"]), O.P(a["lR"]), O.P(a["Li"]),
-            O.P(lvalues), O.P(a["bs"]), sym.nsuper, O.P(timing), O.P(a["aT"]), O.P(a["cT"]), O.P(a["rT"]),
-            O.P(a["c2s"]), nl, O.P(levelPtr), None, 0, O.P(parPtr), O.P(partition), 1, 1,
-            sym.maxSupWid + 1, sym.maxCol + 1, None)
-        assert ok
+    class OracleEngine:
+        """One level of the Cholesky view = the rank's supernodes of that level, each a w-partition of its own."""
 
-    lv = torch.zeros(int(sym.xsize), dtype=torch.float64)
-    factor_subset(cut.mask(rank), lv.numpy())
-    # the exchange step in its packed form: only the panel rows the root part reads travel
-    px = MG.PackedExchange(sym, cut)
-    packed = px.run(lv, rank, dist)
+        def begin(self, L, stream):
+            L.zero_()
+
+        def level(self, lev, L, stream):
+            mine = np.where((pieces["level"] == lev) & (D.owner == rank))[0]
+            if len(mine) == 0:
+                return
+            partition = pieces["supernode"][mine].astype(np.int32)
+            parPtr = np.arange(len(partition) + 1, dtype=np.int32)
+            levelPtr = np.array([0, len(partition), len(partition)], dtype=np.int32)   # + an empty root phase
+            timing = np.zeros(16)
+            ok = O.lib().oracle_cholesky_left_par_05(
+                sym.n, O.P(a["c"]), O.P(a["r"]), O.P(a["v"]), O.P(a["lC"]), O.P(a["lR"]), O.P(a["Li"]),
+                O.P(L.numpy()), O.P(a["bs"]), sym.nsuper, O.P(timing), O.P(a["aT"]), O.P(a["cT"]), O.P(a["rT"]),
+                O.P(a["c2s"]), 2, O.P(levelPtr), None, 0, O.P(parPtr), O.P(partition), 1, 1,
+                sym.maxSupWid + 1, sym.maxCol + 1, None)
+            assert ok
+
+        def end(self, L, stream):
+            pass
+
+    L = torch.zeros(int(sym.xsize), dtype=torch.float64)
+    DF = MG.DistributedFactorization(D, rank, dist, None)
+    DF.factor(OracleEngine(), L)
+    # every piece is final on its owner: before the gather, compare the rank's own pieces with the reference
+    np.save(Path(out_dir) / f"own_{rank}.npy", L.numpy().copy())
+    moved = MG.gather_factor(L, pieces, D.owner, rank, dist)
     if rank == 0:
-        factor_subset(cut.root_mask(), lv.numpy())
-        np.save(Path(out_dir) / "root_part.npy", lv.numpy().copy())
-    # the rest of the subtree panels follows where one rank wants the whole factor
-    moved = MG.gather_to_root(lv, cut, sym, rank, dist)
+        np.save(Path(out_dir) / "gathered.npy", L.numpy())
+        np.save(Path(out_dir) / "meta.npy", np.array([moved, D.info["n_subtrees"], D.info["n_root_pieces"],
+                                                      D.info["exchange_elements"], D.info["n_messages"]]))
+    sent = torch.tensor([float(DF.sent_elements)], dtype=torch.float64)
+    dist.all_reduce(sent)
     if rank == 0:
-        np.save(Path(out_dir) / "sharded.npy", lv.numpy())
-        np.save(Path(out_dir) / "moved.npy", np.array([moved, len(cut.subtrees), len(cut.root_nodes), packed,
-                                                      px.full_elements]))
+        np.save(Path(out_dir) / "sent.npy", sent.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["small3d", "mid3d"])
-def test_two_rank_subtree_factorization_matches_single_process(tmp_path, oracle, name):
+@pytest.mark.parametrize("name,world,min_subtrees", [("small3d", 2, 0), ("mid3d", 2, 4), ("lap30", 4, 0), ("mid3d", 4, 0),
+                                                     ("lap30", 2, 8)])
+def test_distributed_factorization_matches_single_process(tmp_path, oracle, monkeypatch, name, world, min_subtrees):
     import torch.multiprocessing as mp
     from conftest import problem
-    from parsy_bench_amd import inspector as I
+    from parsy_bench_amd import api, inspector as I
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_rank_main, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(world, port, name, str(tmp_path), min_subtrees), nprocs=world, join=True)
+    if min_subtrees:
+        monkeypatch.setenv("PARSY_DIST_MIN_SUBTREES", str(min_subtrees))
     A, perm, sym = problem(name)
     ok, ref, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
-    got = np.load(tmp_path / "sharded.npy")
-    moved, nsub, nroot, packed, full = np.load(tmp_path / "moved.npy")
+    got = np.load(tmp_path / "gathered.npy")
+    moved, nsub, nroot, exch, nmsg = np.load(tmp_path / "meta.npy")
     assert ok and np.array_equal(got, ref)
-    assert nsub >= 2 and nroot >= 1 and moved > 0
-    # the packed exchange moved less than the whole panels and was enough for the root part: every
-    # root-part panel is already final (bitwise) before the full gather
-    assert 0 < packed < full == moved
-    from parsy_bench_amd import multigpu as MG
-    cut = MG.cut_subtrees(sym, 2)
-    rp = np.load(tmp_path / "root_part.npy")
-    for s in cut.root_nodes:
-        a, b = int(sym.p[sym.super[s]]), int(sym.p[sym.super[s + 1]])
-        assert np.array_equal(rp[a:b], ref[a:b])
+    assert nsub >= world and nroot >= 1 and moved > 0 and nmsg > 0
+    # what the ranks sent is what the distribution announced
+    assert float(np.load(tmp_path / "sent.npy")[0]) == float(exch)
+    # every rank's own pieces were final (bitwise) before the gather, and the part above the cut was factored by
+    # more than one rank
+    plan = api.Plan(sym, -1)
+    pieces = plan.pieces()
+    D = api.Dist(plan, world)
+    own = [np.load(tmp_path / f"own_{r}.npy") for r in range(world)]
+    for p in range(len(D.owner)):
+        a, b = int(pieces["value_begin"][p]), int(pieces["value_end"][p])
+        assert np.array_equal(own[D.owner[p]][a:b], ref[a:b])
+    cost_share = D.rank_cost / D.rank_cost.sum()
+    assert cost_share.max() < (0.75 if world == 2 else 0.55)
+    above = np.where(D.in_subtree == 0)[0]
+    assert len(above) == int(nroot)
+    if nroot >= 2:
+        assert len(set(D.owner[above].tolist())) >= 2, "the pieces above the cut all went to one rank"
+    if min_subtrees or world >= 4:
+        assert nroot >= 2, "this case is meant to have the part above the cut factored by more than one rank"

@@ -4,8 +4,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import problem
-from parsy_bench_amd import _native as N, inspector as I, multigpu as MG
+from conftest import problem, shard_masks
+from parsy_bench_amd import _native as N, inspector as I
 
 
 def host_plan(sym):
@@ -59,35 +59,6 @@ def test_malformed_pattern_is_rejected():
                                            sym.A1i, sym.A2p, sym.A2i)]
     h = N.lib().parsy_plan_create(sym.n, sym.nsuper, *[N.ptr(v) for v in a], -1)
     assert not h and "supernode rows" in N.last_error()
-
-
-@pytest.mark.parametrize("name,nranks", [("small3d", 2), ("mid3d", 4), ("ex15", 8)])
-def test_subtree_cut_is_a_partition_into_independent_subtrees(name, nranks):
-    A, perm, sym = problem(name)
-    cut = MG.cut_subtrees(sym, nranks)
-    assert len(cut.owner) == sym.nsuper
-    # every supernode is in exactly one subtree or in the root part
-    covered = np.zeros(sym.nsuper, int)
-    for first, last, rank, cost in cut.subtrees:
-        covered[first:last + 1] += 1
-        assert (cut.owner[first:last + 1] == rank).all()
-        # closed under "descendant of": parents stay inside except the subtree root's
-        par = sym.sParent[first:last + 1]
-        assert ((par[:-1] >= first) & (par[:-1] <= last)).all()
-        assert par[-1] < 0 or cut.owner[par[-1]] < 0
-    covered[cut.root_nodes] += 1
-    assert (covered == 1).all()
-    # the root part is upward closed
-    for s in cut.root_nodes:
-        assert sym.sParent[s] < 0 or cut.owner[sym.sParent[s]] < 0
-    # no update crosses between two different ranks' subtrees
-    tgt = np.repeat(np.arange(sym.nsuper), np.diff(sym.updPtr))
-    o_t, o_d = cut.owner[tgt], cut.owner[sym.updSn]
-    assert ((o_t < 0) | (o_t == o_d)).all()
-    # slices are disjoint, ordered ranges of lValues
-    sl = sorted((a, b) for _, a, b in cut.slices(sym))
-    assert all(sl[i][1] <= sl[i + 1][0] for i in range(len(sl) - 1))
-    assert cut.rank_cost.max() <= cut.cost.sum()
 
 
 @pytest.mark.parametrize("name", ["small3d", "mid3d", "lap30", "ex15", "nd24k"])
@@ -158,8 +129,7 @@ def test_cholesky_view_is_consistent(monkeypatch, name, piece, mink, group):
         # the chain launches of the view cannot deadlock either
         assert N.lib().parsy_plan_chain_check(h, 512) == 0
         # restricting the launches to a subtree keeps the sequence consistent
-        cut = MG.cut_subtrees(sym, 2)
-        for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+        for mask in shard_masks(sym, 2) + shard_masks(sym, 3):
             assert N.lib().parsy_plan_set_active(h, N.ptr(np.ascontiguousarray(mask))) == 0
             assert N.lib().parsy_plan_check(h) == 0, N.last_error()
     finally:
@@ -194,9 +164,7 @@ def test_subtree_launches_replace_the_narrow_levels(name, monkeypatch):
         assert info["solve_launches"] <= levels_only["solve_launches"]
         assert info["backsolve_launches"] <= levels_only["backsolve_launches"]
         # a shard (every other subtree of a 2-way cut): only active supernodes are launched, still each exactly once
-        from parsy_bench_amd import multigpu as MG
-        cut = MG.cut_subtrees(sym, 2)
-        for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+        for mask in shard_masks(sym, 2) + shard_masks(sym, 3):
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             assert N.lib().parsy_plan_set_active(h, N.ptr(m)) == 0, N.last_error()
             assert N.lib().parsy_plan_check(h) == 0, N.last_error()
@@ -222,9 +190,7 @@ def test_solve_launches_are_consistent(name, monkeypatch):
         h, info = host_plan(sym)
         try:
             assert N.lib().parsy_plan_check(h) == 0, (env, N.last_error())
-            from parsy_bench_amd import multigpu as MG
-            cut = MG.cut_subtrees(sym, 2)
-            for mask in (cut.mask(0), cut.mask(1), cut.root_mask()):
+            for mask in shard_masks(sym, 2) + shard_masks(sym, 3):
                 m = np.ascontiguousarray(mask, dtype=np.uint8)
                 assert N.lib().parsy_plan_set_active(h, N.ptr(m)) == 0, N.last_error()
                 assert N.lib().parsy_plan_check(h) == 0, (env, N.last_error())
