@@ -1004,6 +1004,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_solve_chain_w(const SnDesc
 // columns, so that the owner's t_jb = x - sum is just the negated accumulator.  x_jb = inv(L_jj) t_jb is an MFMA
 // product too (t through LDS into operand layout); the rows below the supernode's columns are scattered at the end
 // with atomics, as in the one-vector kernel.
+static constexpr int kMrhsWideBlocks = 128;   // backward launches of at least this many blocks take 64 right-hand sides per pass
 static constexpr int kLdXm = kRhsM + 16;  // row stride of the staged x_jb / t_jb (doubles): conflict-free operand reads
 
 __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* __restrict__ sn,
@@ -1490,6 +1491,291 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// Backward solve, many right-hand sides (from mrhs_min() on): the counterpart of k_solve_small_mrhs /
+// k_solve_chain_mrhs -- 64 right-hand sides per pass over L instead of 4, every product on the matrix cores.
+// One workgroup (4 waves) per block of <= 64 columns, as k_bsolve_block:
+//     T = Y_blk - L(below, blk)' X(below)        (64 columns x 64 right-hand sides)
+// with the panel ROWS as the contraction index of v_mfma_f64_16x16x4_f64: lane (c, kk) holds L[k0 + kk][cb + c]
+// (A operand: 16 columns x 4 consecutive rows -- 32-byte runs of 16 panel columns per load, every 128-byte line is
+// used up by four consecutive k steps) and lane (kk, q) holds X[row(k0 + kk)][q] (B operand, gathered through the
+// row ids).  The 64-row chunks below the block are dealt over the four waves, each keeps all 16 tiles of T (128
+// accumulator registers; one workgroup per CU); chain launches then take the later blocks of the supernode as their
+// X is published (armed buffer: the data is the flag), 16 rows per wave.  The waves' parts are subtracted from the
+// staged Y one after the other (fixed order: reproducible), then X_blk = inv(L_bb)' T -- chain launches: a product
+// with the inverse diagonal block (DIAG_INVERSE) on the matrix cores; otherwise the blocked substitution of
+// k_bsolve_block.  Reference: the backward solve is an extension; the forward kernel it mirrors
+// replaces Triangular_BCSC.h:139-157.
+// ---------------------------------------------------------------------------
+#define TSM(c, q) ts[(c) * kLdXm + (q)]
+template <int QG>   // 16-right-hand-side groups per pass: 4 (64 per pass over L) or 1 (small launches: more workgroups)
+__global__ __launch_bounds__(kThreads, QG == 4 ? 1 : 2) void k_bsolve_block_mrhs(const SnDesc* __restrict__ sn,
+                                                                   const PanelDesc* __restrict__ pds,
+                                                                   const int32_t* __restrict__ rows,
+                                                                   const double* __restrict__ L,
+                                                                   double* __restrict__ x, double* __restrict__ xscratch,
+                                                                   int nrhs, int ldx, int chain, int* __restrict__ info,
+                                                                   int* __restrict__ ticket, int wait_bias, int nblocks,
+                                                                   const int32_t* __restrict__ ranges,
+                                                                   const double* __restrict__ dinv) {
+    __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double invd[kTile];
+    __shared__ double ts[kTile * kLdXm];
+    __shared__ int s_task;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
+    __syncthreads();
+    const int plane = s_task / nblocks;
+    const int task = s_task - plane * nblocks;
+    const int q_begin = ranges ? ranges[2 * task] : task;
+    const int q_end = ranges ? ranges[2 * task + 1] : q_begin + 1;
+  for (int qsn = q_begin; qsn < q_end; ++qsn) {
+    if (qsn > q_begin) __syncthreads();
+    const PanelDesc pd = pds[qsn];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    const int kbeg = cb + wbk;
+    {   // diagonal block (identity padded) -> LDS; chain launch: its inverse instead (same layout)
+        double dtmp[kTile * kTile / kThreads];
+        const double* __restrict__ inv_blk = chain ? dinv + (int64_t)(D.dslot + pd.jb) * (kTile * kTile) : nullptr;
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            const int c = e >> 6, i = e & 63;
+            double v = (i == c) ? 1.0 : 0.0;
+            if (chain) v = inv_blk[e];
+            else if (c < wbk && i < wbk && i >= c) v = G[(int64_t)(cb + c) * r + cb + i];
+            dtmp[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+        }
+    }
+    __syncthreads();
+    if (!chain && tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
+    __syncthreads();
+    if (!chain && tid < kTile && (tid & ~15) < wbk) {   // inverses of the 16x16 diagonal sub-blocks (as k_bsolve_block)
+        const int b16 = tid & ~15, c = tid & 15;
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
+            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr)
+            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+    }
+    const int nbc = (w + kTile - 1) / kTile;
+    constexpr int kPassRhs = 16 * QG;
+    for (int pass = plane; pass * kPassRhs < nrhs; pass += kPassLanes) {
+        const int q0 = pass * kPassRhs;
+        const int nq = min(kPassRhs, nrhs - q0);
+        __syncthreads();
+        for (int e = tid; e < kTile * kPassRhs; e += kThreads) {
+            const int c = e & 63, q = e >> 6;
+            TSM(c, q) = (c < wbk && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] : 0.0;
+        }
+        double4_s acc[4][QG];   // [16 columns][16 right-hand sides]: lane (q = l15, c = kq + 4 v)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < QG; ++b) acc[a][b] = double4_s{0, 0, 0, 0};
+        // operand pointers of this lane: column c = 16 cg + l15 of the block (clamped), right-hand side 16 qg + l15
+        const double* __restrict__ acol[4];
+        const double* __restrict__ xcol[QG];
+        bool aok[4], bok[QG];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            aok[g] = 16 * g + l15 < wbk;
+            acol[g] = G + (int64_t)(cb + min(16 * g + l15, wbk - 1)) * r;
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            bok[g] = 16 * g + l15 < nq;
+            xcol[g] = x + (int64_t)(q0 + min(16 * g + l15, nq - 1)) * ldx;
+        }
+        // ---- the rows below (chain: below the supernode's own columns -- ancestors, final; otherwise everything
+        // below the block: the later blocks were solved by earlier launches): 64-row chunks over the waves, 16 rows
+        // (4 k steps) of loads in flight ahead of their 64 products
+        for (int k0 = (chain ? w : kbeg) + 64 * wave; k0 < r; k0 += 64 * (kThreads / 64)) {
+#pragma unroll 2
+            for (int s4 = 0; s4 < 4; ++s4) {
+                double av[4][4], bv[4][QG];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int k = k0 + 16 * s4 + 4 * st + kq;
+                    const bool kin = k < r;
+                    const int kc = min(k, r - 1);
+                    const int rid = (kc < w) ? (D.c0 + kc) : ri[kc];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double a = acol[g][kc];
+                        av[st][g] = (kin && aok[g]) ? a : 0.0;
+                    }
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        const double b = xcol[g][rid];
+                        bv[st][g] = (kin && bok[g]) ? b : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st][cg], bv[st][qg], acc[cg][qg], 0, 0, 0);
+            }
+        }
+        if (chain) {
+            // ---- the later blocks of this supernode, last one first, each as soon as its X is published: rows
+            // 64 I + 16 wave .. + 15 for this wave
+            bool ok = true;
+            for (int I = nbc - 1; I > pd.jb && ok; --I) {
+                double av[4][4], bv[4][QG];
+                int kk[4];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    kk[st] = I * kTile + 16 * wave + 4 * st + kq;
+                    const int kc = min(kk[st], w - 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double a = acol[g][kc];
+                        av[st][g] = (kk[st] < w && aok[g]) ? a : 0.0;
+                    }
+                }
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                for (;;) {
+                    bool in = true;
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) {
+                            long long b = 0;
+                            if (kk[st] < w && bok[g])
+                                b = __hip_atomic_load(reinterpret_cast<const long long*>(
+                                                          xscratch + (xcol[g] - x) + D.c0 + kk[st]),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            bv[st][g] = __longlong_as_double(b);
+                        }
+                    if (__all(in && wait_bias == 0)) break;
+                    if ((++spins & 15) == 0 &&
+                        (wall_clock64() - t0 > kSolveSpinTicks ||
+                         __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) {
+                    if (lane == 0) atomicMin(info, -1);
+                    break;   // (the result is wrong and reported; nobody may hang)
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st][cg], bv[st][qg], acc[cg][qg], 0, 0, 0);
+            }
+        }
+        // ---- T = Y - (the waves' parts, one wave after the other: a fixed order of sums; waves that had no rows --
+        // fewer than four 64-row chunks below the block and no chain -- are skipped)
+        const int nparts = chain ? kThreads / 64 : min(kThreads / 64, (r - kbeg + 63) / 64);
+        for (int wv = 0; wv < nparts; ++wv) {
+            __syncthreads();
+            if (wave == wv) {
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) TSM(16 * cg + kq + 4 * v, 16 * qg + l15) -= acc[cg][qg][v];
+            }
+        }
+        __syncthreads();
+        if (chain) {
+            // X_blk = inv(L_bb)' T on the matrix cores: X[c][q] = sum_k inv(L_bb)[k][c] T[k][q]; Dg[c][k] holds
+            // inv(L_bb)[k][c] (zero for k < c).  Wave = 16 columns; the result replaces T behind a barrier.
+            double4_s out[QG];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) out[qg] = double4_s{0, 0, 0, 0};
+            for (int st = 4 * wave; st < kTile / 4; ++st) {   // (k < 16 wave: the inverse is zero there)
+                const double a = Dg[(16 * wave + l15) * kLdDiag + 4 * st + kq];
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    out[qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, TSM(4 * st + kq, 16 * qg + l15), out[qg], 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) TSM(16 * wave + kq + 4 * v, 16 * qg + l15) = out[qg][v];
+            __syncthreads();
+        }
+        // otherwise: x_blk = inv(L_bb)' t, 16 columns at a time from the last sub-block up (as k_bsolve_block)
+        for (int b16 = chain ? -1 : ((wbk - 1) & ~15); b16 >= 0; b16 -= 16) {
+            const int i = tid & 15;
+            double zv[QG];
+#pragma unroll
+            for (int u = 0; u < QG; ++u) {
+                const int q = (tid >> 4) + 16 * u;
+                double z = 0.0;
+                if (q < nq) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        double lv = 0.0;  // inv(L_bb)'[i][k] = inv(L_bb)[k][i]
+                        if (k > i) lv = Dg[(b16 + k) * kLdDiag + b16 + i];
+                        else if (k == i) lv = invd[b16 + i];
+                        z = fma(lv, TSM(b16 + k, q), z);
+                    }
+                }
+                zv[u] = z;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < QG; ++u) {
+                const int q = (tid >> 4) + 16 * u;
+                if (q < nq) TSM(b16 + i, q) = zv[u];
+            }
+            __syncthreads();
+            // columns above the sub-block: t[a] -= sum_k L[b16+k][a] z[k]
+            for (int e = tid; e < b16 * nq; e += kThreads) {
+                const int qq = e / b16, a2 = e - qq * b16;
+                double accv = TSM(a2, qq);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) accv = fma(-Dg[a2 * kLdDiag + b16 + k], TSM(b16 + k, qq), accv);
+                TSM(a2, qq) = accv;
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < kTile * kPassRhs; e += kThreads) {
+            const int c = e & 63, q = e >> 6;
+            if (c < wbk && q < nq) {
+                x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = TSM(c, q);
+                if (chain)
+                    __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], TSM(c, q), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+  }
+}
+#undef TSM
+
 // Backward solve of supernodes of width <= 16: one WAVE per supernode, or per subtree of them from its root down
 // (ranges != null), no LDS and no barrier -- the counterpart of k_solve_tiny.  The rows below the diagonal block
 // are one row per lane (their x is final: ancestors), every lane keeps its part of t_c = sum_k L[k][c] x_k for
@@ -1571,6 +1857,124 @@ __global__ __launch_bounds__(64) void k_bsolve_tiny(const SnDesc* __restrict__ s
                 }
             }
             if (lane < w) xq[D.c0 + lane] = xfin;
+        }
+    }
+}
+
+// Backward solve of supernodes of width <= 16, many right-hand sides: one WAVE per supernode (or per subtree of
+// them from its root down), 64 right-hand sides per pass, products on the matrix cores.  T = Y - L21' X(below) as in
+// k_bsolve_block_mrhs (panel rows = contraction index; 4 tiles of 16 columns x 16 right-hand sides); the result
+// layout of v_mfma_f64_16x16x4_f64 (lane (q, c = kq + 4 v)) is the B-operand layout of k step v, so
+// X_blk = inv(L_bb)' T is four more products per tile with T straight from the accumulators -- inv(L_bb) by
+// substitution, one column per lane, through 4 KB of LDS.
+__global__ __launch_bounds__(64, 4) void k_bsolve_tiny_mrhs(const SnDesc* __restrict__ sn, const PanelDesc* __restrict__ pds,
+                                                         const int32_t* __restrict__ ranges,
+                                                         const int32_t* __restrict__ rows, const double* __restrict__ L,
+                                                         double* __restrict__ x, int nrhs, int ldx) {
+    constexpr int W = kTinyWidth, kLd = W + 1;
+    __shared__ double Db[W * kLd];    // diagonal block, column-major: Db[c * kLd + i] = L[i][c]
+    __shared__ double Iv[W * kLd];    // its inverse:                  Iv[c * kLd + i] = inv(L_bb)[i][c]
+    const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
+    const int q_begin = ranges ? ranges[2 * blockIdx.x] : (int)blockIdx.x;
+    const int q_end = ranges ? ranges[2 * blockIdx.x + 1] : q_begin + 1;
+    for (int qsn = q_begin; qsn < q_end; ++qsn) {
+        // (subtree launch: the x this wave stored for the supernode before -- an ancestor -- is read back below)
+        if (qsn > q_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const SnDesc D = sn[pds[qsn].sn];
+        const int r = D.r, w = D.w;
+        const double* __restrict__ G = L + D.px;
+        const int32_t* __restrict__ ri = rows + D.pi;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < W * W / 64; ++t) {
+            const int e = t * 64 + lane, c = e >> 4, i = e & 15;
+            double v = (i == c) ? 1.0 : 0.0;
+            if (c < w && i < w && i >= c) v = G[(int64_t)c * r + i];
+            Db[c * kLd + i] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < W) {   // column `lane` of inv(L_bb): y_c = 1 / d_c, y_rr = -(sum_{k < rr} L[rr][k] y_k) / d_rr
+            // (y lives in LDS, one row of the block per step: a register array indexed by the step would go to scratch)
+            const int c = lane;
+            double* __restrict__ y = &Iv[c * kLd];
+#pragma unroll
+            for (int k = 0; k < W; ++k) y[k] = (k == c) ? 1.0 / Db[k * kLd + k] : 0.0;
+#pragma unroll 1
+            for (int rr = 1; rr < W; ++rr) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < W - 1; k += 2) {
+                    const double l0 = Db[k * kLd + rr], l1 = Db[(k + 1) * kLd + rr];   // (zero above the diagonal: k > rr)
+                    s0 = fma(k < rr ? l0 : 0.0, y[k], s0);
+                    s1 = fma(k + 1 < rr ? l1 : 0.0, y[k + 1], s1);
+                }
+                if (rr > c) y[rr] = -(s0 + s1) / Db[rr * kLd + rr];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // A operands of the diagonal product: lane (c_out = l15, k = 4 st + kq) <- inv(L_bb)[k][c_out]
+        double ainv[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) ainv[st] = Iv[l15 * kLd + 4 * st + kq];
+        const bool aok = l15 < w;
+        const double* __restrict__ acol = G + (int64_t)min(l15, w - 1) * r;
+        for (int q0 = 64 * (int)blockIdx.y; q0 < nrhs; q0 += 64 * (int)gridDim.y) {
+            const int nq = min(64, nrhs - q0), nqg = (nq + 15) >> 4;
+            double4_s acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = double4_s{0, 0, 0, 0};
+            const double* __restrict__ xcol[4];
+            bool bok[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bok[g] = 16 * g + l15 < nq;
+                xcol[g] = x + (int64_t)(q0 + min(16 * g + l15, nq - 1)) * ldx;
+            }
+            constexpr int kSt = 2;   // k steps (4 rows each) whose loads are in flight together
+#pragma unroll 1
+            for (int k0 = w; k0 < r; k0 += 4 * kSt) {
+                double av[kSt], bv[kSt][4];
+#pragma unroll
+                for (int st = 0; st < kSt; ++st) {
+                    const int k = k0 + 4 * st + kq;
+                    const bool kin = k < r;
+                    const int kc = min(k, r - 1);
+                    const int rid = ri[kc];
+                    const double a = acol[kc];
+                    av[st] = (kin && aok) ? a : 0.0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        double b = 0.0;
+                        if (g < nqg) b = xcol[g][rid];
+                        bv[st][g] = (kin && bok[g]) ? b : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < kSt; ++st)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (g < nqg) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st][g], acc[g], 0, 0, 0);
+            }
+            // T = Y - acc in the accumulator layout (lane (q = l15, c = kq + 4 v)), then X_blk = inv(L_bb)' T
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g >= nqg) continue;
+                double4_s t;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = kq + 4 * v;
+                    const double y = xcol[g][D.c0 + min(c, w - 1)];
+                    t[v] = (c < w && bok[g]) ? y - acc[g][v] : 0.0;
+                }
+                double4_s out = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) out = __builtin_amdgcn_mfma_f64_16x16x4f64(ainv[st], t[st], out, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = kq + 4 * v;
+                    if (c < w && bok[g]) x[(int64_t)(q0 + 16 * g + l15) * ldx + D.c0 + c] = out[v];
+                }
+            }
         }
     }
 }
@@ -1794,7 +2198,12 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
     const int chain = mode == 1;
     const PanelDesc* pds = mode == 2 ? P.bsolve_blocks : P.bsolve_blocks + first;
     const int32_t* ranges = mode == 2 ? P.bsolve_ranges + 2 * first : nullptr;
-    if (tiny) {   // width class kTinyWidth (1) or kTinyWidth2 (2), a subtree launch or a level's launch: one wave each
+    if (tiny == 1 && nrhs >= mrhs_min()) {   // many right-hand sides: 64 per pass, matrix cores, one wave per supernode
+        const dim3 grid(count, std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM));
+        hipLaunchKernelGGL(k_bsolve_tiny_mrhs, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs, ldx);
+        return;
+    }
+    if (tiny && nrhs < mrhs_min()) {   // width class kTinyWidth (1) or kTinyWidth2 (2), a subtree launch or a level's launch: one wave each
         const dim3 grid(count, std::min(kPassLanes, nrhs));
         if (tiny == 1)
             hipLaunchKernelGGL(k_bsolve_tiny<kTinyWidth>, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs,
@@ -1802,6 +2211,21 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
         else
             hipLaunchKernelGGL(k_bsolve_tiny<kTinyWidth2>, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs,
                                ldx);
+        return;
+    }
+    if (nrhs >= mrhs_min()) {   // 64 right-hand sides per pass over L, products on the matrix cores
+        // launches of few blocks (the top of the tree, small inputs) take 16 right-hand sides per pass in up to 8
+        // workgroups per block side by side; the others 64 per pass (L read once per 64)
+        const bool wide = count >= kMrhsWideBlocks;
+        const int per = wide ? kRhsM : 16;
+        const int mlanes = std::min(kPassLanes, (nrhs + per - 1) / per);
+        const dim3 mgrid = chain ? dim3(count * mlanes) : dim3(count, mlanes);
+        if (wide)
+            hipLaunchKernelGGL(k_bsolve_block_mrhs<4>, mgrid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
+                               nrhs, ldx, chain, P.sinfo, P.stickets + ticket, wait_bias, count, ranges, dinv);
+        else
+            hipLaunchKernelGGL(k_bsolve_block_mrhs<1>, mgrid, dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch,
+                               nrhs, ldx, chain, P.sinfo, P.stickets + ticket, wait_bias, count, ranges, dinv);
         return;
     }
     const int lanes = nrhs == 1 ? 1 : std::min(kPassLanes, (nrhs + 3) / 4);

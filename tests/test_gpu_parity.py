@@ -527,13 +527,32 @@ def test_unfused_fallback_paths(api, oracle, monkeypatch):
 # backward solve and the end-to-end solve A x = b
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
-@pytest.mark.parametrize("nrhs", [1, 5])
+@pytest.mark.parametrize("nrhs", [1, 5, 16, 19, 64, 70])
 def test_backward_solve_matches_checker(api, oracle, name, nrhs):
+    """One, a few (4 per pass) and many right-hand sides (from 16 on: 64 per pass over L, products on the matrix
+    cores -- k_bsolve_block_mrhs): every column against the checker's transposed solve."""
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(9)
     Y = rng.standard_normal((sym.n, nrhs))
     X, _ = plan.solve2(lo, Y, forward=False)
     for q in range(nrhs):
+        xo = oracle.blocked_ltsolve(sym, lo, Y[:, q])
+        assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+
+
+@pytest.mark.parametrize("name,nrhs", [("lap30", 64), ("mid3d", 19), ("nd24k", 70)])
+def test_backward_solve_many_rhs_without_the_chain(api, oracle, monkeypatch, name, nrhs):
+    """The per-block-column form (PARSY_FORCE_UNFUSED: what runs where a chain launch is not wanted) of the many-
+    right-hand-side backward kernel: later blocks are read from x, the diagonal solve is the blocked substitution."""
+    monkeypatch.setenv("PARSY_FORCE_UNFUSED", "1")
+    A, perm, sym = problem(name)
+    plan = api.Plan(sym, 0)
+    lo, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    rng = np.random.default_rng(10)
+    Y = rng.standard_normal((sym.n, nrhs))
+    X, _ = plan.solve2(lo, Y, forward=False)
+    for q in (0, 1, nrhs // 2, nrhs - 1):
         xo = oracle.blocked_ltsolve(sym, lo, Y[:, q])
         assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
 
