@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="flan")
+    ap.add_argument("--mtx", default=None, help="a MatrixMarket file (e.g. the real Flan_1565.mtx) instead of the "
+                    "synthetic stand-in: lower triangle taken, ordered by --order FILE or by parsy_order_nd")
+    ap.add_argument("--order", default=None, help="ordering file for --mtx (dimension, then n entries)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -338,7 +341,15 @@ def main():
 
     # ---- the headline workload -----------------------------------------------------------
     t0 = time.perf_counter()
-    A, perm = M.workload(args.workload)
+    if args.mtx:
+        # a real SuiteSparse file when it is present on the box: own reader, own ordering (the
+        # reference orders with METIS, absent here) -- no extras and no committed PMC summary apply to it
+        A = M.read_mtx(args.mtx)
+        perm = M.read_ordering(args.order, A.n) if args.order else I.order_nd(A)
+        args.workload = Path(args.mtx).stem
+        args.no_extras = True
+    else:
+        A, perm = M.workload(args.workload)
     sym = I.analyze(A, perm)
     t_inspect = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -472,10 +483,12 @@ def main():
         "scaling": "strong",   # N > 1 shards ONE factorization (total work fixed); N = 1 is its base point
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if not args.mtx else "file",
         "config": {
             "workload": (f"{args.workload}-class stand-in (BASELINE.json configs[2] when flan: Flan_1565): grid "
-                         f"{grid[:3]} {grid[3]}-point stencil, geometric nested dissection" if grid else args.workload),
+                         f"{grid[:3]} {grid[3]}-point stencil, geometric nested dissection" if grid else
+                         (f"{args.mtx} (MatrixMarket file), ordering: " + (args.order or "parsy_order_nd (graph nested "
+                          "dissection)") if args.mtx else args.workload)),
             "n": sym.n, "nnz_A_lower": int(sym.nnzA), "nsuper": sym.nsuper, "nnz_L": int(sym.nnzL),
             "xsize": int(sym.xsize), "flops_F": sym.flops_colcount, "flops_executed": sym.flops_stored,
             "etree_levels": sym.nlevels, "cholesky_view": {k: info[k] for k in (

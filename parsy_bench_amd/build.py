@@ -104,7 +104,7 @@ def build_drivers(hipcc=None, run=None, force: bool = False):
     outs = []
     for name in ("choleskyTest", "choleskyTest03", "triangularTest"):
         src, out = DRIVERS / f"{name}.cpp", DRIVERS / f"{name}.bin"
-        if force or _stale(out, [src, DRIVERS / "mtx_io.hpp", LIB, PKG.parent / "include" / "parsy_amd.h"]):
+        if force or _stale(out, [src, DRIVERS / "mtx_io.hpp", DRIVERS / "verify.hpp", LIB, PKG.parent / "include" / "parsy_amd.h"]):
             run([hipcc, "-x", "c++", "-O2", "-std=c++17", str(src), "-x", "none", "-o", str(out), str(LIB),
                  f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/.."])
         outs.append(out)

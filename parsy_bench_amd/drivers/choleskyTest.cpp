@@ -11,6 +11,14 @@
 // The H-level arrays handed to the executor are the etree level sets with one
 // supernode per w-partition; numThread / chunk / costParam / levelParam / blasThreads /
 // finalSeqNode are accepted and echoed (the GPU executor schedules by etree level).
+//
+// Environment (the reference has no slot for either):
+//   PARSY_VERIFY=1       check the factor after the timed iterations (drivers/verify.hpp: the reference's VERIFY build
+//                        compares with CHOLMOD, examples/choleskyTest01.cpp:459-546); verdict on stderr, exit code -2 on
+//                        failure
+//   PARSY_DEVICES=0,1,.. one factorization over several devices (one rank per entry; parsy_mg_*, include/parsy_amd.h
+//                        section 5): subtrees below a cut on one device each, the pieces of the separators above it
+//                        dealt over all devices
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +28,7 @@
 
 #include "../../include/parsy_amd.h"
 #include "mtx_io.hpp"
+#include "verify.hpp"
 
 int main(int argc, char* argv[]) {
     if (argc < 8) {
@@ -72,7 +81,33 @@ int main(int argc, char* argv[]) {
     struct CholTime { double alltogether, parallel, rootNodes; };
     std::vector<CholTime> timeArray;
     const int iterNo = 5;
-    for (int k = 0; k < iterNo; ++k) {
+    const std::vector<int> devices = parsy_io::device_list();
+    if (!devices.empty()) {
+        // several devices: the distributed factorization (every rank keeps its lValues on its device; the factor is
+        // collected once, after the timed iterations)
+        parsy_mg* mg = parsy_mg_create(sym, (int)devices.size(), devices.data(), 1);
+        if (!mg || parsy_mg_set_values(mg, v.A2x) != 0) {
+            std::cerr << "[choleskyTest] multi-device setup failed: " << parsy_last_error() << "\n";
+            return -1;
+        }
+        for (int k = 0; k < iterNo; ++k) {
+            double sec = 0;
+            const int st = parsy_mg_factor(mg, &sec);
+            if (st != 0) {
+                std::cerr << "[choleskyTest] " << parsy_last_error() << "\n";
+                return -1;
+            }
+            timeArray.push_back({sec, sec, 0.0});
+        }
+        std::vector<double> rank_ms(devices.size());
+        parsy_mg_rank_ms(mg, rank_ms.data());
+        std::cerr << "[choleskyTest] " << devices.size() << " ranks, device ms of the last iteration:";
+        for (double ms : rank_ms) std::cerr << " " << ms;
+        std::cerr << "\n";
+        if (parsy_mg_gather_host(mg, valL.data()) != 0) return -1;
+        parsy_mg_destroy(mg);
+    }
+    for (int k = 0; k < iterNo && devices.empty(); ++k) {
         std::fill(valL.begin(), valL.end(), 0.0);
         std::fill(timingChol.begin(), timingChol.end(), 0.0);
         auto s = std::chrono::system_clock::now();
@@ -93,7 +128,11 @@ int main(int argc, char* argv[]) {
     std::cout << "\n";
     std::cerr << "[choleskyTest] n=" << n << " nsuper=" << v.nsuper << " nnz(L)=" << v.nnzL << " F=" << v.flops_colcount
               << " device_s(iter3)=" << timingChol[2] << "\n";
+    int rc = 0;
+    if (parsy_io::verify_requested() &&
+        !parsy_io::verify_and_report("choleskyTest", sym, v, valL.data(), devices.empty() ? 0 : devices[0]))
+        rc = -2;
     parsy_dropin_reset();
     parsy_symbolic_free(sym);
-    return 0;
+    return rc;
 }

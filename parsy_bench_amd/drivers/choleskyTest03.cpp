@@ -21,6 +21,7 @@
 
 #include "../../include/parsy_amd.h"
 #include "mtx_io.hpp"
+#include "verify.hpp"
 
 int main(int argc, char* argv[]) {
     if (argc < 8) {
@@ -90,7 +91,9 @@ int main(int argc, char* argv[]) {
     std::cout << "\n";
     std::cerr << "[choleskyTest03] n=" << n << " nsuper=" << v.nsuper << " levels=" << nLevels << " nnz(L)=" << v.nnzL
               << " F=" << v.flops_colcount << " device_s(last)=" << timingChol[2] << "\n";
+    int rc = 0;   // PARSY_VERIFY=1: check the factor (drivers/verify.hpp; verdict on stderr, exit code -2 on failure)
+    if (parsy_io::verify_requested() && !parsy_io::verify_and_report("choleskyTest03", sym, v, valL.data(), 0)) rc = -2;
     parsy_dropin_reset();
     parsy_symbolic_free(sym);
-    return 0;
+    return rc;
 }

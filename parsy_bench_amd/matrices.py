@@ -38,6 +38,40 @@ class LowerCSC:
         return (Lo + sp.tril(Lo, -1).T).tocsc()
 
 
+def read_mtx(path: str) -> LowerCSC:
+    """A MatrixMarket file as the reference reads it (common/Util.h:77-179: coordinate real, lower triangle,
+    column-sorted; README.md:31).  Accepts general / symmetric files with either triangle or both: the lower triangle
+    is taken and sorted (what examples/MakingLowerHalf.cpp prepares for the reference)."""
+    import scipy.io
+    import scipy.sparse as sp
+    M_ = scipy.io.mmread(path)
+    if M_.shape[0] != M_.shape[1]:
+        raise ValueError(f"{path}: not a square matrix")
+    M_ = sp.coo_matrix(M_)
+    lo = M_.row >= M_.col
+    up = M_.row < M_.col
+    if up.any() and not lo.sum() > M_.shape[0]:   # an upper-triangular file: mirror it
+        M_ = sp.coo_matrix((M_.data, (M_.col, M_.row)), shape=M_.shape)
+        lo = M_.row >= M_.col
+    L_ = sp.csc_matrix((M_.data[lo], (M_.row[lo], M_.col[lo])), shape=M_.shape)
+    L_.sum_duplicates()
+    L_.sort_indices()
+    return LowerCSC(int(L_.shape[0]), L_.indptr.astype(np.int32), L_.indices.astype(np.int32),
+                    L_.data.astype(np.float64))
+
+
+def read_ordering(path: str, n: int) -> np.ndarray:
+    """An ordering file as the reference's readOrdering takes it (common/Util.h:199-221): the dimension, then n
+    permutation entries (new -> old, 0-based)."""
+    vals = np.loadtxt(path, dtype=np.int64, comments="%").ravel()
+    if len(vals) != n + 1 or vals[0] != n:
+        raise ValueError(f"{path}: expected the dimension {n} followed by {n} entries")
+    perm = vals[1:].astype(np.int32)
+    if not np.array_equal(np.sort(perm), np.arange(n)):
+        raise ValueError(f"{path}: not a permutation of 0..{n - 1}")
+    return perm
+
+
 def grid_spd(nx: int, ny: int, nz: int = 1, stencil: int = 5, shift: float = 0.1) -> LowerCSC:
     lib = N.lib()
     n = nx * ny * nz

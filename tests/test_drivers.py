@@ -46,6 +46,41 @@ def test_choleskyTest_csv(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exe", ["choleskyTest.bin", "choleskyTest03.bin"])
+def test_drivers_verify_the_factor_they_time(tmp_path, exe):
+    """PARSY_VERIFY=1: after the timed iterations the factor is checked through the system it solves (the reference's
+    VERIFY build compares with CHOLMOD, examples/choleskyTest01.cpp:459-546): verdict on stderr, CSV unchanged."""
+    import os
+    mtx, order = _inputs(tmp_path, "mid3d")
+    env = dict(os.environ, PARSY_VERIFY="1")
+    r = subprocess.run([str(DRV / exe), mtx, "4", "1", "4", "0", "1", "2", order], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stderr.splitlines() if "verify:" in l]
+    assert len(line) == 1 and line[0].endswith(": ok")
+    err = float(line[0].split(" is ")[1].split()[0])
+    assert 0 <= err <= 1e-9
+    assert r.stdout.strip().split(",")[0] == mtx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_choleskyTest_over_several_ranks(tmp_path, devices):
+    """PARSY_DEVICES: one factorization over several ranks (here all on device 0) through parsy_mg -- same CSV, the
+    factor collected from the ranks passes the same check."""
+    import os
+    mtx, order = _inputs(tmp_path, "lap30")
+    env = dict(os.environ, PARSY_VERIFY="1", PARSY_DEVICES=devices, PARSY_PIECE_WIDTH="128", PARSY_BIG_MINK="32")
+    r = subprocess.run([str(DRV / "choleskyTest.bin"), mtx, "4", "1", "4", "0", "1", "2", order], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert f"{len(devices.split(','))} ranks" in r.stderr
+    assert any(l.endswith(": ok") for l in r.stderr.splitlines() if "verify:" in l)
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == mtx and float(fields[7]) > 0 and fields[12] == ""
+
+
+@pytest.mark.gpu
 def test_choleskyTest03_csv(tmp_path):
     """The wavefront driver (examples/choleskyTest03.cpp): nrelax = {4,16,0}, getLevelSet schedule,
     cholesky_left_par_waveFront, sorted median; CSV = file, 6 echoed arguments, total, symbolic, ordering."""
@@ -119,3 +154,32 @@ def test_makingLowerHalf_converts_a_full_unsorted_file(tmp_path):
     low.write_text(r.stdout)
     text = low.read_text()
     assert text.startswith("%%MatrixMarket matrix coordinate real symmetric\n3 3 5\n")
+
+
+def test_matrixmarket_input_of_the_bench(tmp_path):
+    """bench.py --mtx / --order: the reader takes the reference's input files (lower triangle, column-sorted
+    MatrixMarket; ordering file = dimension, then n entries: common/Util.h:77-221) and also an unsorted / upper /
+    full symmetric file, of which it keeps the sorted lower triangle."""
+    import numpy as np
+    from parsy_bench_amd import matrices as M
+    mtx, order = _inputs(tmp_path, "tiny2d")
+    A = M.read_mtx(mtx)
+    A0, p0 = M.workload("tiny2d")
+    assert A.n == A0.n and np.array_equal(A.Ap, A0.Ap) and np.array_equal(A.Ai, A0.Ai) and np.allclose(A.Ax, A0.Ax)
+    assert np.array_equal(M.read_ordering(order, A.n), p0)
+    # the same matrix written as its upper triangle, entries shuffled
+    rng = np.random.default_rng(3)
+    rows = np.repeat(np.arange(A0.n), np.diff(A0.Ap))   # column of each entry
+    ent = rng.permutation(A0.nnz)
+    up = tmp_path / "upper.mtx"
+    with open(up, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write(f"{A0.n} {A0.n} {A0.nnz}\n")
+        for k in ent:
+            f.write(f"{rows[k] + 1} {A0.Ai[k] + 1} {A0.Ax[k]:.17g}\n")   # (row, col) swapped: upper triangle
+    B = M.read_mtx(str(up))
+    assert np.array_equal(B.Ap, A0.Ap) and np.array_equal(B.Ai, A0.Ai) and np.allclose(B.Ax, A0.Ax)
+    bad = tmp_path / "bad.ord"
+    bad.write_text(f"{A0.n}\n" + "\n".join(["0"] * A0.n) + "\n")
+    with pytest.raises(ValueError):
+        M.read_ordering(str(bad), A0.n)
