@@ -340,21 +340,23 @@ long long parsy_plan_check(const parsy_plan* pl) {
     return bad;
 }
 
+// The two masks are independent: the supernode mask restricts the solves (and, while no piece mask is set, the
+// factorization: a piece follows its supernode); the piece mask restricts the factorization alone.
 int parsy_plan_set_active(parsy_plan* pl, const uint8_t* mask) {
     if (!pl) return -1;
-    parsy::build_launches(pl->S, mask);
+    std::vector<uint8_t> pieces;
+    if (pl->piece_mask_set) pieces = pl->S.active_piece;
+    parsy::build_launches(pl->S, mask, pl->piece_mask_set ? pieces.data() : nullptr);
+    pl->sn_mask_set = mask != nullptr;
     return parsy::plan_upload_launches(pl);
 }
 
 int parsy_plan_set_active_pieces(parsy_plan* pl, const uint8_t* piece_mask) {
     if (!pl) return -1;
-    std::vector<uint8_t> sn_mask;   // the solves keep the supernode mask they had
-    const uint8_t* keep = nullptr;
-    if (!pl->S.active.empty()) {
-        sn_mask = pl->S.active;
-        keep = sn_mask.data();
-    }
-    parsy::build_launches(pl->S, keep, piece_mask);
+    std::vector<uint8_t> sn_mask;
+    if (pl->sn_mask_set) sn_mask = pl->S.active;
+    parsy::build_launches(pl->S, pl->sn_mask_set ? sn_mask.data() : nullptr, piece_mask);
+    pl->piece_mask_set = piece_mask != nullptr;
     return parsy::plan_upload_launches(pl);
 }
 

@@ -1442,6 +1442,9 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         if (nfr == 0) return;
         const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
         const double* __restrict__ Cb = &S.C[b][32 * wc + l15];
+#ifdef PARSY_BIG_PRIO   // (experiment: the multiplying waves win the issue arbitration over staging / epilogue waves)
+        __builtin_amdgcn_s_setprio(PARSY_BIG_PRIO);
+#endif
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
             double rv[4], cv[2];
@@ -1466,6 +1469,9 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             }
 #endif
         }
+#ifdef PARSY_BIG_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
     // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C), 8 loads of a lane at a time

@@ -16,6 +16,7 @@ struct parsy_plan {
     std::mutex use_mu;        // the drop-in operators hold it across a call: flags, tickets, status and the
                               // host-convenience buffers of a cached plan belong to one call at a time
     bool solve_only = false;  // built from L's pattern alone (no A, no update lists)
+    bool sn_mask_set = false, piece_mask_set = false;  // parsy_plan_set_active / _set_active_pieces are in force
 
     // pattern arrays (uploaded once) and launch arrays (re-uploaded by set_active)
     std::vector<void*> owned;        // every hipMalloc'd block, for destroy()
