@@ -40,13 +40,25 @@ int pick_device() {
 }
 
 // ---- plan cache of the drop-in operators -------------------------------------
+// Pattern hash of the drop-in plan cache: 8 bytes per step in four independent lanes (the Flan-class pattern is
+// hundreds of MB per call; a byte-at-a-time FNV was a measurable part of the call), folded FNV-style.
 uint64_t fnv(uint64_t h, const void* p, size_t bytes) {
     const unsigned char* c = (const unsigned char*)p;
-    for (size_t i = 0; i < bytes; ++i) {
+    uint64_t lane[4] = {h, h ^ 0x9E3779B97F4A7C15ULL, h ^ 0xC2B2AE3D27D4EB4FULL, h ^ 0x165667B19E3779F9ULL};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32)
+        for (int k = 0; k < 4; ++k) {
+            uint64_t w;
+            std::memcpy(&w, c + i + 8 * k, 8);
+            lane[k] = (lane[k] ^ w) * 1099511628211ULL;
+            lane[k] ^= lane[k] >> 29;
+        }
+    for (int k = 0; k < 4; ++k) h = (h ^ lane[k]) * 1099511628211ULL;
+    for (; i < bytes; ++i) {
         h ^= c[i];
         h *= 1099511628211ULL;
     }
-    return h;
+    return h ^ (uint64_t)bytes;
 }
 
 struct CacheKey {

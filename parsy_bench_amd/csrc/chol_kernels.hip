@@ -1442,9 +1442,9 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         if (nfr == 0) return;
         const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
         const double* __restrict__ Cb = &S.C[b][32 * wc + l15];
-#ifdef PARSY_BIG_PRIO   // (experiment: the multiplying waves win the issue arbitration over staging / epilogue waves)
-        __builtin_amdgcn_s_setprio(PARSY_BIG_PRIO);
-#endif
+        // the multiplying waves win the issue arbitration over the waves that stage or write back (-1.7 % of the BIG
+        // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
             double rv[4], cv[2];
@@ -1469,9 +1469,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             }
 #endif
         }
-#ifdef PARSY_BIG_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
     // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C), 8 loads of a lane at a time

@@ -813,6 +813,12 @@ __global__ __launch_bounds__(kThreads) void k_solve_chain(const SnDesc* __restri
 // Rows below the supernode's own columns are scattered at the end with atomics, as in the other kernels.
 static constexpr unsigned kXArmedWord = 0xFFF7A5A5u;   // both 32-bit halves of the armed pattern
 static constexpr long long kXArmed = (long long)(((unsigned long long)kXArmedWord << 32) | kXArmedWord);
+// A published value must differ from the armed pattern.  Arithmetic cannot produce it (operations on NaNs return quiet
+// NaNs), only an input can carry it: it is published as a quiet NaN instead, so that the hand-off completes and the
+// NaN propagates like any other (without this such a right-hand side ran into the 2 s timeout and status -1).
+__device__ __forceinline__ double unarmed(double v) {
+    return __double_as_longlong(v) == kXArmed ? __longlong_as_double(0x7FF8000000000000LL) : v;
+}
 static constexpr int kInvPacked = kTile * (kTile + 1) / 2;   // packed lower triangle of an inverse diagonal block
 static constexpr int kChainThreads = 2 * kSolveRows;         // eight waves
 static constexpr int kChainFewChunks = 384;                  // launches of at most this many chunks: top of the tree
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_solve_chain_w(const SnDesc
             if (lane == 0) __hip_atomic_store(&s_ready[rb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             // ... to everybody else through the armed buffer, and into x
             if (lane < wbk) {
-                __hip_atomic_store(&xscratch[D.c0 + row0 + lane], xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xscratch[D.c0 + row0 + lane], unarmed(xi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x[D.c0 + row0 + lane] = xi;
             }
             // a last diagonal block narrower than 64: the other rows of the block lie below the supernode's columns
@@ -1483,7 +1489,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
             const int q = e / wbk, c = e - q * wbk;
             x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = ts[c][q];
             if (chain)
-                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], ts[c][q], __ATOMIC_RELAXED,
+                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], unarmed(ts[c][q]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
         // (chain launch: nothing else to do -- the values stored in the armed buffer are the publication)
@@ -1767,7 +1773,7 @@ __global__ __launch_bounds__(kThreads, QG == 4 ? 1 : 2) void k_bsolve_block_mrhs
             if (c < wbk && q < nq) {
                 x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = TSM(c, q);
                 if (chain)
-                    __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], TSM(c, q), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], unarmed(TSM(c, q)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -2177,7 +2183,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
         if (lane == 0) __hip_atomic_store(&s_ready[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (lane < wbk) {
-        __hip_atomic_store(&xscratch[D.c0 + cb + lane], xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&xscratch[D.c0 + cb + lane], unarmed(xi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x[D.c0 + cb + lane] = xi;
     }
 }

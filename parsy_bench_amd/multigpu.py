@@ -161,3 +161,116 @@ def gather_factor(L, pieces, owner, rank: int, dist_mod, root: int = 0, stage_on
     for view, buf in landing:
         view.copy_(buf)
     return moved
+
+
+class PlanSolver:
+    """The solves of one rank on its device: a plan restricted (supernode mask) to the rank's subtrees, and -- on the
+    root rank -- one restricted to the supernodes above the cut."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def set_mask(self, mask):
+        self.plan.set_active(mask)
+
+    def forward(self, L, X, nrhs, n, stream):
+        self.plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, n, stream)
+
+    def backward(self, L, X, nrhs, n, stream):
+        self.plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, n, stream)
+
+
+class ShardedSolve:
+    """Forward / backward solves on the distributed factor: every rank solves the subtrees it owns --
+    a supernode of a subtree only writes rows of its ancestors (forward) and only reads them (backward) --, the
+    supernodes above the cut are solved by the root rank, and what crosses the cut is one vector: the forward solve
+    REDUCES the partial x (every rank's updates of the rows above the cut; its own subtree columns solved) onto the
+    root rank, the backward solve BROADCASTS the root rank's x of those rows.  The panels above the cut are collected
+    on the root rank once per factorization (`gather_root_part`); the subtree panels stay where they were factored.
+
+    sub_solver / root_solver: objects with set_mask(mask) / forward(L, X, nrhs, n, stream) / backward(...) --
+    PlanSolver on a GPU; the CPU tests plug in the oracle.  X is n x nrhs column-major (1-D tensor), replicated on
+    entry (every rank passes the same right-hand side); the result is complete on the root rank."""
+
+    def __init__(self, sym, pieces, dist_info, rank: int, dist_mod, sub_solver, root_solver=None, root: int = 0,
+                 stage_on_host: bool = False):
+        import torch
+        self.n, self.rank, self.root, self.dist = sym.n, rank, root, dist_mod
+        self.stage_on_host = stage_on_host
+        self.pieces, self.D = pieces, dist_info
+        first = np.concatenate([[True], np.diff(pieces["supernode"]) != 0])
+        sn_owner, sn_below = dist_info.owner[first], dist_info.in_subtree[first]
+        self.sub_mask = ((sn_below == 1) & (sn_owner == rank)).astype(np.uint8)
+        self.root_mask = (sn_below == 0).astype(np.uint8)
+        w = np.diff(sym.super)
+        mine = np.repeat(self.sub_mask.astype(bool), w)
+        above = np.repeat(self.root_mask.astype(bool), w)
+        self.keep = torch.from_numpy(mine | (above if rank == root else np.zeros_like(above)))   # columns whose b / x this rank carries
+        self.sub, self.rootsolver = sub_solver, root_solver
+        self.sub.set_mask(self.sub_mask)
+        if rank == root:
+            if root_solver is None:
+                raise ValueError("the root rank needs a solver for the supernodes above the cut")
+            root_solver.set_mask(self.root_mask)
+
+    def gather_root_part(self, L):
+        """The pieces above the cut that other ranks factored -> the root rank (runs of consecutive pieces)."""
+        vb, ve = self.pieces["value_begin"], self.pieces["value_end"]
+        owner, below = self.D.owner, self.D.in_subtree
+        ops, landing, moved, p, n = [], [], 0, 0, len(owner)
+        while p < n:
+            q = p
+            while q + 1 < n and owner[q + 1] == owner[p] and below[q + 1] == below[p]:
+                q += 1
+            a, b, own = int(vb[p]), int(ve[q]), int(owner[p])
+            if below[p] == 0 and own != self.root and b > a:
+                moved += b - a
+                view = L[a:b]
+                if self.rank == self.root:
+                    buf = view.cpu() if self.stage_on_host else view
+                    if self.stage_on_host:
+                        landing.append((view, buf))
+                    ops.append(self.dist.P2POp(self.dist.irecv, buf, own))
+                elif self.rank == own:
+                    ops.append(self.dist.P2POp(self.dist.isend, view.cpu() if self.stage_on_host else view, self.root))
+            p = q + 1
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, buf in landing:
+            view.copy_(buf)
+        return moved
+
+    def _masked(self, X, nrhs):
+        keep = self.keep.to(X.device)
+        return (X.view(nrhs, self.n) * keep).view(-1)
+
+    def _collect(self, X, op_reduce=True):
+        if self.stage_on_host and X.is_cuda:
+            h = X.cpu()
+            self.dist.reduce(h, self.root) if op_reduce else self.dist.broadcast(h, self.root)
+            X.copy_(h)
+        elif op_reduce:
+            self.dist.reduce(X, self.root)
+        else:
+            self.dist.broadcast(X, self.root)
+
+    def forward(self, L, B, nrhs: int = 1, stream: int = 0):
+        """L x = b.  Returns X: complete on the root rank."""
+        X = self._masked(B, nrhs).contiguous()
+        self.sub.forward(L, X, nrhs, self.n, stream)      # own subtrees: solved columns + updates of ancestor rows
+        self._collect(X, op_reduce=True)                   # sum over ranks = x after every subtree, on the root
+        if self.rank == self.root:
+            self.rootsolver.forward(L, X, nrhs, self.n, stream)
+        return X
+
+    def backward(self, L, Y, nrhs: int = 1, stream: int = 0):
+        """L' x = y.  Returns X: complete on the root rank."""
+        X = Y.clone()
+        if self.rank == self.root:
+            self.rootsolver.backward(L, X, nrhs, self.n, stream)   # above the cut first: it reads nothing below
+        self._collect(X, op_reduce=False)                           # everybody gets the rows above the cut
+        self.sub.backward(L, X, nrhs, self.n, stream)
+        X = self._masked(X, nrhs).contiguous()                      # own subtree columns (+ above the cut on the root)
+        self._collect(X, op_reduce=True)
+        return X

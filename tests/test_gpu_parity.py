@@ -646,6 +646,36 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
     api.dropin_reset()
 
 
+@pytest.mark.parametrize("nrhs", [1, 5, 64])
+def test_right_hand_side_with_the_armed_nan_pattern_does_not_stall(api, oracle, nrhs):
+    """The chain launches of the solves hand x over as the data itself (a hand-off buffer armed with a signalling-NaN
+    pattern: a value is valid once it differs).  A right-hand side that happens to carry that very pattern must not
+    turn into a 2 s timeout: what is published is the result of arithmetic (a quiet NaN), and a value equal to the
+    pattern would be published as a quiet NaN -- the solve completes, status 0, the NaN propagates to the rows that
+    depend on it and nowhere else."""
+    import time
+    A, perm, sym = problem("lap30")
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0 and sym.maxSupWid > 64     # (wide supernodes: the chain launches run)
+    armed = np.frombuffer(np.array([0xFFF7A5A5FFF7A5A5], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((sym.n, nrhs))
+    poisoned = int(sym.super[sym.nsuper - 1]) + 3          # a column of the root supernode
+    B[poisoned, 0] = armed
+    t0 = time.perf_counter()
+    X, _ = plan.solve(lv, B if nrhs > 1 else B[:, 0])
+    Xb, _ = plan.solve2(lv, B, forward=False)
+    assert time.perf_counter() - t0 < 1.5 and plan.solve_status() == 0
+    X = X.reshape(sym.n, -1)
+    assert np.isnan(X[poisoned, 0]) and np.isnan(Xb[poisoned, 0])
+    assert not np.isnan(X[:poisoned, :]).any()             # forward: only rows after the poisoned one can see it
+    if nrhs > 1:
+        assert not np.isnan(X[:, 1:]).any() and not np.isnan(Xb[:, 1:]).any()
+        xo = oracle.blocked_lsolve(sym, lv, B[:, 1], "serial")
+        assert np.abs(X[:, 1] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+
+
 # ---------------------------------------------------------------------------
 # device helpers of the C ABI
 # ---------------------------------------------------------------------------

@@ -116,3 +116,108 @@ def test_distributed_factorization_matches_single_process(tmp_path, oracle, monk
         assert len(set(D.owner[above].tolist())) >= 2, "the pieces above the cut all went to one rank"
     if min_subtrees or world >= 4:
         assert nroot >= 2, "this case is meant to have the part above the cut factored by more than one rank"
+
+
+# ---------------------------------------------------------------------------
+# sharded solves on the distributed factor (multigpu.ShardedSolve): subtree solves on their owners, one reduce /
+# broadcast of x at the cut, the supernodes above the cut on the root rank
+# ---------------------------------------------------------------------------
+def _solve_rank_main(rank, world, port, name, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, perm = M.workload(name)
+    sym = I.analyze(A, perm)
+    plan = api.Plan(sym, -1)
+    pieces = plan.pieces()
+    D = api.Dist(plan, world)
+    ok, lv, _ = O.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok
+    # every rank keeps only what the distributed factorization leaves it: its own pieces (the rest is poisoned)
+    L = torch.full((int(sym.xsize),), float("nan"), dtype=torch.float64)
+    for p in np.where(D.owner == rank)[0]:
+        a, b = int(pieces["value_begin"][p]), int(pieces["value_end"][p])
+        L[a:b] = torch.from_numpy(lv[a:b])
+    w = np.diff(sym.super)
+    r = np.diff(sym.i_ptr[sym.super].astype(np.int64))
+
+    class OracleSolver:
+        """The checker's solves restricted to a set of supernodes (the reference's leveled forward solve takes any
+        level set, Triangular_BCSC.h:115-164; the backward one is written out here for the small test inputs)."""
+
+        def set_mask(self, mask):
+            self.mask = np.asarray(mask, dtype=bool)
+
+        def forward(self, Lt, X, nrhs, n, stream):
+            lev = np.zeros(sym.nsuper, dtype=np.int64)
+            for l in range(sym.nlevels):
+                lev[sym.levelSet[sym.levelPtr[l]: sym.levelPtr[l + 1]]] = l
+            sel = np.where(self.mask)[0]
+            order = sel[np.argsort(lev[sel], kind="stable")].astype(np.int32)
+            levelPtr = np.zeros(sym.nlevels + 1, dtype=np.int32)
+            np.cumsum(np.bincount(lev[sel], minlength=sym.nlevels), out=levelPtr[1:])
+            a = [np.ascontiguousarray(sym.p, dtype=np.uint64), np.ascontiguousarray(sym.s, dtype=np.int32),
+                 Lt.numpy(), np.ascontiguousarray(sym.i_ptr, dtype=np.uint64),
+                 np.ascontiguousarray(sym.col2Sup, dtype=np.int32), np.ascontiguousarray(sym.super, dtype=np.int32)]
+            Xn = X.numpy()
+            for q in range(nrhs):
+                xq = Xn[q * n: (q + 1) * n]
+                O.lib().oracle_set_threads(1)
+                rc = O.lib().oracle_leveledBlockedLsolve(n, O.P(a[0]), O.P(a[1]), O.P(a[2]), int(sym.xsize), O.P(a[3]),
+                                                         O.P(a[4]), O.P(a[5]), sym.nsuper, O.P(xq), sym.nlevels,
+                                                         O.P(levelPtr), O.P(order), 1)
+                assert rc == 1
+
+        def backward(self, Lt, X, nrhs, n, stream):
+            Ln, Xn = Lt.numpy(), X.numpy()
+            for s in np.where(self.mask)[0][::-1]:
+                c0, ws, rs = int(sym.super[s]), int(w[s]), int(r[s])
+                panel = Ln[int(sym.p[c0]): int(sym.p[c0]) + ws * rs].reshape(ws, rs).T      # rows x columns
+                rows = sym.s[int(sym.i_ptr[c0]): int(sym.i_ptr[c0]) + rs]
+                for q in range(nrhs):
+                    xq = Xn[q * n: (q + 1) * n]
+                    t = xq[c0: c0 + ws] - panel[ws:, :].T @ xq[rows[ws:]]
+                    xq[c0: c0 + ws] = np.linalg.solve(np.tril(panel[:ws, :]).T, t)
+
+    SS = MG.ShardedSolve(sym, pieces, D, rank, dist, OracleSolver(), OracleSolver() if rank == 0 else None)
+    moved = SS.gather_root_part(L)
+    rng = np.random.default_rng(17)            # (same seed on every rank: the right-hand side is replicated)
+    nrhs = 3
+    B = torch.from_numpy(rng.standard_normal(sym.n * nrhs))
+    Xf = SS.forward(L, B, nrhs)
+    Xb = SS.backward(L, B, nrhs)
+    if rank == 0:
+        np.save(Path(out_dir) / "B.npy", B.numpy())
+        np.save(Path(out_dir) / "Xf.npy", Xf.numpy())
+        np.save(Path(out_dir) / "Xb.npy", Xb.numpy())
+        np.save(Path(out_dir) / "moved.npy", np.array([moved, int(SS.root_mask.sum()), int(SS.sub_mask.sum())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("mid3d", 2), ("lap30", 4)])
+def test_sharded_solves_match_the_serial_solves(tmp_path, oracle, name, world):
+    import torch.multiprocessing as mp
+    from conftest import problem
+    from parsy_bench_amd import inspector as I
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_solve_rank_main, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    A, perm, sym = problem(name)
+    ok, lv, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    B = np.load(tmp_path / "B.npy").reshape(3, sym.n)
+    Xf = np.load(tmp_path / "Xf.npy").reshape(3, sym.n)
+    Xb = np.load(tmp_path / "Xb.npy").reshape(3, sym.n)
+    moved, nroot, nsub0 = np.load(tmp_path / "moved.npy")
+    assert nroot >= 1 and nsub0 >= 1
+    for q in range(3):
+        xo = oracle.blocked_lsolve(sym, lv, B[q], "serial")
+        assert np.abs(Xf[q] - xo).max() <= 1e-11 * max(1.0, np.abs(xo).max())
+        xb = oracle.blocked_ltsolve(sym, lv, B[q])
+        assert np.abs(Xb[q] - xb).max() <= 1e-11 * max(1.0, np.abs(xb).max())

@@ -1,0 +1,90 @@
+"""The one-process-per-GPU path on the GPU box: two (three) ranks share the one device, torch.distributed with
+gloo and host-staged messages in place of RCCL (one device cannot host several RCCL ranks) -- everything else is what
+`bench.py --gpus N` runs: the library's distribution, plans restricted to the ranks' pieces, level-by-level
+factorization with the fan-out messages in between (multigpu.DistributedFactorization), then the sharded solves
+(multigpu.ShardedSolve).  Checked on rank 0 against a single plan: factor bitwise, solves to rounding."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _rank_main(rank, world, port, name, env, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env)
+    import torch
+    import torch.distributed as dist
+    from parsy_bench_amd import api, inspector as I, matrices as M, multigpu as MG
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    A, perm = M.workload(name)
+    sym = I.analyze(A, perm)
+    plan = api.Plan(sym, 0)
+    pieces = plan.pieces()
+    D = api.Dist(plan, world)
+    assert D.check(plan) == 0
+    plan.set_active_pieces(D.mask(rank))
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
+    DF = MG.DistributedFactorization(D, rank, dist, dev, stage_on_host=True)
+    engine = MG.PlanEngine(plan, values.data_ptr())
+    for _ in range(2):
+        DF.factor(engine, L, stream)
+    torch.cuda.synchronize()
+    assert plan.status() == 0
+    own = L.cpu().numpy().copy()
+    # sharded solves on the distributed factor
+    sub_plan = api.Plan(sym, 0)
+    root_plan = api.Plan(sym, 0) if rank == 0 else None
+    SS = MG.ShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(sub_plan),
+                         MG.PlanSolver(root_plan) if rank == 0 else None, stage_on_host=True)
+    SS.gather_root_part(L)
+    rng = np.random.default_rng(23)
+    nrhs = 3
+    Bh = rng.standard_normal(sym.n * nrhs)
+    B = torch.from_numpy(Bh).to(dev)
+    Xf = SS.forward(L, B, nrhs, stream)
+    Xb = SS.backward(L, B, nrhs, stream)
+    torch.cuda.synchronize()
+    assert sub_plan.solve_status() == 0
+    # rank 0 collects the factor and checks everything against a single plan
+    np.save(Path(out_dir) / f"own_{rank}.npy", own)
+    dist.barrier()
+    if rank == 0:
+        full = api.Plan(sym, 0)
+        ref, _ = full.factor(sym.A2x)
+        for p in range(len(D.owner)):
+            a, b = int(pieces["value_begin"][p]), int(pieces["value_end"][p])
+            o = np.load(Path(out_dir) / f"own_{D.owner[p]}.npy", mmap_mode="r")
+            assert np.array_equal(o[a:b], ref[a:b]), f"piece {p} differs from the single-plan factor"
+        xf, _ = full.solve(ref, Bh.reshape(nrhs, sym.n).T)
+        xb, _ = full.solve2(ref, Bh.reshape(nrhs, sym.n).T, forward=False)
+        gf = Xf.cpu().numpy().reshape(nrhs, sym.n).T
+        gb = Xb.cpu().numpy().reshape(nrhs, sym.n).T
+        assert np.abs(gf - xf).max() <= 1e-10 * max(1.0, np.abs(xf).max())
+        assert np.abs(gb - xb).max() <= 1e-10 * max(1.0, np.abs(xb).max())
+        np.save(Path(out_dir) / "ok.npy", np.array([D.info["n_messages"], D.info["n_root_pieces"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,env", [
+    ("mid3d", 2, {}),
+    ("lap30", 3, {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "32"}),
+])
+def test_ranks_sharing_the_device_factor_and_solve(tmp_path, name, world, env):
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(world, port, name, env, str(tmp_path)), nprocs=world, join=True)
+    nmsg, nroot = np.load(tmp_path / "ok.npy")
+    assert nmsg > 0 and nroot >= 1
