@@ -424,21 +424,49 @@ def main():
                              "streams; not the headline value (that is one factorization after the other)"}
         del plans2[1:], Ls2[1:]
 
-    # after the timed factorizations the factor is distributed (subtree panels on their owners, root part on
-    # rank 0): collect the rest on rank 0 for the single-GPU solves below (not timed: not part of a factorization)
-    if world > 1:
-        MG.gather_factor(L, pieces, D.owner, rank, dist, stage_on_host=(backend != "nccl"))
-    # ---- forward / backward solves (rank 0 holds the whole factor) -------------------------
+    # ---- forward / backward solves -------------------------------------------------------------
     dt_s = dt_b = solve_err = back_err = None
     nrhs = args.nrhs
     solve_plan = None
     BX = None
-    if rank == 0 and not args.no_solve:
-        solve_plan = plan
-        if world > 1:
-            solve_plan = api.Plan(sym, local_rank)  # all supernodes active
-        dt_s, dt_b, solve_err, BX, back_err = measure_solves(solve_plan, sym, L, nrhs, args.warmup, args.steps)
-    if world > 1:
+    sharded = None
+    if world == 1:
+        if not args.no_solve:
+            solve_plan = plan
+            dt_s, dt_b, solve_err, BX, back_err = measure_solves(solve_plan, sym, L, nrhs, args.warmup, args.steps)
+    elif not args.no_solve:
+        # the factor is distributed (every piece final on its owner): the solves run sharded -- every rank its own
+        # subtrees, ONE reduce (forward) / broadcast (backward) of x at the cut, the supernodes above the cut on rank 0
+        # after their panels were collected there once (untimed: once per factorization, not per solve)
+        root_plan = api.Plan(sym, local_rank) if rank == 0 else None
+        SS = MG.ShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(plan), MG.PlanSolver(root_plan) if rank == 0 else None,
+                             stage_on_host=(backend != "nccl"))
+        moved = SS.gather_root_part(L)
+        import scipy.sparse as sp
+        A2 = sp.csc_matrix((sym.A2x, sym.A2i, sym.A2p), shape=(sym.n, sym.n))
+        ones = np.ones(sym.n)
+        c = A2 @ ones + A2.T @ ones - A2.diagonal()
+        C = torch.from_numpy(c).to(dev).repeat(nrhs).contiguous()
+        holder = {}
+
+        def fwd():
+            holder["y"] = SS.forward(L, C, nrhs, stream)
+
+        def bwd():
+            holder["x"] = SS.backward(L, holder["y"], nrhs, stream)
+
+        dt_s = timed(fwd, args.warmup, args.steps)
+        dt_b = timed(bwd, args.warmup, args.steps)
+        if plan.solve_status() != 0 or (root_plan is not None and root_plan.solve_status() != 0):
+            raise SystemExit("sharded solve: a hand-off wait timed out")
+        if rank == 0:
+            back_err = float((holder["x"] - 1.0).abs().max().item())
+            if not (back_err <= BACK_TOL):
+                raise SystemExit(f"sharded solves are off: max|x - 1| = {back_err:.3e} for L L' x = (P A P') 1")
+            sharded = {"root_part_elements_collected_once": int(moved),
+                       "supernodes_above_the_cut": int(SS.root_mask.sum()),
+                       "note": "forward: subtree solves on their owners, one reduce of x, root part on rank 0; backward: "
+                               "root part on rank 0, one broadcast of x, subtree solves, one reduce to collect x"}
         dist.barrier()
 
     # ---- per-kernel timing (hipEvents on the launch stream, launches serialised) for the roofline ----
@@ -507,6 +535,7 @@ def main():
         "backward_solve_ms": (dt_b / args.steps * 1e3) if dt_b else None,
         "forward_backward_max_abs_err_vs_ones": back_err,
         "throughput_in_flight": pipelined,
+        "sharded_solves": sharded,
         "inspect_seconds": t_inspect, "plan_seconds": t_plan,
     }
 
