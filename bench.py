@@ -42,6 +42,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, datasheet (the microarch gu
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 SOLVE_TOL = 1e-9               # max|x - 1| of the solve of L x = L 1 (reference testTriangular: 1e-3)
 BACK_TOL = 1e-9                # max|x - 1| of forward + backward solve of L L' x = (P A P') 1
+PMC_ROUND = "r03"              # profiles/<round>_<workload>_pmc_traffic.json: the committed counter summary that is quoted
 
 
 def log(*a):
@@ -567,10 +568,10 @@ def main():
         # committed summary is quoted -- only while the kernel sources are the ones it was measured on
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(ROOT / "profiles" / f"r02_{args.workload}_pmc_traffic.json"))
+            pmc = json.load(open(ROOT / "profiles" / f"{PMC_ROUND}_{args.workload}_pmc_traffic.json"))
             if pmc.get("kernel_source_hash") == kernel_source_hash() and key in pmc.get("kernels", {}):
                 traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-                traffic_src = (f"profiles/r02_{args.workload}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                traffic_src = (f"profiles/{PMC_ROUND}_{args.workload}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                f"separate passes, calibrated; same kernel sources)")
             elif key in pmc.get("kernels", {}):
                 traffic_src = "profiles summary is from other kernel sources: not quoted"
@@ -596,7 +597,7 @@ def main():
             sruns = ps["runs"]
             solve_traffic = None
             try:
-                pmc = json.load(open(ROOT / "profiles" / f"r02_{args.workload}_pmc_traffic.json"))
+                pmc = json.load(open(ROOT / "profiles" / f"{PMC_ROUND}_{args.workload}_pmc_traffic.json"))
                 if pmc.get("kernel_source_hash") == kernel_source_hash() and nrhs == 1:
                     ks = pmc["kernels"]
                     # the profiled program runs as many forward (and backward) solves as factorizations; the inverse
