@@ -1471,11 +1471,16 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the
-    // operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C), 8 loads of a lane at a time
+    // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the operands
+    // swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C) through the relative indices, as no-return FP64
+    // atomic adds of the negated product (performed at the memory side: fire and forget -- the read-modify-write
+    // this replaces was five dependent round trips per source; 369 -> 363 ms of BIG launches on the Flan-class
+    // input, the factor unchanged bit for bit: old + (-p) rounds as old - p, the tile belongs to this workgroup
+    // alone within the launch, one lane's adds into one address are performed in program order, and the caller
+    // drains them before the next barrier, so that the order of sums per entry of L stays the list order)
     auto epilogue = [&](const WaveEntry& E, int nfr, int nfc) {
         if (nfr == 0) return;
-#ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no read-modify-write of the tile)
+#ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no update of the tile)
 #pragma unroll
         for (int fc = 0; fc < 2; ++fc)
 #pragma unroll
@@ -1487,7 +1492,9 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
 #endif
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const bool ident = (E.mn >> 16) != 0;
-        int prow[4];
+        // (all twelve index loads in flight together; loading them before the source's last chunk is multiplied, so
+        // that they land behind it, cost more in registers than it hid: 373 vs 365 ms)
+        int prow[4], pcol[2][4];
 #pragma unroll
         for (int fr = 0; fr < 4; ++fr) {
             const int i = 64 * wr + 16 * fr + l15;
@@ -1495,34 +1502,23 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             if (i < mi) prow[fr] = ident ? E.ia + i : relpos[(int64_t)E.rel + E.ia + i] - D.rbias;
         }
 #pragma unroll
+        for (int fc = 0; fc < 2; ++fc)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int j = 32 * wc + 16 * fc + kq + 4 * v;
+                pcol[fc][v] = -1;
+                if (fc < nfc && j < nj) pcol[fc][v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
+            }
+#pragma unroll
         for (int fc = 0; fc < 2; ++fc) {
             if (fc < nfc) {
-                int pcol[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int j = 32 * wc + 16 * fc + kq + 4 * v;
-                    pcol[v] = -1;
-                    if (j < nj) pcol[v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
-                }
+                for (int fr = 0; fr < 4; ++fr)
 #pragma unroll
-                for (int fh = 0; fh < 4; fh += 2) {
-                    double old[2][4];
-#pragma unroll
-                    for (int fr = fh; fr < fh + 2; ++fr)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
-                            old[fr - fh][v] = ok ? G[(int64_t)pcol[v] * ld + prow[fr]] : 0.0;
-                        }
-#pragma unroll
-                    for (int fr = fh; fr < fh + 2; ++fr)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const bool ok = prow[fr] >= 0 && pcol[v] >= 0 && prow[fr] >= pcol[v];
-                            if (ok) G[(int64_t)pcol[v] * ld + prow[fr]] = old[fr - fh][v] - acc[fc][fr][v];
-                        }
-                    asm volatile("" ::: "memory");  // 8 loads of a lane in flight (registers)
-                }
+                    for (int v = 0; v < 4; ++v) {
+                        const bool ok = prow[fr] >= 0 && pcol[fc][v] >= 0 && prow[fr] >= pcol[fc][v];
+                        if (ok) unsafeAtomicAdd(&G[(int64_t)pcol[fc][v] * ld + prow[fr]], -acc[fc][fr][v]);
+                    }
             }
 #pragma unroll
             for (int fr = 0; fr < 4; ++fr) acc[fc][fr] = double4_t{0, 0, 0, 0};
@@ -1547,6 +1543,10 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         ck += kBK;
         if (ck >= CE.K) {
             epilogue(CE, nfr, nfc);
+            // the adds of this source are performed before the barrier: the next source's adds into the same entries
+            // of L may come from other waves (another row map), and the order of sums must not depend on timing
+            // (after the task's last source the end of the kernel does it)
+            if (ce + 1 < e_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ck = 0;
             ++ce;
             if (ce < e_end) {

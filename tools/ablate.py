@@ -25,4 +25,6 @@ for _ in range(3):
     torch.cuda.synchronize()
     plan.profile_collect()
 p = plan.profile_get()
-print(variant, {k: round(v / p["runs"], 3) for k, v in p["ms"].items() if v > 0})
+# (bitwise checksum of the factor: variants that must not change a bit are compared through it)
+chk = int(L.view(torch.int64).sum().item())
+print(variant, {k: round(v / p["runs"], 3) for k, v in p["ms"].items() if v > 0}, "status", plan.status(), "checksum", chk)
