@@ -1445,18 +1445,26 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         // the multiplying waves win the issue arbitration over the waves that stage or write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
         __builtin_amdgcn_s_setprio(1);
+        // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
+        // BIG launches on the Flan-class input)
+        double rv[2][4], cv[2][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rv[0][f] = Rb[kq * kBLd + 16 * f];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) cv[0][f] = Cb[kq * kBLd + 16 * f];
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
-            double rv[4], cv[2];
+            if (ks + 1 < kBK / 4) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) rv[f] = Rb[(4 * ks + kq) * kBLd + 16 * f];
+                for (int f = 0; f < 4; ++f) rv[(ks + 1) & 1][f] = Rb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) cv[f] = Cb[(4 * ks + kq) * kBLd + 16 * f];
+                for (int f = 0; f < 2; ++f) cv[(ks + 1) & 1][f] = Cb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
+            }
 #ifdef PARSY_BIGABL_NOMFMA    // (diagnostic build: operands are read from LDS and dropped)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[f]));
+            for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
 #pragma unroll
-            for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(cv[f]));
+            for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
 #else
 #pragma unroll
             for (int fc = 0; fc < 2; ++fc) {
@@ -1464,7 +1472,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
 #pragma unroll
                     for (int fr = 0; fr < 4; ++fr)
                         if (fr < nfr)
-                            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 0);
+                            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[ks & 1][fc], rv[ks & 1][fr], acc[fc][fr], 0, 0, 0);
                 }
             }
 #endif
