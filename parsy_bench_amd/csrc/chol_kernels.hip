@@ -1319,15 +1319,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
 static constexpr int kBK = PARSY_BK;           // k extent of a staged chunk
 static constexpr int kBLd = kBigTile + 16;     // k stride of a staged chunk in LDS: lanes 16..31 (k + 1) of an
                                                // operand read hit the other half of the banks
-static constexpr int kBigThreads = 512;        // 8 waves: 2 (rows) x 4 (columns), 64 x 32 outputs each; two
-                                               // workgroups per CU = 4 waves per SIMD, so that the epilogue and
-                                               // the start of one task hide behind the multiplies of the others
+#ifndef PARSY_BIG_WC
+#define PARSY_BIG_WC 4
+#endif
+static constexpr int kBigWC = PARSY_BIG_WC;    // waves along the tile's columns: 4 (8 waves: 2 x 4, 64 x 32 outputs each;
+                                               // two workgroups per CU = 4 waves per SIMD, so that the start of one task
+                                               // hides behind the multiplies of the others) or 2 (4 waves of 64 x 64)
+static constexpr int kBigWCols = kBigTile / kBigWC;   // columns of a wave's block (32 / 64)
+static constexpr int kBigNfc = kBigWCols / 16;        // 16-column fragments of it (2 / 4)
+static constexpr int kBigThreads = 64 * 2 * kBigWC;
 struct BigLds {
     double R[2][kBK * kBLd];
     double C[2][kBK * kBLd];
 };
 
-__global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __restrict__ sn,
+__global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* __restrict__ sn,
                                                              const int32_t* __restrict__ relpos,
                                                              const WaveEntry* __restrict__ ents,
                                                              const TileDesc* __restrict__ tasks,
@@ -1335,7 +1341,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
     __shared__ BigLds S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave / kBigWC, wc = wave % kBigWC, l15 = lane & 15, kq = lane >> 4;
     const TileDesc td = tasks[blockIdx.x];
     const SnDesc D = sn[td.sn];
     double* __restrict__ G = L + D.px;
@@ -1347,7 +1353,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
     // ---- loader: thread (row = tid & 127, k = (tid >> 7) + 4 q) of both staged blocks
     constexpr int kLq = kBK * kBigTile / kBigThreads;  // values per thread, block and chunk (4)
     constexpr int kLs = kBigThreads / kBigTile;        // k stride between them (4)
-    const int lrow = tid & (kBigTile - 1), lkh = tid >> 7;
+    const int lrow = tid & (kBigTile - 1), lkh = tid / kBigTile;
     int64_t le = e_begin;
     int lk = 0;                       // k position inside entry le
     WaveEntry LE = ents[le];
@@ -1421,17 +1427,17 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
     int64_t ce = e_begin;
     int ck = 0;
     WaveEntry CE = LE;
-    double4_t acc[2][4];  // [16-row fragment of the column window][... of the row window]
+    double4_t acc[kBigNfc][4];  // [16-row fragment of the column window][... of the row window]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < kBigNfc; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
 
     auto frags = [&](const WaveEntry& E, int& nfr, int& nfc) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         nfr = min(4, max(0, (mi - 64 * wr + 15) >> 4));
-        nfc = min(2, max(0, (nj - 32 * wc + 15) >> 4));
-        if (diag && 64 * wr + 63 < 32 * wc) nfr = 0;  // block strictly above the diagonal of a diagonal tile
+        nfc = min(kBigNfc, max(0, (nj - kBigWCols * wc + 15) >> 4));
+        if (diag && 64 * wr + 63 < kBigWCols * wc) nfr = 0;  // block strictly above the diagonal of a diagonal tile
         if (nfr == 0 || nfc == 0) nfr = nfc = 0;
     };
     // A wave whose block of the tile has no rows of this source skips the chunk; a ragged block skips the
@@ -1441,33 +1447,33 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
     auto compute = [&](int b, int nfr, int nfc) {
         if (nfr == 0) return;
         const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
-        const double* __restrict__ Cb = &S.C[b][32 * wc + l15];
+        const double* __restrict__ Cb = &S.C[b][kBigWCols * wc + l15];
         // the multiplying waves win the issue arbitration over the waves that stage or write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
         __builtin_amdgcn_s_setprio(1);
         // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
         // BIG launches on the Flan-class input)
-        double rv[2][4], cv[2][2];
+        double rv[2][4], cv[2][kBigNfc];
 #pragma unroll
         for (int f = 0; f < 4; ++f) rv[0][f] = Rb[kq * kBLd + 16 * f];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) cv[0][f] = Cb[kq * kBLd + 16 * f];
+        for (int f = 0; f < kBigNfc; ++f) cv[0][f] = Cb[kq * kBLd + 16 * f];
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
             if (ks + 1 < kBK / 4) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) rv[(ks + 1) & 1][f] = Rb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) cv[(ks + 1) & 1][f] = Cb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
+                for (int f = 0; f < kBigNfc; ++f) cv[(ks + 1) & 1][f] = Cb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
             }
 #ifdef PARSY_BIGABL_NOMFMA    // (diagnostic build: operands are read from LDS and dropped)
 #pragma unroll
             for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
 #pragma unroll
-            for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
+            for (int f = 0; f < kBigNfc; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
 #else
 #pragma unroll
-            for (int fc = 0; fc < 2; ++fc) {
+            for (int fc = 0; fc < kBigNfc; ++fc) {
                 if (fc < nfc) {
 #pragma unroll
                     for (int fr = 0; fr < 4; ++fr)
@@ -1490,7 +1496,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         if (nfr == 0) return;
 #ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no update of the tile)
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc)
+        for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
             for (int fr = 0; fr < 4; ++fr) {
                 asm volatile("" ::"v"(acc[fc][fr]));
@@ -1502,7 +1508,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
         const bool ident = (E.mn >> 16) != 0;
         // (all twelve index loads in flight together; loading them before the source's last chunk is multiplied, so
         // that they land behind it, cost more in registers than it hid: 373 vs 365 ms)
-        int prow[4], pcol[2][4];
+        int prow[4], pcol[kBigNfc][4];
 #pragma unroll
         for (int fr = 0; fr < 4; ++fr) {
             const int i = 64 * wr + 16 * fr + l15;
@@ -1510,15 +1516,15 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_chol_big(const SnDesc* __res
             if (i < mi) prow[fr] = ident ? E.ia + i : relpos[(int64_t)E.rel + E.ia + i] - D.rbias;
         }
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc)
+        for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int j = 32 * wc + 16 * fc + kq + 4 * v;
+                const int j = kBigWCols * wc + 16 * fc + kq + 4 * v;
                 pcol[fc][v] = -1;
                 if (fc < nfc && j < nj) pcol[fc][v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
             }
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc) {
+        for (int fc = 0; fc < kBigNfc; ++fc) {
             if (fc < nfc) {
 #pragma unroll
                 for (int fr = 0; fr < 4; ++fr)
