@@ -371,7 +371,7 @@ def main():
     if world > 1:
         # the library's distribution (parsy_dist): subtrees below a cut on one rank each, the pieces above it dealt
         # over the ranks; after every level the finished pieces travel to the ranks that read them (RCCL point to point)
-        D = api.Dist(plan, world, int(os.environ.get("PARSY_DIST_BLOCK", "1")))
+        D = api.Dist(plan, world, int(os.environ.get("PARSY_DIST_BLOCK", "0")))   # 0: the library's default (2)
         if D.check(plan) != 0:
             raise SystemExit("the distribution is inconsistent: " + str(D.check(plan)))
         pieces = plan.pieces()

@@ -227,8 +227,8 @@ typedef struct parsy_dist_info {
     double max_rank_cost;             /* the most loaded rank */
     double lockstep_cost;             /* sum over levels of the most loaded rank of that level */
 } parsy_dist_info;
-/* block: consecutive pieces of one split supernode that stay on one rank (<= 0: default 1). The plan may be a
- * host-only one (device < 0). */
+/* block: consecutive pieces of one split supernode that stay on one rank (<= 0: the default, 2). The plan may be
+ * a host-only one (device < 0). */
 parsy_dist* parsy_dist_create(const parsy_plan* plan, int nranks, int block);
 void parsy_dist_destroy(parsy_dist* dist);
 int parsy_dist_get_info(const parsy_dist* dist, parsy_dist_info* info);

@@ -296,7 +296,7 @@ class Plan:
 class Dist:
     """Ownership of the pieces and the messages that follow every level (parsy_dist; host logic)."""
 
-    def __init__(self, plan: "Plan", nranks: int, block: int = 1, _borrowed=None):
+    def __init__(self, plan: "Plan", nranks: int, block: int = 0, _borrowed=None):
         self._own = _borrowed is None
         self._h = _borrowed or N.lib().parsy_dist_create(plan._h, nranks, block)
         if not self._h:
@@ -352,7 +352,7 @@ class MultiDevice:
     """One process driving several devices (parsy_mg): `devices` lists one HIP device per rank and may
     repeat a device (several ranks share it)."""
 
-    def __init__(self, sym, devices, block: int = 1):
+    def __init__(self, sym, devices, block: int = 0):
         if not getattr(sym, "_handle", None):
             raise RuntimeError("MultiDevice needs an inspector result (parsy_symbolic)")
         dv = np.ascontiguousarray(devices, dtype=np.int32)

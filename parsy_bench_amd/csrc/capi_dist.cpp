@@ -23,7 +23,7 @@ parsy_dist* parsy_dist_create(const parsy_plan* plan, int nranks, int block) {
     }
     parsy_dist* d = new parsy_dist;
     try {
-        parsy::build_dist(parsy::plan_schedule(plan), nranks, block <= 0 ? 1 : block, d->D);
+        parsy::build_dist(parsy::plan_schedule(plan), nranks, block <= 0 ? parsy::kDistBlock : block, d->D);
     } catch (const std::exception& e) {
         set_last_error(std::string("parsy_dist_create: ") + e.what());
         delete d;

@@ -20,6 +20,11 @@
 
 namespace parsy {
 
+// Default `block`: two consecutive pieces of a split supernode per rank -- every other hand-off on the chain of the top
+// separator's pieces stays on one device (model on measured launch times, Flan-class, N = 8: 85 ms against 111 ms
+// with block 1 at the same balance; tools/mg_model.py, profiles/r03_mg_model_flan*.txt).
+constexpr int kDistBlock = 2;
+
 struct DistMessage {               // what rank `src` sends to rank `dst` after level `level`
     int32_t level = 0, src = 0, dst = 0;
     std::vector<int64_t> off;      // segments of lValues (offset, length): rows [first needed, end) of one

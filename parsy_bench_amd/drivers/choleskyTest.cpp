@@ -85,7 +85,7 @@ int main(int argc, char* argv[]) {
     if (!devices.empty()) {
         // several devices: the distributed factorization (every rank keeps its lValues on its device; the factor is
         // collected once, after the timed iterations)
-        parsy_mg* mg = parsy_mg_create(sym, (int)devices.size(), devices.data(), 1);
+        parsy_mg* mg = parsy_mg_create(sym, (int)devices.size(), devices.data(), /*block: default*/ 0);
         if (!mg || parsy_mg_set_values(mg, v.A2x) != 0) {
             std::cerr << "[choleskyTest] multi-device setup failed: " << parsy_last_error() << "\n";
             return -1;

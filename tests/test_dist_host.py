@@ -82,7 +82,7 @@ def test_one_rank_owns_everything_and_sends_nothing():
 
 def test_flan_class_distribution_balances_the_ranks():
     """BASELINE configs[4]: the Flan-class pattern over 2 / 4 / 8 ranks.  Host only (the schedule of the 1.56 M-column
-    pattern takes a second): no rank carries more than 1.05 x its share, and the top separators -- more than half of
+    pattern takes a second): no rank carries more than 1.08 x its share, and the top separators -- more than half of
     the flops -- are spread over all ranks."""
     from parsy_bench_amd import inspector as I, matrices as M
     A, perm = M.workload("flan")
@@ -93,7 +93,7 @@ def test_flan_class_distribution_balances_the_ranks():
         D = api.Dist(plan, nranks)
         assert D.check(plan) == 0, N.last_error()
         share = D.rank_cost / D.rank_cost.sum()
-        assert share.max() <= 1.05 / nranks
+        assert share.max() <= 1.08 / nranks
         above = D.in_subtree == 0
         assert D.info["root_cost"] / D.info["total_cost"] > 0.3
         assert len(set(D.owner[above].tolist())) == nranks

@@ -350,7 +350,7 @@ def test_distributed_flan_class_factorization_on_one_device(api):
     mg = api.MultiDevice(sym, [0] * 8)
     try:
         D = mg.dist
-        assert D.rank_cost.max() / D.rank_cost.sum() <= 1.05 / 8
+        assert D.rank_cost.max() / D.rank_cost.sum() <= 1.08 / 8
         mg.set_values(sym.A2x)
         st, _ = mg.factor()
         assert st == 0

@@ -3,9 +3,10 @@ parsy_mg_profile lets the ranks take turns, so that every launch of every rank r
 and the factor is compared bitwise with the single-device one.  From those times:
   busy[r]     = all launches of rank r + the copies it receives (on one device: device-to-device)
   bound_busy  = T(1 rank, same method) / max_r busy[r]              -- compute-only speed-up bound
-  path        = sum over levels of the slowest rank's MAIN-stream launches of that level (the chain of the level's
-                pieces: a level cannot start before the level below is complete on its owner and has arrived)
-                + per level the largest message / LINK_GBS           -- critical-path estimate
+  path        = the longest chain through the ranks' MAIN-stream launches: a rank starts level l + 1 when it has
+                finished level l and every message of level l addressed to it has arrived (sender's end of level l +
+                bytes / LINK_GBS: each pair of GPUs has its own link, a sender's messages of one level travel side
+                by side)                                                -- critical-path estimate
   est         = max(max_r busy[r], path)
 Usage: python tools/mg_model.py WORKLOAD N[,N...] [block] ["K=V,K=V"]"""
 import os
@@ -41,17 +42,24 @@ for nr in [1] + [n for n in ranks if n > 1]:
     if nr == 1:
         t1 = float(busy[0])
     nl = main.shape[1]
-    link_ms = np.zeros(nl)
+    start = np.zeros(nr)          # when each rank can start the level at hand
+    link_sum = 0.0
     for lev in range(nl):
+        end = start + main[:, lev]
+        nxt = end.copy()
         for (src, dst, off, ln, pk, total) in mg.dist.messages(lev):
-            link_ms[lev] = max(link_ms[lev], total * 8 / (LINK_GBS * 1e6))
-    path = float(main.max(axis=0).sum() + link_ms.sum())
+            t = total * 8 / (LINK_GBS * 1e6)
+            if end[src] + t > nxt[dst]:
+                link_sum += end[src] + t - nxt[dst]
+                nxt[dst] = end[src] + t
+        start = nxt
+    path = float(start.max())
     i = mg.dist.info
     est = max(float(busy.max()), path)
     print(f"N={nr} block={block}: status {st} bitwise = single device: {same} | busy ms {np.round(busy, 1).tolist()} "
           f"(main {np.round(main.sum(axis=1), 1).tolist()} side {np.round(side.sum(axis=1), 1).tolist()} "
           f"copies {np.round(copy.sum(axis=1), 1).tolist()}) | T1 {t1:.1f} ms bound_busy {t1 / busy.max():.2f}x | "
-          f"path {path:.1f} ms (main chain {main.max(axis=0).sum():.1f} + links {link_ms.sum():.1f} at {LINK_GBS:.0f} GB/s) | "
+          f"path {path:.1f} ms (lockstep main chain {main.max(axis=0).sum():.1f}; waits for messages at {LINK_GBS:.0f} GB/s: {link_sum:.1f}) | "
           f"est {est:.1f} ms = {t1 / est:.2f}x | exchange {i['exchange_elements'] * 8 / 1e9:.2f} GB in "
           f"{i['n_messages']} messages, subtrees {i['n_subtrees']}, root pieces {i['n_root_pieces']}", flush=True)
     mg.close()
