@@ -330,6 +330,33 @@ def test_distributed_factorization_on_one_device(api, oracle, monkeypatch, name,
     assert ok and np.abs(ref - lo).max() <= FACTOR_TOL * np.abs(lo).max()
 
 
+@pytest.mark.parametrize("where", ["subtree", "above the cut"])
+def test_distributed_factorization_reports_a_bad_pivot(api, oracle, where):
+    """A non-positive pivot on any rank ends the distributed factorization with the failing column (LAPACK's info, as the
+    reference returns false on it: parallel_PB_Cholesky_05.h:204-209) -- in a subtree owned by one rank or in a piece
+    above the cut."""
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem("lap30")
+    mg = api.MultiDevice(sym, [0] * 3)
+    try:
+        pieces = api.Plan(sym, -1).pieces()
+        sel = np.where(mg.dist.in_subtree == (1 if where == "subtree" else 0))[0]
+        p = int(sel[len(sel) // 2])
+        col = int(pieces["col0"][p]) + 1
+        vals = sym.A2x.copy()
+        assert sym.A2i[sym.A2p[col]] == col          # the diagonal entry comes first in its column
+        vals[sym.A2p[col]] = -5.0
+        mg.set_values(vals)
+        st, _ = mg.factor()
+        ok, lo, bad = oracle.cholesky_05(sym, vals, I.trivial_hlevel(sym))
+        assert not ok and st == col + 1
+        mg.set_values(sym.A2x)                       # the handle is reusable afterwards
+        st, _ = mg.factor()
+        assert st == 0
+    finally:
+        mg.close()
+
+
 def test_distributed_flan_class_factorization_on_one_device(api):
     """BASELINE configs[4] at full size, 8 ranks sharing this device (8 x 19.4 GB of lValues): BIG launches and
     pieces active, the top separator's 40 pieces dealt over all ranks, 45 GB of pieces copied between the ranks'
