@@ -51,3 +51,6 @@ def test_no_device_is_reported_loudly_not_papered_over():
     x = np.ones(sym.n)
     assert api.blockedLsolve(sym.n, sym.p, sym.s, lv, int(sym.xsize), sym.i_ptr, sym.col2Sup, sym.super,
                              sym.nsuper, x) == 0
+    # the multi-device executor likewise (its host half -- the distribution -- works without a device: test_dist_host)
+    with pytest.raises(RuntimeError, match="no HIP device is usable|no CPU fallback"):
+        api.MultiDevice(sym, [0, 0])
