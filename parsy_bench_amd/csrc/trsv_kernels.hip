@@ -257,6 +257,13 @@ static int mrhs_min() {                 // from this many right-hand sides on (P
     }();
     return v;
 }
+static int bmrhs_min() {                // ... of the backward solve (PARSY_BMRHS_MIN)
+    static const int v = [] {
+        const char* e = std::getenv("PARSY_BMRHS_MIN");
+        return e && *e ? std::atoi(e) : 16;
+    }();
+    return v;
+}
 static constexpr int kLdXs = kRhsM + 4; // row stride of xs in LDS
 
 template <int WMAX>  // widest supernode of the launch, rounded up to 16 / 32 / 64: sizes LDS and loops
@@ -1613,34 +1620,59 @@ __global__ __launch_bounds__(kThreads, QG == 4 ? 1 : 2) void k_bsolve_block_mrhs
         // ---- the rows below (chain: below the supernode's own columns -- ancestors, final; otherwise everything
         // below the block: the later blocks were solved by earlier launches): 64-row chunks over the waves, 16 rows
         // (4 k steps) of loads in flight ahead of their 64 products
-        for (int k0 = (chain ? w : kbeg) + 64 * wave; k0 < r; k0 += 64 * (kThreads / 64)) {
-#pragma unroll 2
-            for (int s4 = 0; s4 < 4; ++s4) {
-                double av[4][4], bv[4][QG];
+        // Software-pipelined over the k steps (4 rows each) of all of this wave's chunks: the operands of step t + 3 are
+        // loaded while the 4 x QG products of step t are issued (a ring of four operand sets); the row ids of a chunk are
+        // ONE load per lane, issued a chunk and a half ahead and handed to the lanes that need them by ds_bpermute.
+        // (The plain form -- ids, then operands, then 64 products, per 16 rows -- waited two dependent round trips per 64
+        // products: Flan-class input, 64 right-hand sides: 45 -> 37 ms per backward solve.)
+        {
+            const int kstart = (chain ? w : kbeg) + 64 * wave;
+            constexpr int kStride = 64 * (kThreads / 64);
+            const int nsteps = kstart < r ? 16 * ((r - kstart + kStride - 1) / kStride) : 0;
+            auto row_ids = [&](int j) {   // lane l: the row id of row l of this wave's chunk j (clamped into the panel)
+                const int kr = min(kstart + kStride * j + lane, r - 1);
+                return (kr < w) ? (D.c0 + kr) : ri[kr];
+            };
+            int ridA = row_ids(0), ridB = row_ids(1);
+            double ra[4][4], rb[4][QG];
+            auto load = [&](int t, double (&A)[4], double (&B)[QG]) {
+                const int j = t >> 4, u = t & 15;
+                const int k = kstart + kStride * j + 4 * u + kq;
+                const bool kin = k < r && t < nsteps;
+                const int kc = min(k, r - 1);
+                const int rid = __builtin_amdgcn_ds_bpermute((4 * u + kq) * 4, (j & 1) ? ridB : ridA);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int k = k0 + 16 * s4 + 4 * st + kq;
-                    const bool kin = k < r;
-                    const int kc = min(k, r - 1);
-                    const int rid = (kc < w) ? (D.c0 + kc) : ri[kc];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const double a = acol[g][kc];
-                        av[st][g] = (kin && aok[g]) ? a : 0.0;
-                    }
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-                        const double b = xcol[g][rid];
-                        bv[st][g] = (kin && bok[g]) ? b : 0.0;
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const double a = acol[g][kc];
+                    A[g] = (kin && aok[g]) ? a : 0.0;
                 }
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
+                for (int g = 0; g < QG; ++g) {
+                    const double b2 = xcol[g][rid];
+                    B[g] = (kin && bok[g]) ? b2 : 0.0;
+                }
+            };
+            if (nsteps > 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) load(t, ra[t], rb[t]);
+            }
+            for (int t = 0; t < nsteps; t += 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tt = t + i;
+                    load(tt + 3, ra[(i + 3) & 3], rb[(i + 3) & 3]);
 #pragma unroll
                     for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
                         for (int qg = 0; qg < QG; ++qg)
-                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st][cg], bv[st][qg], acc[cg][qg], 0, 0, 0);
+                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i][cg], rb[i][qg], acc[cg][qg], 0, 0, 0);
+                    if ((tt & 15) == 13) {   // the loads of this chunk's steps are all issued: its id register takes chunk j + 2
+                        const int j = tt >> 4;
+                        const int v = row_ids(j + 2);
+                        if (j & 1) ridB = v;
+                        else ridA = v;
+                    }
+                }
             }
         }
         if (chain) {
@@ -1662,6 +1694,30 @@ __global__ __launch_bounds__(kThreads, QG == 4 ? 1 : 2) void k_bsolve_block_mrhs
                 }
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
+                // Only the block right above this one is on the critical path of the chain.  A workgroup further up
+                // would poll for a long time, with 16 loads per lane and round, next to hundreds of others on the
+                // same lines (the top separator: 313 workgroups): it first watches ONE value of the block lazily
+                // (the last column this wave reads: one load per wave and round), and goes on to the full poll --
+                // normally satisfied at once -- when that value is there.
+                if (I - pd.jb > 1) {
+                    const int kw = min(I * kTile + 16 * wave + 15, w - 1);
+                    const long long* __restrict__ watch =
+                        reinterpret_cast<const long long*>(xscratch + (int64_t)q0 * ldx + D.c0 + kw);
+                    while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed ||
+                           wait_bias != 0) {
+                        if ((++spins & 15) == 0 &&
+                            (wall_clock64() - t0 > kSolveSpinTicks ||
+                             __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(48);
+                    }
+                    if (!ok) {
+                        if (lane == 0) atomicMin(info, -1);
+                        break;
+                    }
+                }
                 for (;;) {
                     bool in = true;
 #pragma unroll
@@ -2204,12 +2260,12 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
     const int chain = mode == 1;
     const PanelDesc* pds = mode == 2 ? P.bsolve_blocks : P.bsolve_blocks + first;
     const int32_t* ranges = mode == 2 ? P.bsolve_ranges + 2 * first : nullptr;
-    if (tiny == 1 && nrhs >= mrhs_min()) {   // many right-hand sides: 64 per pass, matrix cores, one wave per supernode
+    if (tiny == 1 && nrhs >= bmrhs_min()) {   // many right-hand sides: 64 per pass, matrix cores, one wave per supernode
         const dim3 grid(count, std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM));
         hipLaunchKernelGGL(k_bsolve_tiny_mrhs, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs, ldx);
         return;
     }
-    if (tiny && nrhs < mrhs_min()) {   // width class kTinyWidth (1) or kTinyWidth2 (2), a subtree launch or a level's launch: one wave each
+    if (tiny && nrhs < bmrhs_min()) {   // width class kTinyWidth (1) or kTinyWidth2 (2), a subtree launch or a level's launch: one wave each
         const dim3 grid(count, std::min(kPassLanes, nrhs));
         if (tiny == 1)
             hipLaunchKernelGGL(k_bsolve_tiny<kTinyWidth>, grid, dim3(64), 0, stream, P.sn, pds, ranges, P.rows, L, x, nrhs,
@@ -2219,10 +2275,17 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
                                ldx);
         return;
     }
-    if (nrhs >= mrhs_min()) {   // 64 right-hand sides per pass over L, products on the matrix cores
+    // launches of few blocks (the top of the tree, small inputs: a chain of hand-offs, not a stream of L) keep the
+    // light kernel -- 4 right-hand sides per workgroup, up to 8 workgroups per block side by side (nd24k-class, 16
+    // right-hand sides: 1.02 ms against 2.06 with the kernel below everywhere)
+    static const bool wide_only = [] {
+        const char* e = std::getenv("PARSY_BMRHS_WIDE_ONLY");
+        return !(e && e[0] == '0');
+    }();
+    if (nrhs >= bmrhs_min() && (!wide_only || count >= kMrhsWideBlocks)) {   // 64 right-hand sides per pass over L, products on the matrix cores
         // launches of few blocks (the top of the tree, small inputs) take 16 right-hand sides per pass in up to 8
         // workgroups per block side by side; the others 64 per pass (L read once per 64)
-        const bool wide = count >= kMrhsWideBlocks;
+        const bool wide = count >= kMrhsWideBlocks && nrhs > 16;
         const int per = wide ? kRhsM : 16;
         const int mlanes = std::min(kPassLanes, (nrhs + per - 1) / per);
         const dim3 mgrid = chain ? dim3(count * mlanes) : dim3(count, mlanes);
