@@ -59,7 +59,7 @@ for name, reps, subtrees in (("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS /
     plan.factor_device(values.data_ptr(), L.data_ptr(), 0)
     torch.cuda.synchronize()
     rng = np.random.default_rng(3)
-    for nrhs in (1, 5):
+    for nrhs in (1, 5, 64):
         b = torch.from_numpy(rng.standard_normal(sym.n * nrhs)).to(dev)
         x = b.clone(); plan.solve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0); torch.cuda.synchronize()
         xf = x.clone()
@@ -67,7 +67,7 @@ for name, reps, subtrees in (("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS /
         yb = y.clone()
         torch.cuda.synchronize()
         worst = 0.0; bmis = 0; stat = 0
-        n_rounds = reps if nrhs == 1 else reps // 5
+        n_rounds = reps if nrhs == 1 else (reps // 5 if nrhs == 5 else reps // 20)
         for i in range(n_rounds):
             x.copy_(b); plan.solve_device(L.data_ptr(), x.data_ptr(), nrhs, sym.n, 0)
             torch.cuda.synchronize()
