@@ -337,12 +337,14 @@ class Dist:
         for k in range(max(int(lib.parsy_dist_level_messages(self._h, level)), 0)):
             src, dst = C.c_int32(0), C.c_int32(0)
             nseg, total = C.c_int64(0), C.c_int64(0)
-            off, ln, pk = N.c_i64_p(), N.c_int_p(), N.c_i64_p()
+            # (who talks to whom first: the arrays of a message are copied only for the ranks that take part in it)
             if lib.parsy_dist_message(self._h, level, k, C.byref(src), C.byref(dst), C.byref(nseg), C.byref(total),
-                                      C.byref(off), C.byref(ln), C.byref(pk)) != 0:
+                                      None, None, None) != 0:
                 raise RuntimeError(N.last_error())
             if rank is not None and rank not in (src.value, dst.value):
                 continue
+            off, ln, pk = N.c_i64_p(), N.c_int_p(), N.c_i64_p()
+            lib.parsy_dist_message(self._h, level, k, None, None, None, None, C.byref(off), C.byref(ln), C.byref(pk))
             out.append((src.value, dst.value, N.view_array(off, nseg.value, np.int64),
                         N.view_array(ln, nseg.value, np.int32), N.view_array(pk, nseg.value, np.int64), total.value))
         return out
