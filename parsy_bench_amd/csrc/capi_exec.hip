@@ -391,6 +391,31 @@ int parsy_plan_pieces(const parsy_plan* pl, int32_t* supernode, int32_t* level, 
     return nc;
 }
 
+// Diagnostics (tools/big_stats.py; not part of the public header): the BIG tasks of the plan as rows of
+// (task, launch = 2 * source level + push, K, rows in the row window, rows in the column window, identity map,
+// diagonal tile); returns the number of entries (out may be null).
+int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap) {
+    if (!pl) return -1;
+    const parsy::Schedule& S = pl->S;
+    int64_t n = 0, t = 0;
+    for (const parsy::Schedule::BigTask& b : S.big_all) {
+        for (int64_t e = b.e0; e < b.e1; ++e, ++n) {
+            if (!out || n >= cap) continue;
+            const parsy::WaveEntry& E = S.big_entries[(size_t)e];
+            int32_t* o = out + 7 * n;
+            o[0] = (int32_t)t;
+            o[1] = b.src_level * 2 + (b.next ? 0 : 1);
+            o[2] = E.K;
+            o[3] = E.mn & 255;
+            o[4] = (E.mn >> 8) & 255;
+            o[5] = (E.mn >> 16) != 0;
+            o[6] = b.row0 == b.col0;
+        }
+        ++t;
+    }
+    return n;
+}
+
 int parsy_factor_begin(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream, int flags) {
     if (!pl || !d_values || !d_lValues) {
         set_last_error("parsy_factor_begin: null argument");

@@ -1433,21 +1433,32 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
 
-    auto frags = [&](const WaveEntry& E, int& nfr, int& nfc) {
+    // The wave's block of an entry: the 16-row fragments the source has in the two windows (NR x NC, <= 8 x 8) are
+    // dealt EVENLY over the 2 x kBigWC waves -- ceil(NR / 2) x ceil(NC / kBigWC) fragments each, from fragment
+    // (fr0, fc0) on -- not in fixed 64 x 32 blocks: on the Flan-class input two thirds of the chunks have ragged
+    // windows (a 128-row window of the target holds about 64 rows of a source), and with fixed blocks the busiest wave
+    // of a workgroup multiplies 7.3 fragments per k step while the average wave has 4.5 (tools/big_stats.py); the
+    // others wait for it at the chunk barrier.  Dealt evenly the busiest wave has 5.1.  Which wave forms a product
+    // changes nothing in its value: the factor stays bit for bit the same.
+    auto frags = [&](const WaveEntry& E, int& nfr, int& nfc, int& r0, int& c0) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-        nfr = min(4, max(0, (mi - 64 * wr + 15) >> 4));
-        nfc = min(kBigNfc, max(0, (nj - kBigWCols * wc + 15) >> 4));
-        if (diag && 64 * wr + 63 < kBigWCols * wc) nfr = 0;  // block strictly above the diagonal of a diagonal tile
+        const int NR = (mi + 15) >> 4, NC = (nj + 15) >> 4;
+        const int frb = (NR + 1) >> 1, fcb = (NC + kBigWC - 1) / kBigWC;
+        r0 = 16 * frb * wr;
+        c0 = 16 * fcb * wc;
+        nfr = min(frb, max(0, NR - frb * wr));
+        nfc = min(fcb, max(0, NC - fcb * wc));
+        if (diag && r0 + 16 * nfr - 1 < c0) nfr = 0;  // block strictly above the diagonal of a diagonal tile
         if (nfr == 0 || nfc == 0) nfr = nfc = 0;
     };
     // A wave whose block of the tile has no rows of this source skips the chunk; a ragged block skips the
     // 16-row fragments it does not have (wave-uniform branches: a second, branch-free copy of the loop for
     // full blocks made the compiler spill 153 registers; issuing all 8 products always lost more to the
     // ragged windows than the branches cost: 428 vs 390 ms of BIG launches).
-    auto compute = [&](int b, int nfr, int nfc) {
+    auto compute = [&](int b, int nfr, int nfc, int r0, int c0) {
         if (nfr == 0) return;
-        const double* __restrict__ Rb = &S.R[b][64 * wr + l15];
-        const double* __restrict__ Cb = &S.C[b][kBigWCols * wc + l15];
+        const double* __restrict__ Rb = &S.R[b][r0 + l15];
+        const double* __restrict__ Cb = &S.C[b][c0 + l15];
         // the multiplying waves win the issue arbitration over the waves that stage or write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
         __builtin_amdgcn_s_setprio(1);
@@ -1492,7 +1503,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     // input, the factor unchanged bit for bit: old + (-p) rounds as old - p, the tile belongs to this workgroup
     // alone within the launch, one lane's adds into one address are performed in program order, and the caller
     // drains them before the next barrier, so that the order of sums per entry of L stays the list order)
-    auto epilogue = [&](const WaveEntry& E, int nfr, int nfc) {
+    auto epilogue = [&](const WaveEntry& E, int nfr, int nfc, int r0, int c0) {
         if (nfr == 0) return;
 #ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no update of the tile)
 #pragma unroll
@@ -1506,23 +1517,42 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
 #endif
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const bool ident = (E.mn >> 16) != 0;
-        // (all twelve index loads in flight together; loading them before the source's last chunk is multiplied, so
-        // that they land behind it, cost more in registers than it hid: 373 vs 365 ms)
+        // (loading the indices before the source's last chunk is multiplied, so that they land behind it, cost more in
+        // registers than it hid: 373 vs 365 ms)
+        // (the index loads are unconditional -- rows past the window re-read its last one -- so that all twelve are
+        // in flight together: guarded per lane, the compiler waited for each of them in turn)
         int prow[4], pcol[kBigNfc][4];
+        if (ident) {
 #pragma unroll
-        for (int fr = 0; fr < 4; ++fr) {
-            const int i = 64 * wr + 16 * fr + l15;
-            prow[fr] = -1;
-            if (i < mi) prow[fr] = ident ? E.ia + i : relpos[(int64_t)E.rel + E.ia + i] - D.rbias;
+            for (int fr = 0; fr < 4; ++fr) prow[fr] = E.ia + r0 + 16 * fr + l15;
+#pragma unroll
+            for (int fc = 0; fc < kBigNfc; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] = E.ja + c0 + 16 * fc + kq + 4 * v;
+        } else {
+            const int32_t* __restrict__ rpi = relpos + (int64_t)E.rel + E.ia;
+            const int32_t* __restrict__ rpj = relpos + (int64_t)E.rel + E.ja;
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) prow[fr] = rpi[min(r0 + 16 * fr + l15, mi - 1)];
+#pragma unroll
+            for (int fc = 0; fc < kBigNfc; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] = rpj[min(c0 + 16 * fc + kq + 4 * v, nj - 1)];
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) prow[fr] -= D.rbias;
+#pragma unroll
+            for (int fc = 0; fc < kBigNfc; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] -= D.rbias;
         }
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+            if (fr >= nfr || r0 + 16 * fr + l15 >= mi) prow[fr] = -1;
 #pragma unroll
         for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int j = kBigWCols * wc + 16 * fc + kq + 4 * v;
-                pcol[fc][v] = -1;
-                if (fc < nfc && j < nj) pcol[fc][v] = ident ? E.ja + j : relpos[(int64_t)E.rel + E.ja + j] - D.rbias;
-            }
+            for (int v = 0; v < 4; ++v)
+                if (fc >= nfc || c0 + 16 * fc + kq + 4 * v >= nj) pcol[fc][v] = -1;
 #pragma unroll
         for (int fc = 0; fc < kBigNfc; ++fc) {
             if (fc < nfc) {
@@ -1545,18 +1575,18 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     stage(0);
     fetch();
     __syncthreads();
-    int nfr, nfc;
-    frags(CE, nfr, nfc);
+    int nfr, nfc, r0, c0;
+    frags(CE, nfr, nfc, r0, c0);
     for (int n = 0;; ++n) {
         const bool have_next = v_kend >= 0;
         if (have_next) {
             stage((n + 1) & 1);
             fetch();
         }
-        compute(n & 1, nfr, nfc);
+        compute(n & 1, nfr, nfc, r0, c0);
         ck += kBK;
         if (ck >= CE.K) {
-            epilogue(CE, nfr, nfc);
+            epilogue(CE, nfr, nfc, r0, c0);
             // the adds of this source are performed before the barrier: the next source's adds into the same entries
             // of L may come from other waves (another row map), and the order of sums must not depend on timing
             // (after the task's last source the end of the kernel does it)
@@ -1565,7 +1595,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
             ++ce;
             if (ce < e_end) {
                 CE = ents[ce];
-                frags(CE, nfr, nfc);
+                frags(CE, nfr, nfc, r0, c0);
             }
         }
         if (!have_next) break;
