@@ -393,7 +393,7 @@ int parsy_plan_pieces(const parsy_plan* pl, int32_t* supernode, int32_t* level, 
 
 // Diagnostics (tools/big_stats.py; not part of the public header): the BIG tasks of the plan as rows of
 // (task, launch = 2 * source level + push, K, rows in the row window, rows in the column window, identity map,
-// diagonal tile); returns the number of entries (out may be null).
+// first row of the row window - first row of the column window); returns the number of entries (out may be null).
 int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap) {
     if (!pl) return -1;
     const parsy::Schedule& S = pl->S;
@@ -409,9 +409,22 @@ int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap)
             o[3] = E.mn & 255;
             o[4] = (E.mn >> 8) & 255;
             o[5] = (E.mn >> 16) != 0;
-            o[6] = b.row0 == b.col0;
+            o[6] = E.ia - E.ja;
         }
         ++t;
+    }
+    return n;
+}
+
+// Diagnostics: the launches of the last collected profiled run as rows of (kind, level << 1 | side, work items, ms).
+int64_t parsy_debug_launch_times(const parsy_plan* pl, double* out, int64_t cap) {
+    if (!pl) return -1;
+    const int64_t n = (int64_t)std::min(pl->pev_ms.size(), pl->pev_kind.size());
+    for (int64_t i = 0; out && i < n && i < cap; ++i) {
+        out[4 * i] = pl->pev_kind[(size_t)i];
+        out[4 * i + 1] = (size_t)i < pl->pev_level.size() ? pl->pev_level[(size_t)i] : -1;
+        out[4 * i + 2] = (size_t)i < pl->pev_count.size() ? pl->pev_count[(size_t)i] : 0;
+        out[4 * i + 3] = pl->pev_ms[(size_t)i];
     }
     return n;
 }

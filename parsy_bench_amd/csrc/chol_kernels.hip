@@ -1346,7 +1346,6 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     const SnDesc D = sn[td.sn];
     double* __restrict__ G = L + D.px;
     const int ld = D.ld;
-    const bool diag = td.row0 == td.col0;
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
 
@@ -1448,7 +1447,9 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
         c0 = 16 * fcb * wc;
         nfr = min(frb, max(0, NR - frb * wr));
         nfc = min(fcb, max(0, NC - fcb * wc));
-        if (diag && r0 + 16 * nfr - 1 < c0) nfr = 0;  // block strictly above the diagonal of a diagonal tile
+        // a block whose rows all precede its columns in the source's row order lies strictly above the diagonal of
+        // the target (both windows count the source's rows from the same first row)
+        if (E.ia + r0 + 16 * nfr - 1 < E.ja + c0) nfr = 0;
         if (nfr == 0 || nfc == 0) nfr = nfc = 0;
     };
     // A wave whose block of the tile has no rows of this source skips the chunk; a ragged block skips the

@@ -189,8 +189,11 @@ void plan_free(parsy_plan* pl) {
     delete pl;
 }
 
-static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& cursor, int level = -1, int side = 0) {
+static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& cursor, int level = -1, int side = 0,
+                         int count = 0) {
     if (!pl->profile) return;
+    if (cursor >= pl->pev_count.size()) pl->pev_count.resize(cursor + 1, 0);
+    pl->pev_count[cursor] = count;
     if (cursor >= pl->pev_level.size()) pl->pev_level.resize(cursor + 1, 0);
     pl->pev_level[cursor] = level >= 0 ? (level << 1) | (side & 1) : -1;
     if (cursor >= pl->pev.size()) {
@@ -243,7 +246,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                 if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
             }
         }
-        profile_mark(pl, l.kind, stream, cursor, l.level, l.side);
+        profile_mark(pl, l.kind, stream, cursor, l.level, l.side, l.count);
         switch (l.kind) {
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, l.fused == 2, L, stream); break;
             case kLaunchTiles:
@@ -366,6 +369,8 @@ int plan_collect_profile(parsy_plan* pl) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pl->pev[i], pl->pev[i + 1]) != hipSuccess) return -1;
         const int k = pl->pev_kind[i];
+        if (pl->pev_ms.size() <= i) pl->pev_ms.resize(i + 1, 0.f);
+        pl->pev_ms[i] = ms;
         if (k >= 0 && k < 10) {
             pl->kind_ms[k] += ms;
             pl->kind_launches[k] += 1;

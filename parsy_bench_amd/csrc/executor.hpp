@@ -59,6 +59,8 @@ struct parsy_plan {
     std::vector<hipEvent_t> pev;
     std::vector<int> pev_kind;
     std::vector<int> pev_level;     // per mark: level << 1 | side of a factorization launch (-1: other)
+    std::vector<int> pev_count;     // per mark: work items of the launch
+    std::vector<float> pev_ms;      // per mark: elapsed time in the last collected run (diagnostics)
     std::vector<double> level_ms;   // accumulated ms per (level << 1 | side)
     double kind_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int kind_launches[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -1,6 +1,7 @@
 // Host-side construction of the device schedule (see schedule.hpp).
 #include "schedule.hpp"
 
+#include <cstdio>
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -312,11 +313,23 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     S.sn_wp0.assign(nc, -1);
     S.sn_tw0.assign(nc, -1);
     struct Group { int32_t win, first, len; };
-    std::vector<Group> groups;
+    std::vector<Group> groups, cgroups;
     std::vector<int64_t> cursor;
     struct BigKeyed { int64_t launch_tile; WaveEntry e; };  // launch id << 40 | global tile index
     std::vector<BigKeyed> bigk;
     std::vector<int64_t> big_tile0(nc + 1, 0);  // first 128x128 tile index of every tiled piece
+    // edge of a BIG task's super-tile in 128 x 128 tiles, rows x columns (PARSY_BIG_SUPER=RxC or R)
+    int sr = kBigSuperR, sc = kBigSuperC;
+    if (const char* e = std::getenv("PARSY_BIG_SUPER")) {
+        int a = 0, b = 0;
+        const int got = std::sscanf(e, "%dx%d", &a, &b);
+        if (got >= 1 && a >= 1 && a <= 64) {
+            sr = a;
+            sc = (got == 2 && b >= 1 && b <= 64) ? b : a;
+        }
+    }
+    S.big_super_r = sr;
+    S.big_super_c = sc;
     for (int t = 0; t < nc; ++t) {
         SnDesc& T = S.csn[t];
         big_tile0[t + 1] = big_tile0[t];
@@ -389,24 +402,42 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const int lev_s = S.level_of[S.upd_src[u]];
             if (lev_s >= lev_t) throw std::runtime_error("schedule: an update source is not below its target");
             const int64_t launch = (int64_t)lev_s * 2 + (lev_s == lev_t - 1 ? 0 : 1);
-            groups.clear();
-            for (int k = 0; k < U.m;) {
-                const int win = rel_at(U, k) / kBigTile;
-                int k1 = k + 1;
-                if (U.rel < 0) k1 = std::min(U.m, (win + 1) * kBigTile);
-                else while (k1 < U.m && rel_at(U, k1) / kBigTile == win) ++k1;
-                groups.push_back(Group{win, k, k1 - k});
-                k = k1;
-            }
-            for (const Group& gc : groups) {
+            // A task owns a SUPER-TILE of sr x sc 128 x 128 tiles of the target.  The source's rows inside the
+            // super-tile's row window (a run of its panel rows) times its rows inside the column window are cut into
+            // 128 x 128 blocks IN THE SOURCE'S ROW ORDER -- full blocks but for the last of a run -- one entry each:
+            // a 128-row window of the target holds only about 64 rows of a typical source (a face of a sub-box on a
+            // separator plane), so per-tile windows were two-thirds ragged (tools/big_stats.py).  The blocks of one
+            // source touch different entries of L; the sources stay in update order.
+            auto make_groups = [&](int win_rows, std::vector<Group>& out) {
+                out.clear();
+                for (int k = 0; k < U.m;) {
+                    const int win = rel_at(U, k) / win_rows;
+                    int k1 = k + 1;
+                    if (U.rel < 0) k1 = std::min(U.m, (win + 1) * win_rows);
+                    else while (k1 < U.m && rel_at(U, k1) / win_rows == win) ++k1;
+                    out.push_back(Group{win, k, k1 - k});
+                    k = k1;
+                }
+            };
+            make_groups(kBigTile * sr, groups);
+            if (sc == sr) cgroups = groups;
+            else make_groups(kBigTile * sc, cgroups);
+            for (const Group& gc : cgroups) {
                 if (gc.first >= U.n1) break;
-                const int nj = std::min(gc.len, U.n1 - gc.first);
+                const int njt = std::min(gc.len, U.n1 - gc.first);
                 for (const Group& gr : groups) {
-                    if (gr.win < gc.win) continue;
-                    const int64_t tile = big_tile0[t] + (int64_t)gc.win * nbr128 + gr.win;
-                    bigk.push_back(BigKeyed{(launch << 40) | tile,
-                                            WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, gr.first,
-                                                      gc.first, gr.len | (nj << 8) | ((U.rel < 0) << 16)}});
+                    // (the target's rows ascend with the source's: a window strictly above the diagonal holds nothing)
+                    if ((int64_t)(gr.win + 1) * sr * kBigTile - 1 < (int64_t)gc.win * sc * kBigTile) continue;
+                    const int64_t tile = big_tile0[t] + (int64_t)gc.win * sc * nbr128 + (int64_t)gr.win * sr;
+                    for (int cb = 0; cb < njt; cb += kBigTile)
+                        for (int rb = 0; rb < gr.len; rb += kBigTile) {
+                            const int mi = std::min(kBigTile, gr.len - rb), nj = std::min(kBigTile, njt - cb);
+                            const int ia = gr.first + rb, ja = gc.first + cb;
+                            if (ia + mi - 1 < ja) continue;   // block strictly above the diagonal
+                            bigk.push_back(BigKeyed{(launch << 40) | tile,
+                                                    WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, ia, ja,
+                                                              mi | (nj << 8) | ((U.rel < 0) << 16)}});
+                        }
                 }
             }
         }
@@ -475,7 +506,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.big_all.push_back(Schedule::BigTask{t, (int32_t)(local % nbr128) * kBigTile,
                                                   (int32_t)(local / nbr128) * kBigTile,
                                                   (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
-                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0)});
+                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), sr, sc});
             i = j;
         }
     }
@@ -539,7 +570,10 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         auto by_weight = [](const Schedule::BigTask* a, const Schedule::BigTask* b) { return a->weight > b->weight; };
         // group edge: as large as leaves every XCD at least kBigGroupsPerXcd groups to balance with
         int g = big_group;
-        while (g > 1 && (int64_t)v.size() < (int64_t)8 * kBigGroupsPerXcd * g * g) g /= 2;
+        // (a group of g x g tiles holds g * g / (sr * sc) tasks)
+        const int per_task = v[0]->sr * v[0]->sc;
+        while (g > 1 && (int64_t)v.size() * per_task < (int64_t)8 * kBigGroupsPerXcd * g * g) g /= 2;
+        if (g < std::max(v[0]->sr, v[0]->sc)) g = 1;
         if (g <= 1) {
             std::stable_sort(v.begin(), v.end(), by_weight);
             for (const Schedule::BigTask* b : v) S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
@@ -1187,6 +1221,13 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
         const double K = E.K, mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         return same_window ? K * nj * (nj + 1) + 2.0 * K * (mi - nj) * nj : 2.0 * K * mi * nj;
     };
+    // a BIG entry is any block of the source's rows x rows: the pairs (i, j), i >= j, of it
+    auto block_flops = [](const WaveEntry& E) {
+        const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+        double pairs = 0;
+        for (int j = E.ja; j < E.ja + nj; ++j) pairs += std::max(0, E.ia + mi - std::max(E.ia, j));
+        return 2.0 * E.K * pairs;
+    };
     for (int t = 0; t < nc; ++t) {
         const SnDesc& T = S.csn[t];
         for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u)
@@ -1218,7 +1259,8 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
         const SnDesc& T = S.csn[b.sn];
         if (b.src_level >= S.level_of[b.sn] || (b.next != 0) != (b.src_level == S.level_of[b.sn] - 1))
             fail("BIG task of piece " + std::to_string(b.sn) + " is filed under the wrong source level");
-        if (b.row0 % kBigTile || b.col0 % kBigTile || b.row0 < b.col0 || b.row0 >= T.r || b.col0 >= T.w)
+        const int win_r = kBigTile * b.sr, win_c = kBigTile * b.sc;
+        if (b.sr < 1 || b.sc < 1 || b.row0 % win_r || b.col0 % win_c || b.row0 + win_r <= b.col0 || b.row0 >= T.r || b.col0 >= T.w)
             fail("BIG task of piece " + std::to_string(b.sn) + " has a bad tile origin");
         for (int64_t e = b.e0; e < b.e1; ++e) {
             const WaveEntry& E = S.big_entries[(size_t)e];
@@ -1234,10 +1276,10 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             }
             // the rows it names land in the task's tile
             auto rel_at = [&](int k) { return ident ? k : S.relpos[(size_t)S.upd[u].rel + k] - T.rbias; };
-            if (rel_at(E.ia) / kBigTile != b.row0 / kBigTile || rel_at(E.ia + mi - 1) / kBigTile != b.row0 / kBigTile ||
-                rel_at(E.ja) / kBigTile != b.col0 / kBigTile || rel_at(E.ja + nj - 1) / kBigTile != b.col0 / kBigTile)
+            if (rel_at(E.ia) / win_r != b.row0 / win_r || rel_at(E.ia + mi - 1) / win_r != b.row0 / win_r ||
+                rel_at(E.ja) / win_c != b.col0 / win_c || rel_at(E.ja + nj - 1) / win_c != b.col0 / win_c)
                 fail("BIG entry " + std::to_string(e) + " names rows outside its task's tile");
-            covered[(size_t)u] += entry_flops(E, E.ia == E.ja);
+            covered[(size_t)u] += block_flops(E);
         }
     }
     {

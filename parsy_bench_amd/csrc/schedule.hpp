@@ -137,6 +137,7 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
+constexpr int kBigSuperR = 1, kBigSuperC = 1;  // BIG tasks: super-tile of this many 128 x 128 tiles (PARSY_BIG_SUPER=RxC)
 constexpr int kBigGroup = 8;               // BIG launches: edge of the super-tiles whose tasks share an XCD (PARSY_BIG_GROUP)
 constexpr int kBigGroupsPerXcd = 2;        // ... used only where every XCD gets at least this many of them
 constexpr int kBigTailGroups = 16;         // ... the lightest groups are dealt again at half the edge
@@ -173,6 +174,7 @@ struct Schedule {
     std::vector<int> clevelPtr, clevelSet;  // level sets of the chain-extended etree
     int cnlevels = 0;
     int big_min_k = kBigMinK, piece_width = kPieceWidth, push_group = kPushGroup;
+    int big_super_r = kBigSuperR, big_super_c = kBigSuperC;
     std::vector<UpdDesc> upd;        // update descriptors of the Cholesky view (per piece)
     std::vector<int32_t> upd_src;    // ... and the piece that completes each one's source (its last piece)
     std::vector<int32_t> relpos;
@@ -198,7 +200,8 @@ struct Schedule {
     // and launch; launches go by the level of the SOURCE: NEXT(s) = targets one level up (main stream,
     // before their chain), PUSH(s) = targets further up (side stream, as soon as level s is complete).
     std::vector<WaveEntry> big_entries;   // per task: (source, row window, column window), sources in update order
-    struct BigTask { int32_t sn, row0, col0, weight; int64_t e0, e1; int32_t src_level, next; };
+    struct BigTask { int32_t sn, row0, col0, weight; int64_t e0, e1; int32_t src_level, next;
+                     int32_t sr, sc; };   // sr x sc: the super-tile's edge in 128 x 128 tiles
     std::vector<BigTask> big_all;         // every task, grouped by (src_level, next)
     std::vector<TileDesc> big_tasks;      // tasks of the launches (active targets): wp = e0, sp = e1
     double big_flops = 0;                 // flops of the BIG launches
