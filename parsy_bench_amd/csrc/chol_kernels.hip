@@ -24,6 +24,17 @@ static constexpr int kThreads = 256;
 static constexpr int kLdSub = kSub + 1;   // padded leading dimension of a wave's sub-tile in LDS
 static constexpr int kLdDiag = kTile + 1; // padded leading dimension of a diagonal block in LDS
 
+#ifdef PARSY_BIGSTAMPS
+// diagnostic build only (tools/big_timeline.py): shader-clock stamps of the phases of k_chol_big's chunk loop, for
+// workgroup g_bigstamp_cfg[1] of the launch whose grid has g_bigstamp_cfg[0] workgroups: per chunk 8 stamps of waves 0
+// and 5 (loop top, staged, fetched, multiplied, tile updated, barrier passed, fragments, k of the entry)
+__device__ unsigned long long g_bigtrace[2 * 8 * 1024];
+__device__ int g_bigstamp_cfg[2];
+#define BIGSTAMP(i) do { if (st_on) g_bigtrace[((size_t)st_slot * 1024 + st_n) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BIGSTAMP(i) do { } while (0)
+#endif
+
 #ifdef PARSY_STAMPS
 // diagnostic build only: phase stamps (100 MHz wall clock) of the last workgroup that factored
 // the last diagonal tile of a supernode; read back with parsy_debug_stamps().
@@ -1303,15 +1314,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
 // ---------------------------------------------------------------------------
 // BIG: the updates from wide descendants (reference DSYRK + DGEMM at
 // parallel_PB_Cholesky_05.h:160,173 with K in the hundreds or thousands), and the updates
-// between the pieces of a split supernode.  One workgroup per 128x128 tile of the target's
-// panel; per source the rows of the descendant that fall into the tile's row window (R, <= 128
-// consecutive rows of its column-major panel) and into its column window (C) are staged through
-// LDS in 16-wide k chunks (double-buffered, next chunk prefetched into registers across entry
-// boundaries), shared by the four waves (2x2, 64x64 outputs each: 16 accumulators of
+// between the pieces of a split supernode.  One workgroup per task = a super-tile of the target's
+// panel and a list of entries (source, <= 128 of its rows for the tile's rows: R, <= 128 for the
+// tile's columns: C, consecutive rows of its column-major panel).  Per entry R and C are staged
+// through LDS in 16-wide k chunks by LDS-DMA (global_load_lds_dwordx4: no register on the way, no
+// LDS store instruction), double-buffered, shared by the 8 waves (2 x 4; the 16 x 16 fragments of
+// an entry are dealt evenly over them, at most 4 x 2 each: 8 accumulators of
 // v_mfma_f64_16x16x4_f64); 16 flop per byte fetched against 4 for the per-wave streams.  The
-// product is formed as C x R' (lanes along the target's ROWS: 128-B segments), and at the end of a
-// source it is subtracted from the tile in the panel through the relative indices -- the tile
-// belongs to this workgroup alone within the launch, sources in list order: fixed summation order.
+// product is formed as C x R' (lanes along the target's ROWS: 128-B segments), negated, and at
+// the end of a source it is added to the tile in the panel through the relative indices -- the
+// tile belongs to this workgroup alone within the launch, sources in list order: fixed summation
+// order.
 // ---------------------------------------------------------------------------
 #ifndef PARSY_BK
 #define PARSY_BK 16
@@ -1322,23 +1335,40 @@ static constexpr int kBLd = kBigTile + 16;     // k stride of a staged chunk in 
 #ifndef PARSY_BIG_WC
 #define PARSY_BIG_WC 4
 #endif
-static constexpr int kBigWC = PARSY_BIG_WC;    // waves along the tile's columns: 4 (8 waves: 2 x 4, 64 x 32 outputs each;
-                                               // two workgroups per CU = 4 waves per SIMD, so that the start of one task
-                                               // hides behind the multiplies of the others) or 2 (4 waves of 64 x 64)
+static constexpr int kBigWC = PARSY_BIG_WC;    // waves along the tile's columns: 4 (8 waves: 2 x 4, up to 64 x 32 outputs
+                                               // each; two workgroups per CU = 4 waves per SIMD, so that the start of one
+                                               // task hides behind the multiplies of the others) or 2 (4 waves of 64 x 64)
 static constexpr int kBigWCols = kBigTile / kBigWC;   // columns of a wave's block (32 / 64)
 static constexpr int kBigNfc = kBigWCols / 16;        // 16-column fragments of it (2 / 4)
-static constexpr int kBigThreads = 64 * 2 * kBigWC;
+static constexpr int kBigWaves = 2 * kBigWC;
+static constexpr int kBigThreads = 64 * kBigWaves;
+static_assert(kBK % 4 == 0 && kBK % kBigWaves == 0 && kBigWaves >= 4, "k_chol_big: a wave stages kBK / waves columns per operand");
 struct BigLds {
     double R[2][kBK * kBLd];
     double C[2][kBK * kBLd];
 };
+
+// one LDS-DMA instruction: 16 bytes per lane from the lane's own global address to lds + 16 * lane
+__device__ __forceinline__ void glds16(const double* g, double* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
 
 __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* __restrict__ sn,
                                                              const int32_t* __restrict__ relpos,
                                                              const WaveEntry* __restrict__ ents,
                                                              const TileDesc* __restrict__ tasks,
                                                              double* __restrict__ L) {
-    __shared__ BigLds S;
+    __shared__ __attribute__((aligned(16))) BigLds S;
+#ifndef PARSY_BIG_NOAGPR
+    // The accumulators live in AGPRs (64 of the wave's 128 registers): one inline-asm operand of class "a" makes the
+    // compiler select the AGPR form of the matrix instructions (it still places every wait state itself); the
+    // atomic adds of the tile update take their data straight from there.
+    {
+        int agpr_hint = 0;
+        asm volatile("; accumulators in AGPRs %0" ::"a"(agpr_hint));
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / kBigWC, wc = wave % kBigWC, l15 = lane & 15, kq = lane >> 4;
@@ -1348,54 +1378,60 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     const int ld = D.ld;
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
+#ifdef PARSY_BIGABL_ZEROOPS
+    const long long zmask = td.part == 12345 ? -1ll : 0ll;   // (0 at run time; the compiler cannot know)
+#endif
+#ifdef PARSY_BIGSTAMPS
+    const bool st_on = (int)gridDim.x == g_bigstamp_cfg[0] && (int)blockIdx.x == g_bigstamp_cfg[1] && lane == 0 &&
+                       (wave == 0 || wave == 5);
+    const int st_slot = wave == 0 ? 0 : 1;
+    int st_n = 0;
+#endif
 
-    // ---- loader: thread (row = tid & 127, k = (tid >> 7) + 4 q) of both staged blocks
-    constexpr int kLq = kBK * kBigTile / kBigThreads;  // values per thread, block and chunk (4)
-    constexpr int kLs = kBigThreads / kBigTile;        // k stride between them (4)
-    const int lrow = tid & (kBigTile - 1), lkh = tid / kBigTile;
+    // ---- loader: wave w moves columns k = w, w + 8 of both staged blocks of a chunk, lane l rows 2l and 2l + 1 of
+    // a column (16 bytes: 1 KiB per instruction, one whole column of the block).  Rows past a ragged window re-read
+    // its last row -- at most one row beyond it: the rows of a panel column are followed by the next column, and a
+    // source's last column by the next panel of lValues (a source is never the last one) -- and land in positions
+    // whose products are never stored.
     int64_t le = e_begin;
     int lk = 0;                       // k position inside entry le
     WaveEntry LE = ents[le];
-    double vR[kLq], vC[kLq];
-    int v_kend = 0;                   // valid k of the chunk held in vR / vC (-1: no chunk)
-    // per entry: this thread's two row pointers at k = lkh of the current chunk, and the distance of kLs columns
-    const double* __restrict__ l_pr = L;
-    const double* __restrict__ l_pc = L;
-    int64_t l_step = 0;
+    int offR = 0, offC = 0;           // this lane's first row in the two windows of entry le
     auto enter = [&]() {
         const int mi = LE.mn & 255, nj = (LE.mn >> 8) & 255;
-        const double* __restrict__ base = L + LE.src + (int64_t)lkh * LE.ld;
-        l_pr = base + LE.ia + min(lrow, mi - 1);
-        l_pc = base + LE.ja + min(lrow, nj - 1);
-        l_step = (int64_t)kLs * LE.ld;
+        offR = min(2 * lane, mi - 1);
+        offC = min(2 * lane, nj - 1);
     };
     enter();
-    auto fetch = [&]() {
-        if (le >= e_end) {
-            v_kend = -1;
-            return;
-        }
+    // start the DMA of the loader's next chunk into buffer b; returns its k extent (0: the task has no more chunks)
+    auto fetch = [&](int b) -> int {
+        if (le >= e_end) return 0;
         const int kend = min(kBK, LE.K - lk);
-        if (kend == kBK) {  // a full chunk: the same loads every time, no clamps
+#ifndef PARSY_BIGABL_NOLOAD   // (diagnostic build: every chunk re-reads the entry's first one -- cache hits)
+        const double* __restrict__ base = L + LE.src + (int64_t)lk * LE.ld;
+#else
+        const double* __restrict__ base = L + LE.src;
+#endif
 #pragma unroll
-            for (int q = 0; q < kLq; ++q) {
-                vR[q] = l_pr[q * l_step];
-                vC[q] = l_pc[q * l_step];
-            }
-        } else {            // ragged end of a source: k past the end re-reads its last column (staged as 0)
-#pragma unroll
-            for (int q = 0; q < kLq; ++q) {
-                const int64_t ko = (int64_t)(min(lkh + kLs * q, kend - 1) - lkh) * LE.ld;
-                vR[q] = l_pr[ko];
-                vC[q] = l_pc[ko];
+        for (int h = 0; h < kBK / kBigWaves; ++h) {
+            const int k = wave + kBigWaves * h;
+            if (k < kend) {
+                const double* __restrict__ col = base + (int64_t)k * LE.ld;
+                glds16(col + LE.ia + offR, &S.R[b][k * kBLd]);
+                glds16(col + LE.ja + offC, &S.C[b][k * kBLd]);
             }
         }
-        v_kend = kend;
+        // ragged end of a source: the columns up to the next multiple of four are zero (k steps go by four)
+        if (kend < kBK) {
+            const int kz = kend + wave;
+            if (kz < ((kend + 3) & ~3)) {
+                S.R[b][kz * kBLd + 2 * lane] = 0.0;
+                S.R[b][kz * kBLd + 2 * lane + 1] = 0.0;
+                S.C[b][kz * kBLd + 2 * lane] = 0.0;
+                S.C[b][kz * kBLd + 2 * lane + 1] = 0.0;
+            }
+        }
         lk += kBK;
-#ifndef PARSY_BIGABL_NOLOAD   // (diagnostic build: every chunk re-reads the entry's first one -- cache hits)
-        l_pr += (int64_t)kBK * LE.ld;
-        l_pc += (int64_t)kBK * LE.ld;
-#endif
         if (lk >= LE.K) {
             lk = 0;
             ++le;
@@ -1404,22 +1440,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
                 enter();
             }
         }
-    };
-    auto stage = [&](int b) {
-        if (v_kend == kBK) {
-#pragma unroll
-            for (int q = 0; q < kLq; ++q) {
-                S.R[b][(lkh + kLs * q) * kBLd + lrow] = vR[q];
-                S.C[b][(lkh + kLs * q) * kBLd + lrow] = vC[q];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < kLq; ++q) {
-                const int k = lkh + kLs * q;
-                S.R[b][k * kBLd + lrow] = k < v_kend ? vR[q] : 0.0;
-                S.C[b][k * kBLd + lrow] = k < v_kend ? vC[q] : 0.0;
-            }
-        }
+        return kend;
     };
 
     // ---- consumer state: entry ce, progress ck
@@ -1435,10 +1456,10 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     // The wave's block of an entry: the 16-row fragments the source has in the two windows (NR x NC, <= 8 x 8) are
     // dealt EVENLY over the 2 x kBigWC waves -- ceil(NR / 2) x ceil(NC / kBigWC) fragments each, from fragment
     // (fr0, fc0) on -- not in fixed 64 x 32 blocks: on the Flan-class input two thirds of the chunks have ragged
-    // windows (a 128-row window of the target holds about 64 rows of a source), and with fixed blocks the busiest wave
-    // of a workgroup multiplies 7.3 fragments per k step while the average wave has 4.5 (tools/big_stats.py); the
-    // others wait for it at the chunk barrier.  Dealt evenly the busiest wave has 5.1.  Which wave forms a product
-    // changes nothing in its value: the factor stays bit for bit the same.
+    // windows, and with fixed blocks the busiest wave of a workgroup multiplies 7.3 fragments per k step while the
+    // average wave has 4.5 (tools/big_stats.py); the others wait for it at the chunk barrier.  Dealt evenly the
+    // busiest wave has 5.1.  Which wave forms a product changes nothing in its value: the factor stays bit for bit
+    // the same.
     auto frags = [&](const WaveEntry& E, int& nfr, int& nfc, int& r0, int& c0) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const int NR = (mi + 15) >> 4, NC = (nj + 15) >> 4;
@@ -1454,56 +1475,66 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     };
     // A wave whose block of the tile has no rows of this source skips the chunk; a ragged block skips the
     // 16-row fragments it does not have (wave-uniform branches: a second, branch-free copy of the loop for
-    // full blocks made the compiler spill 153 registers; issuing all 8 products always lost more to the
-    // ragged windows than the branches cost: 428 vs 390 ms of BIG launches).
-    auto compute = [&](int b, int nfr, int nfc, int r0, int c0) {
+    // full blocks made the compiler spill; issuing all 8 products always lost more to the ragged windows than the
+    // branches cost: 428 vs 390 ms of BIG launches).  nks = k steps of four the chunk holds.
+    auto compute = [&](int b, int nks, int nfr, int nfc, int r0, int c0) {
         if (nfr == 0) return;
-        const double* __restrict__ Rb = &S.R[b][r0 + l15];
-        const double* __restrict__ Cb = &S.C[b][c0 + l15];
-        // the multiplying waves win the issue arbitration over the waves that stage or write back (-1.7 % of the BIG
+        const double* __restrict__ Rb = &S.R[b][kq * kBLd + r0 + l15];
+        const double* __restrict__ Cb = &S.C[b][kq * kBLd + c0 + l15];
+        // the multiplying waves win the issue arbitration over the waves that write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
         __builtin_amdgcn_s_setprio(1);
         // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
         // BIG launches on the Flan-class input)
         double rv[2][4], cv[2][kBigNfc];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) rv[0][f] = Rb[kq * kBLd + 16 * f];
+        for (int f = 0; f < 4; ++f) rv[0][f] = Rb[16 * f];
 #pragma unroll
-        for (int f = 0; f < kBigNfc; ++f) cv[0][f] = Cb[kq * kBLd + 16 * f];
+        for (int f = 0; f < kBigNfc; ++f) cv[0][f] = Cb[16 * f];
 #pragma unroll
         for (int ks = 0; ks < kBK / 4; ++ks) {
-            if (ks + 1 < kBK / 4) {
+            if (ks < nks) {
+                if (ks + 1 < kBK / 4 && ks + 1 < nks) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) rv[(ks + 1) & 1][f] = Rb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
+                    for (int f = 0; f < 4; ++f) rv[(ks + 1) & 1][f] = Rb[4 * (ks + 1) * kBLd + 16 * f];
 #pragma unroll
-                for (int f = 0; f < kBigNfc; ++f) cv[(ks + 1) & 1][f] = Cb[(4 * (ks + 1) + kq) * kBLd + 16 * f];
-            }
+                    for (int f = 0; f < kBigNfc; ++f) cv[(ks + 1) & 1][f] = Cb[4 * (ks + 1) * kBLd + 16 * f];
+                }
 #ifdef PARSY_BIGABL_NOMFMA    // (diagnostic build: operands are read from LDS and dropped)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
+                for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
 #pragma unroll
-            for (int f = 0; f < kBigNfc; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
+                for (int f = 0; f < kBigNfc; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
 #else
+#ifdef PARSY_BIGABL_ZEROOPS   // (diagnostic build: the products are formed on all-zero operands -- what the data costs)
 #pragma unroll
-            for (int fc = 0; fc < kBigNfc; ++fc) {
-                if (fc < nfc) {
+                for (int f = 0; f < 4; ++f)
+                    rv[ks & 1][f] = __longlong_as_double(__double_as_longlong(rv[ks & 1][f]) & zmask);
 #pragma unroll
-                    for (int fr = 0; fr < 4; ++fr)
-                        if (fr < nfr)
-                            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[ks & 1][fc], rv[ks & 1][fr], acc[fc][fr], 0, 0, 0);
-                }
-            }
+                for (int f = 0; f < kBigNfc; ++f)
+                    cv[ks & 1][f] = __longlong_as_double(__double_as_longlong(cv[ks & 1][f]) & zmask);
 #endif
+#pragma unroll
+                for (int fc = 0; fc < kBigNfc; ++fc) {
+                    if (fc < nfc) {
+#pragma unroll
+                        for (int fr = 0; fr < 4; ++fr)
+                            if (fr < nfr)
+                                acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[ks & 1][fc], rv[ks & 1][fr], acc[fc][fr], 0, 0, 1);
+                    }
+                }
+#endif
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    // subtract the finished product from the tile (C/D layout of v_mfma_f64_16x16x4_f64 with the operands
-    // swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of C) through the relative indices, as no-return FP64
-    // atomic adds of the negated product (performed at the memory side: fire and forget -- the read-modify-write
-    // this replaces was five dependent round trips per source; 369 -> 363 ms of BIG launches on the Flan-class
-    // input, the factor unchanged bit for bit: old + (-p) rounds as old - p, the tile belongs to this workgroup
-    // alone within the launch, one lane's adds into one address are performed in program order, and the caller
-    // drains them before the next barrier, so that the order of sums per entry of L stays the list order)
+    // add the finished (negated: the instruction's neg modifier on one operand, exact) product to the tile (C/D
+    // layout of v_mfma_f64_16x16x4_f64 with the operands swapped: lane & 15 = row of R, (lane >> 4) + 4 reg = row of
+    // C) through the relative indices, as no-return FP64 atomic adds (performed at the memory side: fire and forget
+    // -- the read-modify-write this replaces was five dependent round trips per source; 369 -> 363 ms of BIG launches
+    // on the Flan-class input, the factor unchanged bit for bit: old + (-p) rounds as old - p, the tile belongs to
+    // this workgroup alone within the launch, one lane's adds into one address are performed in program order, and the
+    // caller drains them before the next barrier, so that the order of sums per entry of L stays the list order)
     auto epilogue = [&](const WaveEntry& E, int nfr, int nfc, int r0, int c0) {
         if (nfr == 0) return;
 #ifdef PARSY_BIGABL_NOEPI     // (diagnostic build: the product is dropped -- no update of the tile)
@@ -1518,10 +1549,9 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
 #endif
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const bool ident = (E.mn >> 16) != 0;
-        // (loading the indices before the source's last chunk is multiplied, so that they land behind it, cost more in
-        // registers than it hid: 373 vs 365 ms)
         // (the index loads are unconditional -- rows past the window re-read its last one -- so that all twelve are
-        // in flight together: guarded per lane, the compiler waited for each of them in turn)
+        // in flight together: guarded per lane, the compiler waited for each of them in turn; loading them before the
+        // source's last chunk is multiplied, so that they land behind it, cost more in registers than it hid)
         int prow[4], pcol[kBigNfc][4];
         if (ident) {
 #pragma unroll
@@ -1562,7 +1592,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const bool ok = prow[fr] >= 0 && pcol[fc][v] >= 0 && prow[fr] >= pcol[fc][v];
-                        if (ok) unsafeAtomicAdd(&G[(int64_t)pcol[fc][v] * ld + prow[fr]], -acc[fc][fr][v]);
+                        if (ok) unsafeAtomicAdd(&G[(int64_t)pcol[fc][v] * ld + prow[fr]], acc[fc][fr][v]);
                     }
             }
 #pragma unroll
@@ -1570,21 +1600,25 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
         }
     };
 
-    // ---- pipeline: chunk n is multiplied from LDS buffer n & 1 while chunk n + 1 moves from
-    // registers to the other buffer and chunk n + 2 is on its way from the panel
-    fetch();
-    stage(0);
-    fetch();
+    // ---- pipeline: chunk n is multiplied from LDS buffer n & 1 while the DMA of chunk n + 1 fills the other buffer
+    // (started right after the barrier that ended the reads of that buffer; __syncthreads() waits for this wave's
+    // DMA -- it counts as vector memory traffic -- before the barrier)
+    int kcur = fetch(0);
     __syncthreads();
     int nfr, nfc, r0, c0;
     frags(CE, nfr, nfc, r0, c0);
     for (int n = 0;; ++n) {
-        const bool have_next = v_kend >= 0;
-        if (have_next) {
-            stage((n + 1) & 1);
-            fetch();
+        BIGSTAMP(0);
+        const int knext = fetch((n + 1) & 1);
+        BIGSTAMP(2);
+        compute(n & 1, (kcur + 3) >> 2, nfr, nfc, r0, c0);
+        BIGSTAMP(3);
+#ifdef PARSY_BIGSTAMPS
+        if (st_on) {
+            g_bigtrace[((size_t)st_slot * 1024 + st_n) * 8 + 6] = (unsigned long long)(nfr * nfc);
+            g_bigtrace[((size_t)st_slot * 1024 + st_n) * 8 + 7] = (unsigned long long)ck | ((unsigned long long)CE.K << 32);
         }
-        compute(n & 1, nfr, nfc, r0, c0);
+#endif
         ck += kBK;
         if (ck >= CE.K) {
             epilogue(CE, nfr, nfc, r0, c0);
@@ -1599,12 +1633,28 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
                 frags(CE, nfr, nfc, r0, c0);
             }
         }
-        if (!have_next) break;
+        BIGSTAMP(4);
+        if (knext == 0) break;
+        kcur = knext;
 #ifndef PARSY_BIGABL_NOBARRIER   // (diagnostic build: waves race through the staged chunks -- wrong results)
         __syncthreads();
 #endif
+        BIGSTAMP(5);
+#ifdef PARSY_BIGSTAMPS
+        if (st_n < 1023) ++st_n;
+#endif
     }
 }
+
+#ifdef PARSY_BIGSTAMPS
+extern "C" void parsy_debug_bigstamp_cfg(int grid, int block) {
+    const int v[2] = {grid, block};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bigstamp_cfg), v, sizeof(v));
+}
+extern "C" void parsy_debug_bigtrace(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bigtrace), sizeof(unsigned long long) * 2 * 8 * 1024);
+}
+#endif
 
 #ifdef PARSY_STAMPS
 extern "C" void parsy_debug_stamps(unsigned long long* out) {

@@ -315,21 +315,71 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     struct Group { int32_t win, first, len; };
     std::vector<Group> groups, cgroups;
     std::vector<int64_t> cursor;
-    struct BigKeyed { int64_t launch_tile; WaveEntry e; };  // launch id << 40 | global tile index
+    struct BigKeyed { int64_t launch_tile; WaveEntry e; int16_t sr, sc; };  // launch id << 40 | global tile index
     std::vector<BigKeyed> bigk;
     std::vector<int64_t> big_tile0(nc + 1, 0);  // first 128x128 tile index of every tiled piece
-    // edge of a BIG task's super-tile in 128 x 128 tiles, rows x columns (PARSY_BIG_SUPER=RxC or R)
-    int sr = kBigSuperR, sc = kBigSuperC;
+    // Edge of a BIG task's super-tile in 128 x 128 tiles, rows x columns, per launch (source level, kind).  A launch
+    // with many tasks whose 128 x 128 windows are mostly ragged (a 128-row window of the target holds about 64 rows of
+    // a typical source) takes 2 x 2 super-tiles -- a source's rows inside the larger windows are cut into FULL
+    // 128 x 128 blocks in its own row order: a quarter fewer chunks for the same products -- the others (pushes
+    // between the pieces of a separator: full windows anyway; launches of few tasks: they end with their longest
+    // task) stay with single tiles.  Measured per launch on the Flan-class input (tools/big_launches.py): early levels
+    // 10.7 -> 7.8 ms, the big pushes 37 -> 34 ms, launches below ~12 000 tasks 3-10 % slower with super-tiles.
+    // PARSY_BIG_SUPER=RxC (or R) forces one size everywhere (diagnostics, tests).
+    int env_sr = 0, env_sc = 0;
     if (const char* e = std::getenv("PARSY_BIG_SUPER")) {
         int a = 0, b = 0;
         const int got = std::sscanf(e, "%dx%d", &a, &b);
         if (got >= 1 && a >= 1 && a <= 64) {
-            sr = a;
-            sc = (got == 2 && b >= 1 && b <= 64) ? b : a;
+            env_sr = a;
+            env_sc = (got == 2 && b >= 1 && b <= 64) ? b : a;
         }
     }
-    S.big_super_r = sr;
-    S.big_super_c = sc;
+    std::vector<int8_t> launch_super((size_t)2 * std::max(S.cnlevels, 1), 1);
+    if (env_sr == 0 && !S.solve_only) {
+        std::vector<int64_t> ltasks(launch_super.size(), 0);
+        std::vector<double> lfrag(launch_super.size(), 0.0), lchunks(launch_super.size(), 0.0);
+        std::vector<int64_t> keys;
+        for (int t = 0; t < nc; ++t) {
+            const SnDesc& T = S.csn[t];
+            if (is_small(T)) continue;
+            const int lev_t = S.level_of[t], nbr128 = ceil_div(T.r, kBigTile);
+            keys.clear();
+            for (int64_t u = T.upd0; u < T.upd0 + T.nupd; ++u) {
+                const UpdDesc& U = S.upd[u];
+                if (!is_big(U, t)) continue;
+                const int lev_s = S.level_of[S.upd_src[u]];
+                const int64_t launch = (int64_t)lev_s * 2 + (lev_s == lev_t - 1 ? 0 : 1);
+                groups.clear();
+                for (int k = 0; k < U.m;) {
+                    const int win = (U.rel < 0 ? k : S.relpos[(size_t)U.rel + k] - T.rbias) / kBigTile;
+                    int k1 = k + 1;
+                    if (U.rel < 0) k1 = std::min(U.m, (win + 1) * kBigTile);
+                    else while (k1 < U.m && (S.relpos[(size_t)U.rel + k1] - T.rbias) / kBigTile == win) ++k1;
+                    groups.push_back(Group{win, k, k1 - k});
+                    k = k1;
+                }
+                const double chunks = ceil_div(U.K, 16);
+                for (const Group& gc : groups) {
+                    if (gc.first >= U.n1) break;
+                    const int nj = std::min(gc.len, U.n1 - gc.first);
+                    for (const Group& gr : groups) {
+                        if (gr.win < gc.win) continue;
+                        keys.push_back((launch << 40) | ((int64_t)gc.win * nbr128 + gr.win));
+                        lfrag[(size_t)launch] += chunks * ceil_div(gr.len, 16) * ceil_div(nj, 16);
+                        lchunks[(size_t)launch] += chunks;
+                    }
+                }
+            }
+            std::sort(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+            for (int64_t k : keys) ltasks[(size_t)(k >> 40)]++;
+        }
+        for (size_t l = 0; l < launch_super.size(); ++l)
+            if (ltasks[l] >= kBigSuperMinTasks && lfrag[l] < kBigSuperMaxFill * 64.0 * lchunks[l]) launch_super[l] = 2;
+    }
+    S.big_super_r = env_sr;
+    S.big_super_c = env_sc;
     for (int t = 0; t < nc; ++t) {
         SnDesc& T = S.csn[t];
         big_tile0[t + 1] = big_tile0[t];
@@ -402,6 +452,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const int lev_s = S.level_of[S.upd_src[u]];
             if (lev_s >= lev_t) throw std::runtime_error("schedule: an update source is not below its target");
             const int64_t launch = (int64_t)lev_s * 2 + (lev_s == lev_t - 1 ? 0 : 1);
+            const int sr = env_sr ? env_sr : launch_super[(size_t)launch], sc = env_sr ? env_sc : launch_super[(size_t)launch];
             // A task owns a SUPER-TILE of sr x sc 128 x 128 tiles of the target.  The source's rows inside the
             // super-tile's row window (a run of its panel rows) times its rows inside the column window are cut into
             // 128 x 128 blocks IN THE SOURCE'S ROW ORDER -- full blocks but for the last of a run -- one entry each:
@@ -436,7 +487,8 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                             if (ia + mi - 1 < ja) continue;   // block strictly above the diagonal
                             bigk.push_back(BigKeyed{(launch << 40) | tile,
                                                     WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, ia, ja,
-                                                              mi | (nj << 8) | ((U.rel < 0) << 16)}});
+                                                              mi | (nj << 8) | ((U.rel < 0) << 16)},
+                                                    (int16_t)sr, (int16_t)sc});
                         }
                 }
             }
@@ -506,7 +558,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.big_all.push_back(Schedule::BigTask{t, (int32_t)(local % nbr128) * kBigTile,
                                                   (int32_t)(local / nbr128) * kBigTile,
                                                   (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
-                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), sr, sc});
+                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), bigk[i].sr, bigk[i].sc});
             i = j;
         }
     }

@@ -137,7 +137,8 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
-constexpr int kBigSuperR = 1, kBigSuperC = 1;  // BIG tasks: super-tile of this many 128 x 128 tiles (PARSY_BIG_SUPER=RxC)
+constexpr int kBigSuperMinTasks = 12288;    // BIG launches with at least this many single-tile tasks ...
+constexpr double kBigSuperMaxFill = 0.85;   // ... whose windows hold less than this share of their 8 x 8 fragments take 2 x 2 super-tiles
 constexpr int kBigGroup = 8;               // BIG launches: edge of the super-tiles whose tasks share an XCD (PARSY_BIG_GROUP)
 constexpr int kBigGroupsPerXcd = 2;        // ... used only where every XCD gets at least this many of them
 constexpr int kBigTailGroups = 16;         // ... the lightest groups are dealt again at half the edge
@@ -174,7 +175,7 @@ struct Schedule {
     std::vector<int> clevelPtr, clevelSet;  // level sets of the chain-extended etree
     int cnlevels = 0;
     int big_min_k = kBigMinK, piece_width = kPieceWidth, push_group = kPushGroup;
-    int big_super_r = kBigSuperR, big_super_c = kBigSuperC;
+    int big_super_r = 0, big_super_c = 0;   // forced super-tile size (PARSY_BIG_SUPER), 0: per launch
     std::vector<UpdDesc> upd;        // update descriptors of the Cholesky view (per piece)
     std::vector<int32_t> upd_src;    // ... and the piece that completes each one's source (its last piece)
     std::vector<int32_t> relpos;

@@ -66,7 +66,28 @@ print("chunks per task percentiles 10/50/90/max:", np.percentile(cpt, [10, 50, 9
 # tasks per launch
 tl = np.zeros(ntask, dtype=np.int64)
 tl[task] = launch
-tpl = np.bincount(tl)
-tpl = tpl[tpl > 0]
+tpl_all = np.bincount(tl, minlength=int(launch.max()) + 1)
+tpl = tpl_all[tpl_all > 0]
 print(f"{len(tpl)} launches; tasks per launch percentiles 10/50/90: {np.percentile(tpl, [10, 50, 90])}; "
       f"launches with fewer than 512 / 1024 tasks: {(tpl < 512).sum()} / {(tpl < 1024).sum()}")
+
+# ---- per launch: tasks, chunks, issued 16x16x4 products (even deal) -> with the measured times of tools/big_launches.py
+# (argv[2], optional) the share of the MFMA pipes' time each launch keeps busy
+if len(sys.argv) > 2:
+    tot, mx = dealt(True)
+    rows = [l.split() for l in open(sys.argv[2]) if l.startswith("level")]
+    ms = {(int(r[1]), int(r[3])): float(r[7]) for r in rows}
+    prod = np.bincount(launch, weights=tot * w * 4)
+    crit = np.bincount(launch, weights=mx * w * 4)
+    nch = np.bincount(launch, weights=w)
+    print("level side | tasks chunks | ms | MFMA busy | busiest-wave bound ms | chunks/slot us/chunk")
+    for lid in np.nonzero(prod)[0]:
+        lev, side = lid >> 1, lid & 1
+        key = (lev + 2, 1) if side else (lev + 1, 0)   # the level whose launches wait for a side launch: s + 2
+        if key not in ms:
+            continue
+        t = ms[key] * 1e-3
+        busy = prod[lid] * 64 / (1024 * 2.37e9 * t)
+        bound = crit[lid] * 64 * 2 / (512 * 2.37e9) * 1e3 / 2   # 8 waves on 4 SIMDs: two waves per SIMD and workgroup
+        print(f"{lev:3d} {side} | {tpl_all[lid]:6d} {int(nch[lid]):9d} | {ms[key]:8.3f} | {busy:.3f} | {bound:8.3f} | "
+              f"{nch[lid] / 512:8.0f} {t * 1e6 / max(nch[lid] / 512, 1):6.2f}")
