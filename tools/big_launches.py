@@ -1,5 +1,6 @@
-"""Per-launch times of the BIG launches of one profiled factorization (every launch alone on the device).
-Usage: [PARSY_BIG_SUPER=..] big_launches.py [WORKLOAD] -> rows (level, side, tasks, ms), sorted by time."""
+"""Per-launch times of the BIG (or, with KIND = 0 SMALL / 1 TILES / 2 CHAIN, another kind's) launches of one profiled
+factorization (every launch alone on the device).
+Usage: [PARSY_BIG_SUPER=..] big_launches.py [WORKLOAD [KIND]] -> rows (level, side, tasks, ms)."""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -27,7 +28,8 @@ lib.parsy_debug_launch_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 n = lib.parsy_debug_launch_times(plan._h, None, 0)
 out = np.zeros((n, 4))
 lib.parsy_debug_launch_times(plan._h, out.ctypes.data, n)
-big = out[out[:, 0] == 3]
-print("BIG launches", len(big), "total ms", big[:, 3].sum())
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+big = out[out[:, 0] == kind]
+print("launches of kind", kind, ":", len(big), "total ms", big[:, 3].sum())
 for r in big:
     print(f"level {int(r[1]) >> 1:3d} side {int(r[1]) & 1} tasks {int(r[2]):7d} ms {r[3]:8.3f}")

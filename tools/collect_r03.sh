@@ -10,7 +10,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 W=${1:-flan}
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/${OUTDIR:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 H=$(python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_hash())")

@@ -58,6 +58,21 @@ __global__ __launch_bounds__(256) void calib_write8(double* __restrict__ p, long
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = (double)i;
 }
 
+// LDS-DMA, 16 B per lane, 64 lanes contiguous (1 KiB per wave instruction) from an address that is 8- but not
+// 16-byte aligned: the staging of k_chol_big (round 3: global_load_lds_dwordx4)
+__global__ __launch_bounds__(256) void calib_dma16(const double* __restrict__ p, double* __restrict__ out, long n2) {
+    __shared__ __attribute__((aligned(16))) double S[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double acc = 0;
+    for (long i = (long)blockIdx.x * 256 + wave * 64; i + 64 <= n2 - 1; i += (long)gridDim.x * 256) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 1 + 2 * (i + lane)),
+                                         (__attribute__((address_space(3))) void*)&S[wave][0], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc += S[wave][lane];
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+
 int main() {
     double *buf, *out;
     if (hipMalloc(&buf, kBytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
@@ -71,10 +86,11 @@ int main() {
         hipLaunchKernelGGL(calib_write8_sc1, dim3(4096), dim3(256), 0, 0, buf, n);
         hipLaunchKernelGGL(calib_read8, dim3(4096), dim3(256), 0, 0, buf, out, n);
         hipLaunchKernelGGL(calib_write8, dim3(4096), dim3(256), 0, 0, buf, n);
+        hipLaunchKernelGGL(calib_dma16, dim3(4096), dim3(256), 0, 0, buf, out, n / 2);
     }
     hipDeviceSynchronize();
     printf("{\"calib_read8_mfma_bytes\": %ld, \"calib_read16_bytes\": %ld, \"calib_write8_sc1_bytes\": %ld, "
-           "\"calib_read8_bytes\": %ld, \"calib_write8_bytes\": %ld}\n",
-           read8_bytes, (long)kBytes, (long)kBytes, (long)kBytes, (long)kBytes);
+           "\"calib_read8_bytes\": %ld, \"calib_write8_bytes\": %ld, \"calib_dma16_bytes\": %ld}\n",
+           read8_bytes, (long)kBytes, (long)kBytes, (long)kBytes, (long)kBytes, (long)((n / 2 - 1) / 64 * 64 * 16));
     return 0;
 }

@@ -20,21 +20,23 @@ def unit(summary, kernel, counter, known):
 u_read8 = unit(cf, "calib_read8", "FETCH_SIZE", calib["calib_read8_bytes"])
 u_read8m = unit(cf, "calib_read8_mfma", "FETCH_SIZE", calib["calib_read8_mfma_bytes"])
 u_read16 = unit(cf, "calib_read16", "FETCH_SIZE", calib["calib_read16_bytes"])
+u_dma16 = unit(cf, "calib_dma16", "FETCH_SIZE", calib["calib_dma16_bytes"]) if "calib_dma16" in cf else u_read16
 u_write8 = unit(cw, "calib_write8", "WRITE_SIZE", calib["calib_write8_bytes"])
 u_write8s = unit(cw, "calib_write8_sc1", "WRITE_SIZE", calib["calib_write8_sc1_bytes"])
 nfact = rf.get("k_scatter_a", {}).get("launches", 1)
 out = {
     "workload": workload, "kernel_source_hash": khash,
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 tools/one_factor.py <workload> 2 2 "
-               "(one pass per counter; tools/collect_r02.sh)",
+               "(one pass per counter; tools/collect_r03.sh)",
     "calibration_bytes_per_count": {"FETCH_SIZE, 8-B lanes contiguous (k_chol_big staging, solve rows)": u_read8,
                                     "FETCH_SIZE, 8-B lanes in 128-B segments (wave streams)": u_read8m,
                                     "FETCH_SIZE, 16-B lanes contiguous": u_read16,
+                                    "FETCH_SIZE, LDS-DMA 16-B lanes contiguous, 8-byte aligned (k_chol_big staging, round 3)": u_dma16,
                                     "WRITE_SIZE, plain 8-B stores": u_write8,
                                     "WRITE_SIZE, 8-B sc1 stores": u_write8s},
     "factorizations_in_the_profiled_run": nfact, "kernels": {},
 }
-shape = {"k_chol_big": (u_read8, u_write8), "k_chol_tiles": (u_read8m, u_write8), "k_chol_chain": (u_read8m, u_write8s),
+shape = {"k_chol_big": (u_dma16, u_write8), "k_chol_tiles": (u_read8m, u_write8), "k_chol_chain": (u_read8m, u_write8s),
          "k_chol_small": (u_read8, u_write8), "k_scatter_a": (u_read8, u_write8)}
 for name in sorted(set(rf) | set(rw)):
     if not name.startswith("k_"):
