@@ -90,6 +90,7 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 // critical path of every block step).
 // ---------------------------------------------------------------------------
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) double lds_f64;
 static constexpr int kPotrfScratch = 2 * 4 * kTile;
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
@@ -188,6 +189,124 @@ __device__ __forceinline__ void potrf64_regs(double (&a)[4][4], double* __restri
                     for (int k = 0; k < 4; ++k) a[ri][ci] = fma(-li[ri][k], lc[ci][k], a[ri][ci]);
         }
         PPROBE(4);
+    }
+}
+
+// Step (a) of potrf64_panel, by ONE wave, out of line: the sweep keeps ~30 wave-uniform multipliers in scalar
+// registers at a time, which the walker around it has none to spare for (inlined, the compiler parked them in
+// vector lanes: 1 000 extra lane moves per panel).  Returns the first column (1-based, within the tile) of the panel
+// whose pivot was not positive, or 0.
+__device__ __noinline__ int potrf64_panel_sweep(lds_f64* __restrict__ Cb, int c0, int nb, lds_f64* __restrict__ inv_out,
+                                                lds_f64* __restrict__ scr) {
+    const int lane = threadIdx.x & 63;
+    // lane l holds row c0 + l of the tile (the rows above the panel have nothing in it), so that the pivot of
+    // column j sits in lane j and the multiplier of column c in lane c: constant lane numbers
+    const int row = c0 + lane;
+    const bool live = row < nb;          // (rows past nb: an identity, never stored)
+    // column c0 + j of this lane's row: j * kLdSub doubles from `mine` (a panel lies inside one 32-column half)
+    const int rowc = min(row, kTile - 1);
+    lds_f64* __restrict__ mine = Cb + ((rowc >> 5) * 2 + (c0 >> 5)) * (kSub * kLdSub) + (c0 & 31) * kLdSub + (rowc & 31);
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double v = mine[j * kLdSub];
+        x[j] = (lane >= j && live && c0 + j < nb) ? v : ((lane == j) ? 1.0 : 0.0);
+    }
+    double mydiag = 1.0, myinv = 1.0;    // lane j: L[j][j] and its reciprocal
+    // Column j: pivot and the multiplier of column j + 1 -- the critical chain -- reach the lanes as wave-uniform
+    // values (v_readlane); the multipliers of the later columns go through 16 doubles of LDS (lanes 0..15 park the
+    // scaled column, everybody reads the ones it needs two at a time as broadcasts): a third of the instructions of
+    // reading every multiplier lane by lane, and a single wave is bound by the instructions it issues.
+    typedef __attribute__((address_space(3))) double2_t lds_f64x2;
+    lds_f64x2* __restrict__ bc = (lds_f64x2*)scr;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double d = readlane_f64(x[j], j);
+        // 1/sqrt(d): hardware estimate + one correction step (as potrf64_regs); a pivot that is not positive
+        // leaves a NaN on the diagonal, which is how it is found below
+        const double y0 = __builtin_amdgcn_rsq(d);
+        const double e = fma(-d * y0, y0, 1.0);
+        const double inv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+        const double ljj = d * inv;
+        mydiag = (lane == j) ? ljj : mydiag;
+        myinv = (lane == j) ? inv : myinv;
+        x[j] = (lane == j) ? ljj : x[j] * inv;
+        if (j + 1 < 16) {
+            if (j + 2 < 16 && lane < 16) scr[lane] = x[j];
+            const double l1 = readlane_f64(x[j], j + 1);
+            x[j + 1] = fma(-x[j], l1, x[j + 1]);
+            // (pairs (c, c + 1) from an even c on: 16-byte broadcast reads)
+#pragma unroll
+            for (int c = (j + 2) & ~1; c < 16; c += 2) {
+                const double2_t l = bc[c >> 1];
+                if (c >= j + 2) x[c] = fma(-x[j], l[0], x[c]);
+                x[c + 1] = fma(-x[j], l[1], x[c + 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (columns one after the other: hoisted reads cost registers the caller must save)
+    }
+    const bool in_block = lane < 16 && row < nb;
+    const unsigned long long badmask = __ballot(in_block && !(mydiag > 0.0));
+    if (lane < 16) inv_out[row] = in_block ? myinv : 1.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (lane >= j && live && c0 + j < nb) mine[j * kLdSub] = x[j];
+    return badmask != 0 ? c0 + (int)__builtin_ctzll(badmask) + 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// POTRF of a 64x64 diagonal tile held in LDS (sub-tile layout of the tile kernel: 4 x 32x33, lower triangle valid), in
+// place, by 16-column panels (the walker of the chain launch; reference dpotrf at parallel_PB_Cholesky_05.h:204):
+//   (a) wave 0 factors the panel with ONE ROW PER LANE: lane i keeps its 16 entries of the panel in registers; per
+//       column the pivot and the multipliers of the later columns reach all lanes as wave-uniform values
+//       (v_readlane), so a column costs one pivot chain + (15 - j) independent multiply-adds per lane, and the rows
+//       below the diagonal block are solved by the same instructions (the TRSM of the panel comes for free) -- no
+//       barrier, no LDS traffic inside a panel;
+//   (b) the panel goes back to LDS, one barrier;
+//   (c) the four waves subtract P_i P_j' from the 16x16 blocks to the right of the panel (v_mfma_f64_16x16x4_f64,
+//       K = 16: four products per block, at most two blocks per wave), one barrier.
+// 4 barrier pairs and 64 pivots in sequence instead of 16 steps of (4 pivots + 4x4 solve + publish + barrier + rank-4
+// update) over the 256 threads' register blocks (potrf64_regs above, still the SMALL kernel's).  Rows / columns past
+// nb are treated as an identity.  `bad` receives (1-based, lane 0 of wave 0 only) the first column whose pivot was
+// not positive; inv_out (64 doubles of LDS) the reciprocals of the factor's diagonal; scr: 16 doubles of LDS, 16-byte
+// aligned.  A workgroup barrier must precede the call; one ends it.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void potrf64_panel(double* __restrict__ Cb, int nb, int& bad, double* __restrict__ inv_out,
+                                              double* __restrict__ scr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    auto cell = [&](int i, int c) -> double& {
+        return Cb[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
+    };
+    bad = 0;
+    const int np = (nb + 15) >> 4;
+    for (int p = 0; p < np; ++p) {
+        const int c0 = 16 * p;
+        if (wave == 0) {
+            const int pb = potrf64_panel_sweep((lds_f64*)Cb, c0, nb, (lds_f64*)inv_out, (lds_f64*)scr);
+            if (lane == 0 && bad == 0) bad = pb;   // (the first of the whole block: later panels see its NaNs)
+        }
+        __syncthreads();
+        // blocks (bi, bj), p < bj <= bi < np, in the order (p+1,p+1), (p+2,p+1), (p+2,p+2), ...: block q to wave q % 4
+        int q = 0;
+        for (int bi = p + 1; bi < np; ++bi)
+            for (int bj = p + 1; bj <= bi; ++bj, ++q) {
+                if ((q & 3) != wave) continue;
+                double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double av = cell(16 * bi + l15, c0 + kq + 4 * u);
+                    const double bv = cell(16 * bj + l15, c0 + kq + 4 * u);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * bi + kq + 4 * v, c = 16 * bj + l15;
+                    if (i >= c && i < nb) cell(i, c) -= acc[v];   // (rows past nb may be rows of the panel below the block)
+                }
+            }
+        __syncthreads();
     }
 }
 
@@ -522,7 +641,6 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
     r2 = l2;
 }
 
-typedef __attribute__((address_space(3))) double lds_f64;
 
 // X := B inv(Ljj') on the 64 rows of the LDS tile `tile` (sub-tile layout of the tile kernel: 4 x
 // 32x33); Dg holds Ljj (Dg[c * 65 + i], zeros above the diagonal), invd the reciprocals of its
@@ -1093,16 +1211,6 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         for (int J = 0; J < nbc; ++J) {
             const int col0 = J * kTile, nb = min(kTile, w - col0);
             TRACE(J, 0);
-            double a[4][4];
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    const int i = 4 * ti + ri, c = 4 * tj + ci;
-                    double v = (i == c) ? 1.0 : 0.0;
-                    if (c < nb && i < nb && i >= c) v = cell(Cb, i, c);
-                    a[ri][ci] = v;
-                }
             const bool has_next = J + 1 < nbc;
             const bool tail_rows = !has_next && nb < kTile && col0 + nb < r;
             const int f_diag = D.tflag0 + J * nbc + J;
@@ -1138,7 +1246,32 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
 #ifdef PARSY_STAMPS
             if (tid == 0 && J < 512) g_trace[J * 16 + 8] = clock64();
 #endif
+#ifndef PARSY_WALKER_POTRF_PANEL   // the 4-columns-per-step form over the 256 threads' register blocks (default)
+            double a[4][4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = 4 * ti + ri, c = 4 * tj + ci;
+                    double v = (i == c) ? 1.0 : 0.0;
+                    if (c < nb && i < nb && i >= c) v = cell(Cb, i, c);
+                    a[ri][ci] = v;
+                }
             potrf64_regs(a, colbuf, ti, tj, nb, bad, s_invd);
+#else
+            // (the 16-column panel form: built and measured in round 3 -- 14.8 vs 14.5 us per 64 x 64 block on the
+            // nd24k-class input: one wave is bound by the instructions it issues, not by the pivots' chain -- not the default)
+            potrf64_panel(Cb, nb, bad, s_invd, colbuf);
+            double a[4][4];   // thread (ti, tj)'s 4x4 block of the factor, as the rest of the step takes it
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = 4 * ti + ri, c = 4 * tj + ci;
+                    a[ri][ci] = (c < nb && i < nb && i >= c) ? cell(Cb, i, c) : 0.0;
+                }
+            __syncthreads();   // (the buffer that held the tile may be the one Ljj is laid out in below)
+#endif
 #ifdef PARSY_STAMPS
             if (tid == 0 && J < 512) g_trace[J * 16 + 9] = clock64();
 #endif
