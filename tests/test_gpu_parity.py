@@ -639,6 +639,34 @@ def test_factor_with_pieces_and_big_launches(api, oracle, monkeypatch, name, pie
 
 
 # ---------------------------------------------------------------------------
+# super-tiles of the BIG launches (a task owns R x C tiles; a source's rows inside the larger window are cut into
+# 128 x 128 blocks in the source's own row order): forced onto small inputs (PARSY_BIG_SUPER; by itself the schedule
+# takes 2 x 2 only for launches of >= 12 288 tasks).  Which task forms a product changes nothing in its value and the
+# sources keep their order: the factor must be BITWISE the single-tile one, and agree with the oracle.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,piece,mink,sup", [("mid3d", 128, 16, "2"), ("mid3d", 128, 16, "4x2"), ("lap30", 128, 32, "2x4"),
+                                                 ("lap30", 256, 64, "3"), ("ex15", 128, 16, "2"), ("mid3d", 0, 32, "8")])
+def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, sup):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_BIG_SUPER", "1")
+    plan1 = api.Plan(sym, 0)
+    lv1, _ = plan1.factor(sym.A2x)
+    assert plan1.status() == 0
+    monkeypatch.setenv("PARSY_BIG_SUPER", sup)
+    plan = api.Plan(sym, 0)
+    assert 0 < plan.info["big_tasks"] <= plan1.info["big_tasks"]
+    assert plan.info["big_flops"] == plan1.info["big_flops"]
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    assert np.array_equal(lv, lv1), f"{name} super {sup}: the factor differs from the single-tile one"
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok and np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+# ---------------------------------------------------------------------------
 # a hand-off wait of the solve's chain launches that times out is REPORTED: own status word, host
 # conveniences and drop-in solves fail, the factorization's status is untouched
 # ---------------------------------------------------------------------------

@@ -95,6 +95,50 @@ def test_chain_dry_run_with_many_walkers():
         N.lib().parsy_plan_destroy(h)
 
 
+@pytest.mark.parametrize("name,piece,mink,sup", [("mid3d", 128, 16, "2"), ("mid3d", 128, 16, "4x2"), ("lap30", 128, 32, "2x4"),
+                                                 ("lap30", 256, 64, "3"), ("nd24k", 256, 64, "2"), ("nd24k", 512, 128, "4")])
+def test_super_tiles_cover_every_update_once(monkeypatch, name, piece, mink, sup):
+    """BIG tasks that own R x C tiles (PARSY_BIG_SUPER; by itself the schedule takes 2 x 2 for launches of many ragged
+    tasks): every entry is a block of at most 128 x 128 rows of its source inside the task's window, the blocks cover
+    every update exactly once (flop identity), every task is launched exactly once -- parsy_plan_check -- and there
+    are fewer tasks for the same flops than with single tiles."""
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_BIG_SUPER", "1")
+    h1, info1 = host_plan(sym)
+    monkeypatch.setenv("PARSY_BIG_SUPER", sup)
+    h, info = host_plan(sym)
+    try:
+        assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+        assert 0 < info["big_tasks"] < info1["big_tasks"]
+        assert info["big_flops"] == info1["big_flops"] and info["big_entries"] <= info1["big_entries"]
+        for mask in shard_masks(sym, 2):
+            assert N.lib().parsy_plan_set_active(h, N.ptr(np.ascontiguousarray(mask))) == 0
+            assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+    finally:
+        N.lib().parsy_plan_destroy(h)
+        N.lib().parsy_plan_destroy(h1)
+
+
+def test_flan_class_plan_takes_super_tiles_by_itself(monkeypatch):
+    """BASELINE configs[2] at full size, host only: the launches with many ragged single-tile tasks take 2 x 2
+    super-tiles without being told to (a third fewer tasks, a quarter fewer chunks), the plan checks."""
+    from parsy_bench_amd import matrices as M
+    A, perm = M.workload("flan")
+    sym = I.analyze(A, perm)
+    h, info = host_plan(sym)
+    monkeypatch.setenv("PARSY_BIG_SUPER", "1")
+    h1, info1 = host_plan(sym)
+    try:
+        assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+        assert info["big_flops"] == info1["big_flops"]
+        assert info["big_tasks"] < 0.75 * info1["big_tasks"] and info["big_entries"] < 0.75 * info1["big_entries"]
+    finally:
+        N.lib().parsy_plan_destroy(h)
+        N.lib().parsy_plan_destroy(h1)
+
+
 @pytest.mark.parametrize("name,piece,mink,group", [
     ("small3d", None, None, None), ("mid3d", None, None, None), ("ex15", None, None, None), ("nd24k", None, None, None),
     ("mid3d", 128, 16, 1), ("mid3d", 128, 48, 2), ("lap30", 128, 32, 1), ("lap30", 256, 64, 4), ("lap30", 0, 16, 1),
