@@ -657,8 +657,7 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
     assert plan1.status() == 0
     monkeypatch.setenv("PARSY_BIG_SUPER", sup)
     plan = api.Plan(sym, 0)
-    assert 0 < plan.info["big_tasks"] <= plan1.info["big_tasks"]
-    assert plan.info["big_flops"] == plan1.info["big_flops"]
+    assert plan.info["big_tasks"] > 0 and plan.info["big_flops"] == plan1.info["big_flops"]
     lv, _ = plan.factor(sym.A2x)
     assert plan.status() == 0
     assert np.array_equal(lv, lv1), f"{name} super {sup}: the factor differs from the single-tile one"
