@@ -49,6 +49,7 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.big_tasks, pl->dp.big_tasks, true)) return -1;
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
+    if (upload(pl, S.solve_mtasks, pl->dp.solve_mtasks, true)) return -1;
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
     if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
     if (upload(pl, S.bsolve_blocks, pl->dp.bsolve_blocks, true)) return -1;
@@ -268,7 +269,10 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, stream); break;
             case kLaunchSolvePanel:
-                if (l.fused)
+                if (l.fused && nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain)
+                    launch_solve_blocks_mrhs(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
+                                             l.jb, pl->solve_wait_bias, stream);
+                else if (l.fused)
                     launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
                                        pl->epoch, l.jb, pl->solve_wait_bias, stream);
                 else
@@ -498,7 +502,14 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
     // one right-hand side: the chain launches hand x over through xscratch itself
+    // (many right-hand sides: likewise, k_solve_blocks_mrhs; PARSY_OLD_MRHS_CHAIN=1: the flag protocol of rounds 1-2)
+    {
+        const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
+        pl->old_mrhs_chain = e && e[0] == '1';
+    }
     if (nrhs == 1 && pl->S.n_solve_wide > 0) PARSY_HIP(solve_arm_handoff(pl->xscratch, ldx, stream));
+    else if (nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain && pl->S.n_solve_wide > 0)
+        PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());

@@ -56,6 +56,7 @@ struct parsy_plan {
 
     // optional per-launch profiling (hipEvents on the launch stream)
     bool profile = false;
+    bool old_mrhs_chain = false;    // PARSY_OLD_MRHS_CHAIN=1: forward chain launches with many right-hand sides by flags
     std::vector<hipEvent_t> pev;
     std::vector<int> pev_kind;
     std::vector<int> pev_level;     // per mark: level << 1 | side of a factorization launch (-1: other)

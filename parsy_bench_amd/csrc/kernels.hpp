@@ -31,6 +31,7 @@ struct DevicePattern {           // device copies of Schedule arrays
     const TileDesc* big_tasks = nullptr;
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
+    const PanelDesc* solve_mtasks = nullptr;
     const int32_t* solve_fix_list = nullptr;
     const int32_t* solve_wide_list = nullptr;   // (supernode, block column) pairs: diagonal blocks to invert
     const PanelDesc* bsolve_pairs = nullptr;   // backward chain launches, one right-hand side: block-column pairs
@@ -65,6 +66,10 @@ void launch_solve_panel(const DevicePattern& P, int first, int count, const doub
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream);
+void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                              double* x, double* xscratch, int nrhs, int ldx, int ticket, int wait_bias,
+                              hipStream_t stream);
+int solve_mrhs_min();
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);

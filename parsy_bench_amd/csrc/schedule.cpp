@@ -589,6 +589,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     S.chol.clear();
     S.solve_small_list.clear();
     S.solve_panels.clear();
+    S.solve_mtasks.clear();
     S.solve_fix_list.clear();
     S.solve_wide_list.clear();
     S.solve.clear();
@@ -917,6 +918,15 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                     for (int c = 0; c * kSolveRows < S.sn[t].r; ++c)
                         S.solve_panels.push_back(PanelDesc{t, c, c * kSolveRows, 0});
                 Lc.count = (int32_t)S.solve_panels.size() - Lc.first;
+                // the same launch for many right-hand sides (k_solve_blocks_mrhs): the block columns of the triangles
+                // first (producers, ascending), then the row chunks below the supernodes' own columns
+                Lc.lds_bytes = (int32_t)S.solve_mtasks.size();
+                for (int t : sbigs)
+                    for (int jb = 0; jb * kTile < S.sn[t].w; ++jb) S.solve_mtasks.push_back(PanelDesc{t, jb, -1, 0});
+                for (int t : sbigs)
+                    for (int c = 0, row0 = S.sn[t].w; row0 < S.sn[t].r; ++c, row0 += kSolveRows)
+                        S.solve_mtasks.push_back(PanelDesc{t, c, row0, 0});
+                Lc.wait_level = (int32_t)S.solve_mtasks.size() - Lc.lds_bytes;
                 S.solve.push_back(Lc);
                 for (int t : sbigs) {
                     for (int jb = 0; jb * kTile < S.sn[t].w; ++jb) {
@@ -1169,6 +1179,40 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
                     else if (l.fused) {
                         if (pd.row0 != pd.jb * kSolveRows || pd.row0 >= S.sn[pd.sn].r) fail("forward chain launch: bad chunk rows");
                         chunks[pd.sn]++;
+                    }
+                }
+                if (l.fused) {
+                    // the same launch for many right-hand sides: per supernode its block columns in ascending order BEFORE
+                    // anything that waits for them (tickets go in list order), every row below its columns exactly once
+                    if (l.lds_bytes < 0 || l.wait_level < 0 || (size_t)l.lds_bytes + (size_t)l.wait_level > S.solve_mtasks.size())
+                        fail("forward chain launch: bad task range (many right-hand sides)");
+                    else {
+                        std::vector<int> next_block(ns, 0);
+                        std::vector<int64_t> next_row(ns, -1);
+                        for (int q = l.lds_bytes; q < l.lds_bytes + l.wait_level; ++q) {
+                            const PanelDesc& pd = S.solve_mtasks[(size_t)q];
+                            if (pd.sn < 0 || pd.sn >= ns || S.sn[pd.sn].w <= kTile || level_of[pd.sn] != l.level) {
+                                fail("forward chain launch: bad task " + std::to_string(q));
+                                continue;
+                            }
+                            const SnDesc& T = S.sn[pd.sn];
+                            if (pd.row0 < 0) {
+                                if (pd.jb != next_block[pd.sn]++ || pd.jb * kTile >= T.w) fail("forward chain launch: block columns out of order");
+                                if (next_row[pd.sn] >= 0) fail("forward chain launch: a block column after the row chunks that wait for it");
+                            } else {
+                                if (next_block[pd.sn] != ceil_div(T.w, kTile)) fail("forward chain launch: row chunk before the supernode's block columns");
+                                if (next_row[pd.sn] < 0) next_row[pd.sn] = T.w;
+                                if (pd.row0 != next_row[pd.sn] || pd.row0 >= T.r) fail("forward chain launch: row chunks do not tile the rows below");
+                                next_row[pd.sn] = pd.row0 + kSolveRows;
+                            }
+                        }
+                        for (int q = l.first; q < l.first + l.count; ++q) {
+                            const int t = S.solve_panels[q].sn;
+                            if (t < 0 || t >= ns) continue;
+                            const SnDesc& T = S.sn[t];
+                            if (next_block[t] != ceil_div(T.w, kTile) || (T.r > T.w && next_row[t] < T.r) || (T.r == T.w && next_row[t] >= 0))
+                                fail("forward chain launch: supernode " + std::to_string(t) + " is not covered by the many-right-hand-side tasks");
+                        }
                     }
                 }
             }

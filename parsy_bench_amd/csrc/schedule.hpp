@@ -117,12 +117,13 @@ struct Launch {
     int32_t first, count;  // range in the kind's descriptor array
     int32_t level;         // etree level of the targets; side launches: level whose main-stream launches wait for it
     int32_t jb;            // SMALL: stage size; CHAIN: index of its ticket counter; SOLVE_PANEL / BACK: block column
-    int32_t lds_bytes;     // dynamic LDS (SMALL); BACK chain launch: first entry of its workgroups in bsolve_pairs
+    int32_t lds_bytes;     // dynamic LDS (SMALL); BACK chain launch: first entry of its workgroups in bsolve_pairs;
+                           // SOLVE_PANEL chain launch: first entry of its tasks in solve_mtasks
     int32_t fused;         // SOLVE_PANEL / BACK: 1 = chain launch of the whole level; SMALL, SOLVE_SMALL, BACK:
                            // 2 = subtree launch (first / count: (begin, end) pairs in the kind's range array)
     int32_t side;          // 1: runs on the plan's side stream (TILES), 0: main stream
     int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only);
-                           // BACK chain launch: number of its entries in bsolve_pairs
+                           // BACK chain launch: number of its entries in bsolve_pairs; SOLVE_PANEL chain launch: in solve_mtasks
     int32_t early;         // TILES: always 1 (kept for the launch dumps)
 };
 
@@ -211,6 +212,9 @@ struct Schedule {
     // solve launch data
     std::vector<int32_t> solve_small_list;
     std::vector<PanelDesc> solve_panels;
+    std::vector<PanelDesc> solve_mtasks;  // chain launches, many right-hand sides: per wide supernode its block columns
+                                          // (row0 = -1), then the 256-row chunks of the rows below its columns (row0 >= w);
+                                          // Launch::lds_bytes / wait_level = first entry / number of entries of a launch
     std::vector<int32_t> solve_fix_list;  // wide supernodes solved by per-block-column launches
     std::vector<int32_t> solve_wide_list; // (supernode, block column) pairs of the wide supernodes solved by
                                           // SOLVE_CHAIN: the diagonal blocks whose inverses a solve needs

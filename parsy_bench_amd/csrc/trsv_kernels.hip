@@ -250,13 +250,20 @@ __global__ __launch_bounds__(64) void k_solve_tiny(const SnDesc* __restrict__ sn
 //       and is subtracted from x with atomics (the reference's `omp atomic`, Triangular_BCSC.h:154).
 typedef double double4_s __attribute__((ext_vector_type(4)));
 static constexpr int kRhsM = 64;        // right-hand sides per pass
-static int mrhs_min() {                 // from this many right-hand sides on (PARSY_MRHS_MIN: diagnostics)
+// The many-right-hand-side kernels (64 per pass over L, matrix cores) take over from the 8-per-pass kernels
+//   * for the narrow supernodes (k_solve_small_mrhs) from 6 right-hand sides on,
+//   * for the wide supernodes' chain (k_solve_blocks_mrhs) from 2 on
+// (parabolic_fem-class input, MI355X, forward solve: 4 right-hand sides 1.02 -> 0.85 ms, 8: 1.41 -> 0.89 ms; Flan-class,
+// 8: 18.2 -> 11.6 ms).  PARSY_MRHS_MIN=k sets both thresholds to k (diagnostics, tests).
+static int mrhs_env() {
     static const int v = [] {
         const char* e = std::getenv("PARSY_MRHS_MIN");
-        return e && *e ? std::atoi(e) : 16;
+        return e && *e ? std::atoi(e) : 0;
     }();
     return v;
 }
+static int mrhs_min() { return mrhs_env() > 0 ? mrhs_env() : 6; }         // narrow supernodes
+static int chain_mrhs_min() { return mrhs_env() > 0 ? mrhs_env() : 2; }   // wide supernodes' chain
 static int bmrhs_min() {                // ... of the backward solve (PARSY_BMRHS_MIN)
     static const int v = [] {
         const char* e = std::getenv("PARSY_BMRHS_MIN");
@@ -1195,6 +1202,308 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Forward chain launch for many right-hand sides, round 3 (replaces k_solve_chain_mrhs's protocol: flag + barrier +
+// staged copy per block column, 35 us per block column on the parabolic_fem-class root): the armed buffer of the
+// one-vector kernels -- the data is the flag -- and two kinds of workgroups, taken by ticket, producers first:
+//   * one per BLOCK COLUMN jb of a wide supernode (task row0 < 0), the counterpart of k_bsolve_block_mrhs's chain form:
+//       T = B_jb - sum_{k < jb} L(jb, k) X_k,     X_jb = inv(L_jj) T
+//     with the COLUMNS of the earlier blocks as the contraction index: wave v takes columns 16 v .. 16 v + 15 of every
+//     earlier block k as soon as X_k is there (lane (row, kk) holds L[cb + row][64 k + 16 v + 4 st + kk]: 128-byte
+//     segments along the rows; lane (q, kk) holds X_k through the armed buffer), keeps its part of T in 16 accumulator
+//     tiles, the four parts are subtracted from the staged B in a fixed order, the product with the inverse diagonal
+//     block (DIAG_INVERSE) is on the matrix cores too; only the last k is on the chain's critical path (the loads of
+//     L(jb, k) are issued before the wait);
+//   * one per 256-ROW CHUNK of the rows below the supernode's own columns (row0 >= w): the running update of its rows
+//     over ALL block columns in accumulator layout, each X_jb staged through LDS as soon as it is published, one
+//     atomicAdd per (row, right-hand side) at the end (reference Triangular_BCSC.h:139-157: the `omp atomic` scatter).
+// 64 right-hand sides per pass over L.  Every wait is bounded and watches the solve's status word.
+// ---------------------------------------------------------------------------
+#define TSF(c, q) ts[(c) * kLdXm + (q)]
+__global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc* __restrict__ sn,
+                                                                   const PanelDesc* __restrict__ pds,
+                                                                   const int32_t* __restrict__ rows,
+                                                                   const double* __restrict__ L,
+                                                                   const double* __restrict__ dinv,
+                                                                   double* __restrict__ x, double* __restrict__ xscratch,
+                                                                   int nrhs, int ldx, int* __restrict__ info,
+                                                                   int* __restrict__ ticket, int wait_bias, int ntasks) {
+    __shared__ double Dg[kTile * kLdDiag];   // block task: inverse diagonal block, Dg[k][row] = inv(L_jj)[row][k]
+    __shared__ double ts[kTile * kLdXm];     // block task: T / X_jb as [row][q]; chunk task: the staged X_jb as [col][q]
+    __shared__ int32_t s_task, s_ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    if (tid == 0) {
+        s_task = atomicAdd(ticket, 1);
+        s_ok = 1;
+    }
+    __syncthreads();
+    const int plane = s_task / ntasks;
+    const PanelDesc pd = pds[s_task - plane * ntasks];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w;
+    const int nbc = (w + kTile - 1) / kTile;
+    const double* __restrict__ G = L + D.px;
+    // all lanes of a wave: true when every value of `vals` differs from the armed pattern
+    auto give_up = [&](unsigned long long t0, int& spins) {
+        return (++spins & 15) == 0 && (wall_clock64() - t0 > kSolveSpinTicks ||
+                                       __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0);
+    };
+
+    if (pd.row0 < 0) {
+        // ================= a block column of the triangle =================
+        // Every wave works for itself on 16 right-hand sides and ALL 64 rows of the block -- no LDS traffic and no
+        // barrier on the chain's path: lane (q, kk) keeps T[4 st + kk][q], st = 0..15, in registers (the accumulator
+        // layout of v_mfma_f64_16x16x4_f64 -- lane (q, kk) holds rows kk + 4 v of a 16-row group -- IS the B-operand
+        // layout of the product with the inverse block: k step st = 4 rg + v), the rows of L(jb, k) come straight from
+        // the panel as A operands (each wave reads all of them: L2 hits for three of the four).
+        const int jb = pd.jb, cb = jb * kTile, wbk = min(kTile, w - cb);
+        {   // inverse diagonal block -> LDS (the only shared data; one barrier per task)
+            const double* __restrict__ inv_blk = dinv + (int64_t)(D.dslot + jb) * (kTile * kTile);
+            double dtmp[kTile * kTile / kThreads];
+#pragma unroll
+            for (int t = 0; t < kTile * kTile / kThreads; ++t) dtmp[t] = inv_blk[t * kThreads + tid];
+#pragma unroll
+            for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+                const int e = t * kThreads + tid;
+                Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+            }
+        }
+        __syncthreads();
+        // this lane's rows of the block as A operand: row 16 rg + l15 (clamped into the block)
+        const double* __restrict__ arow[4];
+        bool aok[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            aok[rg] = 16 * rg + l15 < wbk;
+            arow[rg] = G + cb + min(16 * rg + l15, wbk - 1);
+        }
+        for (int pass = plane; pass * kRhsM < nrhs; pass += kPassLanes) {
+            const int q0 = pass * kRhsM;
+            const int nq = min(kRhsM, nrhs - q0);
+            if (16 * wave >= nq) continue;             // (this wave's 16 right-hand sides are not in the pass)
+            const bool qok = 16 * wave + l15 < nq;
+            const int64_t qoff = (int64_t)(q0 + min(16 * wave + l15, nq - 1)) * ldx + D.c0;
+            const double* __restrict__ xq = xscratch + qoff;      // this lane's right-hand side in the armed buffer
+            // B_jb (with every contribution of the levels below): rows 4 st + kq
+            double tv[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int c = 4 * st + kq;
+                const double v = x[qoff + cb + min(c, wbk - 1)];
+                tv[st] = (qok && c < wbk) ? v : 0.0;
+            }
+            double4_s acc[4];   // [16 rows rg]: lane (q = l15, row = kq + 4 v)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[rg] = double4_s{0, 0, 0, 0};
+            bool ok = true;
+            for (int k = 0; k < jb && ok; ++k) {
+                // L(jb, k): columns 64 k + 4 st + kq, issued before the wait for X_k
+                double av[16][4];
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const int64_t col = (int64_t)(k * kTile + 4 * st + kq) * r;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const double a = arow[rg][col];
+                        av[st][rg] = aok[rg] ? a : 0.0;
+                    }
+                }
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                // only the block right before this one is on the critical path: a workgroup further down the chain
+                // first watches ONE value of X_k lazily, then goes on to the full poll (normally satisfied at once)
+                if (jb - k > 1) {
+                    const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + k * kTile + 63);
+                    while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
+                        if (give_up(t0, spins)) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(48);
+                    }
+                }
+                double bv[16];
+                while (ok) {
+                    bool in = true;
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const long long b = __hip_atomic_load(reinterpret_cast<const long long*>(xq + k * kTile + 4 * st + kq),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        in = in && b != kXArmed;
+                        bv[st] = qok ? __longlong_as_double(b) : 0.0;
+                    }
+                    if (__all((in || !qok) && wait_bias == 0)) break;
+                    if (give_up(t0, spins)) ok = false;
+                    else __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) break;
+#pragma unroll
+                for (int st = 0; st < 16; ++st)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        acc[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st][rg], bv[st], acc[rg], 0, 0, 0);
+            }
+            if (!ok) {   // a hand-off timed out: reported; this block's x stays armed, its waiters give up on the status word
+                if (lane == 0) atomicMin(info, -1);
+                return;
+            }
+            // T = B - sum: k step st = 4 rg + v of the product with the inverse block
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tv[4 * rg + v] -= acc[rg][v];
+            // X_jb = inv(L_jj) T (row group rg needs k <= 16 rg + 15)
+            double4_s out[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) out[rg] = double4_s{0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (st < 4 * rg + 4)
+                        out[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(4 * st + kq) * kLdDiag + 16 * rg + l15], tv[st], out[rg], 0, 0, 0);
+            // straight from the accumulators to x and the armed buffer (lane (q = l15, row = kq + 4 v))
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = 16 * rg + kq + 4 * v;
+                    if (c < wbk && qok) {
+                        __hip_atomic_store(&xscratch[qoff + cb + c], unarmed(out[rg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        x[qoff + cb + c] = out[rg][v];
+                    }
+                }
+        }
+        return;
+    }
+
+    // ================= a 256-row chunk of the rows below the supernode's columns =================
+    const int row0 = pd.row0;
+    const int wrow0 = row0 + 64 * wave;                 // first panel row of this wave
+    int prow[4];                                        // this lane's row of each 16-row fragment (-1: past the panel)
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) prow[rf] = (wrow0 + 16 * rf + l15 < r) ? wrow0 + 16 * rf + l15 : -1;
+    const bool wave_on = wrow0 < r;
+    for (int pass = plane; pass * kRhsM < nrhs; pass += kPassLanes) {
+        const int q0 = pass * kRhsM;
+        const int nq = min(kRhsM, nrhs - q0);
+        const int nfn = (nq + 15) >> 4;                 // 16-wide fragments of right-hand sides in use
+        double4_s acc[4][4];                            // [fragment of right-hand sides][fragment of rows]
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int rf = 0; rf < 4; ++rf) acc[nf][rf] = double4_s{0, 0, 0, 0};
+        for (int jb = 0; jb < nbc; ++jb) {
+            const int cb = jb * kTile, wbk = min(kTile, w - cb);
+            // this wave's rows of L against block column jb, in B-operand layout: issued before the wait for X_jb
+            double lv[4][16];
+            if (wave_on) {
+#pragma unroll
+                for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int c = 4 * st + kq;
+                        const bool okl = prow[rf] >= 0 && c < wbk;
+                        lv[rf][st] = okl ? G[(int64_t)(cb + min(c, wbk - 1)) * r + max(prow[rf], 0)] : 0.0;
+                    }
+            }
+            __syncthreads();  // ts of the previous block column is free
+            // X_jb through the armed buffer into LDS: thread (c = tid & 63, q = (tid >> 6) + 4 u)
+            {
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                const int c = tid & 63;
+                double xv[kRhsM / 4];
+                bool ok = true;
+                if (c < wbk) {
+                    // (a chunk far behind the chain first watches one value lazily)
+                    const long long* __restrict__ watch =
+                        reinterpret_cast<const long long*>(xscratch + (int64_t)q0 * ldx + D.c0 + cb + c);
+                    while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
+                        if (give_up(t0, spins)) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    while (ok) {
+                        bool in = true;
+#pragma unroll
+                        for (int u = 0; u < kRhsM / 4; ++u) {
+                            const int q = (tid >> 6) + 4 * u;
+                            long long b = 0;
+                            if (q < nq)
+                                b = __hip_atomic_load(reinterpret_cast<const long long*>(
+                                                          xscratch + (int64_t)(q0 + q) * ldx + D.c0 + cb + c),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            xv[u] = __longlong_as_double(b);
+                        }
+                        if (in) break;
+                        if (give_up(t0, spins)) ok = false;
+                        else __builtin_amdgcn_s_sleep(1);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kRhsM / 4; ++u) xv[u] = 0.0;
+                }
+                if (!ok) {
+                    atomicMin(info, -1);
+                    s_ok = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < kRhsM / 4; ++u) TSF(c, (tid >> 6) + 4 * u) = xv[u];
+            }
+            __syncthreads();
+            if (!s_ok) return;
+            // accumulator += x_jb' L(rows, jb)'
+            if (wave_on) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    if (nf < nfn) {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) {
+                            const double av = TSF(4 * st + kq, 16 * nf + l15);
+#pragma unroll
+                            for (int rf = 0; rf < 4; ++rf)
+                                acc[nf][rf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv[rf][st], acc[nf][rf], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // x[row] -= accumulated update
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+            if (prow[rf] >= 0) {
+                const int xrow = rows[D.pi + prow[rf]];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int q = 16 * nf + kq + 4 * v;
+                        if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + xrow], -acc[nf][rf][v]);
+                    }
+            }
+        }
+    }
+}
+#undef TSF
+
+void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
+                              double* x, double* xscratch, int nrhs, int ldx, int ticket, int wait_bias,
+                              hipStream_t stream) {
+    if (count <= 0) return;
+    const int lanes_m = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
+    hipLaunchKernelGGL(k_solve_blocks_mrhs, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn, P.solve_mtasks + first,
+                       P.rows, L, dinv, x, xscratch, nrhs, ldx, P.sinfo, P.stickets + ticket, wait_bias, count);
+}
+
+// the many-right-hand-side kernels start at this many right-hand sides (the executor arms the hand-off buffer for them)
+int solve_mrhs_min() { return chain_mrhs_min(); }
+
 // One right-hand side: the chain launches hand x over through xscratch itself (k_solve_chain_w); every entry must
 // hold the armed pattern when the solve starts.
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream) {
@@ -1205,7 +1514,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream) {
     if (count <= 0) return;
-    if (nrhs >= mrhs_min()) {
+    if (nrhs >= chain_mrhs_min()) {
         const int lanes_m = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
         hipLaunchKernelGGL(k_solve_chain_mrhs, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn,
                            P.solve_panels + first, P.rows, L, dinv, x, xscratch, nrhs, ldx, P.flags, epoch0, P.sinfo,

@@ -55,10 +55,11 @@ def test_factor_residual_dense(api, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
-@pytest.mark.parametrize("nrhs", [1, 3, 8, 16, 19, 64, 70])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 6, 8, 16, 19, 64, 70])
 def test_solve_matches_oracle(api, oracle, name, nrhs):
-    """nrhs >= 16 takes the many-right-hand-side kernels (64 per pass over a panel, MFMA products): every
-    column is checked against the oracle's one-vector solve."""
+    """From 2 right-hand sides on the wide supernodes' chain, from 6 on the narrow supernodes too take the
+    many-right-hand-side kernels (64 per pass over a panel, MFMA products): every column is checked against the
+    oracle's one-vector solve."""
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(1)
     b1 = oracle.rhs_init_blocked(sym, lo)  # b = L * 1  (common/Util.h:277)
@@ -69,6 +70,22 @@ def test_solve_matches_oracle(api, oracle, name, nrhs):
         assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
     assert np.abs(X[:, 0] - 1.0).max() <= 1e-9
     assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(np.ascontiguousarray(X[:, 0]))) == 1
+
+
+@pytest.mark.parametrize("nrhs", [3, 19])
+def test_solve_flag_protocol_chain_matches_oracle(api, oracle, monkeypatch, nrhs):
+    """PARSY_OLD_MRHS_CHAIN=1: the chain launches of rounds 1-2 (flags + staged copies per block column; 8 right-hand
+    sides per pass below 16) stay available as a fallback and stay correct."""
+    monkeypatch.setenv("PARSY_OLD_MRHS_CHAIN", "1")
+    monkeypatch.setenv("PARSY_MRHS_MIN", "16")
+    A, sym, plan, lv, lo = _factor_both(api, oracle, "lap30")
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((sym.n, nrhs))
+    X, _ = plan.solve(lo, B)
+    assert plan.solve_status() == 0
+    for q in range(nrhs):
+        xo = oracle.blocked_lsolve(sym, lo, B[:, q], "serial")
+        assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
 
 
 # ---------------------------------------------------------------------------
