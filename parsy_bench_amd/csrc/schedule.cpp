@@ -924,7 +924,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                 for (int t : sbigs)
                     for (int jb = 0; jb * kTile < S.sn[t].w; ++jb) S.solve_mtasks.push_back(PanelDesc{t, jb, -1, 0});
                 for (int t : sbigs)
-                    for (int c = 0, row0 = S.sn[t].w; row0 < S.sn[t].r; ++c, row0 += kSolveRows)
+                    for (int c = 0, row0 = S.sn[t].w; row0 < S.sn[t].r; ++c, row0 += kSolveRowsMrhs)
                         S.solve_mtasks.push_back(PanelDesc{t, c, row0, 0});
                 Lc.wait_level = (int32_t)S.solve_mtasks.size() - Lc.lds_bytes;
                 S.solve.push_back(Lc);
@@ -1203,7 +1203,7 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
                                 if (next_block[pd.sn] != ceil_div(T.w, kTile)) fail("forward chain launch: row chunk before the supernode's block columns");
                                 if (next_row[pd.sn] < 0) next_row[pd.sn] = T.w;
                                 if (pd.row0 != next_row[pd.sn] || pd.row0 >= T.r) fail("forward chain launch: row chunks do not tile the rows below");
-                                next_row[pd.sn] = pd.row0 + kSolveRows;
+                                next_row[pd.sn] = pd.row0 + kSolveRowsMrhs;
                             }
                         }
                         for (int q = l.first; q < l.first + l.count; ++q) {

@@ -52,6 +52,7 @@ constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solv
 constexpr int kTinyWidth2 = 32;
 constexpr int kPanelRows = 128;       // TRSM row chunk per workgroup (staged in LDS)
 constexpr int kSolveRows = 256;       // solve row chunk per workgroup
+constexpr int kSolveRowsMrhs = 128;   // ... of the many-right-hand-side chain launches (k_solve_blocks_mrhs: 32 rows per wave)
 
 struct SnDesc {       // one per supernode
     int64_t px;       // offset of the panel in lValues

@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_solve_chain_w(const SnDesc
 // with atomics, as in the one-vector kernel.
 static constexpr int kMrhsWideBlocks = 128;   // backward launches of at least this many blocks take 64 right-hand sides per pass
 static constexpr int kLdXm = kRhsM + 16;  // row stride of the staged x_jb / t_jb (doubles): conflict-free operand reads
+static constexpr int kSolveRowsM = kSolveRowsMrhs;   // rows of a chunk task of k_solve_blocks_mrhs (schedule.hpp)
 
 __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* __restrict__ sn,
                                                                   const PanelDesc* __restrict__ pds,
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* 
 //     tiles, the four parts are subtracted from the staged B in a fixed order, the product with the inverse diagonal
 //     block (DIAG_INVERSE) is on the matrix cores too; only the last k is on the chain's critical path (the loads of
 //     L(jb, k) are issued before the wait);
-//   * one per 256-ROW CHUNK of the rows below the supernode's own columns (row0 >= w): the running update of its rows
+//   * one per 128-ROW CHUNK of the rows below the supernode's own columns (row0 >= w): the running update of its rows
 //     over ALL block columns in accumulator layout, each X_jb staged through LDS as soon as it is published, one
 //     atomicAdd per (row, right-hand side) at the end (reference Triangular_BCSC.h:139-157: the `omp atomic` scatter).
 // 64 right-hand sides per pass over L.  Every wait is bounded and watches the solve's status word.
@@ -1379,39 +1380,46 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
         return;
     }
 
-    // ================= a 256-row chunk of the rows below the supernode's columns =================
+    // ================= a 128-row chunk of the rows below the supernode's columns =================
+    // wave = 32 rows; its rows of L against block column jb + 1 are loaded while block column jb is multiplied (two
+    // register sets: with one set and 64 rows per wave the loads had only the hand-off to hide behind, and the one wave
+    // per SIMD that fits waited for them: 16 TFLOP/s on the Flan-class input)
     const int row0 = pd.row0;
-    const int wrow0 = row0 + 64 * wave;                 // first panel row of this wave
-    int prow[4];                                        // this lane's row of each 16-row fragment (-1: past the panel)
+    const int wrow0 = row0 + (kSolveRowsM / 4) * wave;   // first panel row of this wave
+    int prow[2];                                         // this lane's row of each 16-row fragment (-1: past the panel)
 #pragma unroll
-    for (int rf = 0; rf < 4; ++rf) prow[rf] = (wrow0 + 16 * rf + l15 < r) ? wrow0 + 16 * rf + l15 : -1;
+    for (int rf = 0; rf < 2; ++rf) prow[rf] = (wrow0 + 16 * rf + l15 < r && 16 * rf + (kSolveRowsM / 4) * wave < kSolveRowsM)
+                                                   ? wrow0 + 16 * rf + l15 : -1;
     const bool wave_on = wrow0 < r;
+    auto load_l = [&](int jb, double (&lv)[2][16]) {
+        const int cb = jb * kTile, wbk = min(kTile, w - cb);
+        if (!wave_on || jb >= nbc) return;
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int c = 4 * st + kq;
+                const bool okl = prow[rf] >= 0 && c < wbk;
+                const double v = G[(int64_t)(cb + min(c, wbk - 1)) * r + max(prow[rf], 0)];
+                lv[rf][st] = okl ? v : 0.0;
+            }
+    };
     for (int pass = plane; pass * kRhsM < nrhs; pass += kPassLanes) {
         const int q0 = pass * kRhsM;
         const int nq = min(kRhsM, nrhs - q0);
         const int nfn = (nq + 15) >> 4;                 // 16-wide fragments of right-hand sides in use
-        double4_s acc[4][4];                            // [fragment of right-hand sides][fragment of rows]
+        double4_s acc[4][2];                            // [fragment of right-hand sides][fragment of rows]
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-            for (int rf = 0; rf < 4; ++rf) acc[nf][rf] = double4_s{0, 0, 0, 0};
-        for (int jb = 0; jb < nbc; ++jb) {
+            for (int rf = 0; rf < 2; ++rf) acc[nf][rf] = double4_s{0, 0, 0, 0};
+        double lvA[2][16], lvB[2][16];
+        load_l(0, lvA);
+        // one block column: stage X_jb (armed buffer -> LDS), start the loads of the next one, multiply
+        auto step = [&](int jb, double (&cur)[2][16], double (&nxt)[2][16]) -> bool {
             const int cb = jb * kTile, wbk = min(kTile, w - cb);
-            // this wave's rows of L against block column jb, in B-operand layout: issued before the wait for X_jb
-            double lv[4][16];
-            if (wave_on) {
-#pragma unroll
-                for (int rf = 0; rf < 4; ++rf)
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) {
-                        const int c = 4 * st + kq;
-                        const bool okl = prow[rf] >= 0 && c < wbk;
-                        lv[rf][st] = okl ? G[(int64_t)(cb + min(c, wbk - 1)) * r + max(prow[rf], 0)] : 0.0;
-                    }
-            }
             __syncthreads();  // ts of the previous block column is free
-            // X_jb through the armed buffer into LDS: thread (c = tid & 63, q = (tid >> 6) + 4 u)
-            {
+            {   // thread (c = tid & 63, q = (tid >> 6) + 4 u)
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
                 const int c = tid & 63;
@@ -1457,7 +1465,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                 for (int u = 0; u < kRhsM / 4; ++u) TSF(c, (tid >> 6) + 4 * u) = xv[u];
             }
             __syncthreads();
-            if (!s_ok) return;
+            if (!s_ok) return false;
+            load_l(jb + 1, nxt);
             // accumulator += x_jb' L(rows, jb)'
             if (wave_on) {
 #pragma unroll
@@ -1467,16 +1476,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                         for (int st = 0; st < 16; ++st) {
                             const double av = TSF(4 * st + kq, 16 * nf + l15);
 #pragma unroll
-                            for (int rf = 0; rf < 4; ++rf)
-                                acc[nf][rf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv[rf][st], acc[nf][rf], 0, 0, 0);
+                            for (int rf = 0; rf < 2; ++rf)
+                                acc[nf][rf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cur[rf][st], acc[nf][rf], 0, 0, 0);
                         }
                     }
                 }
             }
+            return true;
+        };
+        for (int jb = 0; jb < nbc; jb += 2) {
+            if (!step(jb, lvA, lvB)) return;
+            if (jb + 1 < nbc && !step(jb + 1, lvB, lvA)) return;
         }
         // x[row] -= accumulated update
 #pragma unroll
-        for (int rf = 0; rf < 4; ++rf) {
+        for (int rf = 0; rf < 2; ++rf) {
             if (prow[rf] >= 0) {
                 const int xrow = rows[D.pi + prow[rf]];
 #pragma unroll
