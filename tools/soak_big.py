@@ -18,6 +18,8 @@ bad = 0
 CASES = [("lap30", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16"}, REPS),
          ("nd24k", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16"}, REPS),
          ("nd24k", {"PARSY_PIECE_WIDTH": "256", "PARSY_BIG_MINK": "64", "PARSY_PUSH_GROUP": "2"}, REPS),
+         ("nd24k", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16", "PARSY_BIG_SUPER": "2"}, REPS),
+         ("lap30", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16", "PARSY_BIG_SUPER": "4x2"}, REPS),
          ("64x64x64", {}, max(REPS // 3, 10)),
          ("flan", {}, max(REPS // 15, 5))]
 for name, env, reps in CASES:
