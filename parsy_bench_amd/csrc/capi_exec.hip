@@ -429,35 +429,6 @@ int64_t parsy_debug_launch_times(const parsy_plan* pl, double* out, int64_t cap)
     return n;
 }
 
-// Diagnostics: the subtrees of the forward solve's subtree launch as rows of (supernodes, columns, rows below the
-// subtree's columns summed over its supernodes, largest supernode width); returns their number.
-int64_t parsy_debug_solve_subtrees(const parsy_plan* pl, int32_t* out, int64_t cap) {
-    if (!pl) return -1;
-    const parsy::Schedule& S = pl->S;
-    int64_t n = 0;
-    for (const parsy::Launch& l : S.solve) {
-        if (l.kind != parsy::kLaunchSolveSmall || l.fused != 2) continue;
-        for (int b = l.first; b < l.first + l.count; ++b, ++n) {
-            if (!out || n >= cap) continue;
-            const int32_t q0 = S.solve_small_ranges[2 * (size_t)b], q1 = S.solve_small_ranges[2 * (size_t)b + 1];
-            const parsy::SnDesc& A = S.sn[(size_t)S.solve_small_list[(size_t)q0]];
-            const parsy::SnDesc& Z = S.sn[(size_t)S.solve_small_list[(size_t)q1 - 1]];
-            int64_t below = 0;
-            int wmax = 0;
-            for (int32_t q = q0; q < q1; ++q) {
-                const parsy::SnDesc& D = S.sn[(size_t)S.solve_small_list[(size_t)q]];
-                below += D.r - D.w;
-                wmax = std::max(wmax, D.w);
-            }
-            out[4 * n] = q1 - q0;
-            out[4 * n + 1] = Z.c0 + Z.w - A.c0;
-            out[4 * n + 2] = (int32_t)below;
-            out[4 * n + 3] = wmax;
-        }
-    }
-    return n;
-}
-
 int parsy_factor_begin(parsy_plan* pl, const double* d_values, double* d_lValues, void* stream, int flags) {
     if (!pl || !d_values || !d_lValues) {
         set_last_error("parsy_factor_begin: null argument");
