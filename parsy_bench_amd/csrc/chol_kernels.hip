@@ -1473,7 +1473,13 @@ static constexpr int kBigWC = PARSY_BIG_WC;    // waves along the tile's columns
                                                // task hides behind the multiplies of the others) or 2 (4 waves of 64 x 64)
 static constexpr int kBigWCols = kBigTile / kBigWC;   // columns of a wave's block (32 / 64)
 static constexpr int kBigNfc = kBigWCols / 16;        // 16-column fragments of it (2 / 4)
-static constexpr int kBigWaves = 2 * kBigWC;
+#ifndef PARSY_BIG_WR
+#define PARSY_BIG_WR 2
+#endif
+static constexpr int kBigWR = PARSY_BIG_WR;           // waves along the tile's rows: 2, or 4 (16 waves of up to 32 x 32
+                                                      // outputs: one workgroup per compute unit with PARSY_BK = 32)
+static constexpr int kBigNfr = kBigTile / kBigWR / 16;   // 16-row fragments of a wave's block (4 / 2)
+static constexpr int kBigWaves = kBigWR * kBigWC;
 static constexpr int kBigThreads = 64 * kBigWaves;
 static_assert(kBK % 4 == 0 && kBK % kBigWaves == 0 && kBigWaves >= 4, "k_chol_big: a wave stages kBK / waves columns per operand");
 struct BigLds {
@@ -1487,7 +1493,7 @@ __device__ __forceinline__ void glds16(const double* g, double* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* __restrict__ sn,
+__global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) void k_chol_big(const SnDesc* __restrict__ sn,
                                                              const int32_t* __restrict__ relpos,
                                                              const WaveEntry* __restrict__ ents,
                                                              const TileDesc* __restrict__ tasks,
@@ -1580,14 +1586,14 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     int64_t ce = e_begin;
     int ck = 0;
     WaveEntry CE = LE;
-    double4_t acc[kBigNfc][4];  // [16-row fragment of the column window][... of the row window]
+    double4_t acc[kBigNfc][kBigNfr];  // [16-row fragment of the column window][... of the row window]
 #pragma unroll
     for (int a = 0; a < kBigNfc; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
+        for (int b = 0; b < kBigNfr; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
 
     // The wave's block of an entry: the 16-row fragments the source has in the two windows (NR x NC, <= 8 x 8) are
-    // dealt EVENLY over the 2 x kBigWC waves -- ceil(NR / 2) x ceil(NC / kBigWC) fragments each, from fragment
+    // dealt EVENLY over the kBigWR x kBigWC waves -- ceil(NR / kBigWR) x ceil(NC / kBigWC) fragments each, from fragment
     // (fr0, fc0) on -- not in fixed 64 x 32 blocks: on the Flan-class input two thirds of the chunks have ragged
     // windows, and with fixed blocks the busiest wave of a workgroup multiplies 7.3 fragments per k step while the
     // average wave has 4.5 (tools/big_stats.py); the others wait for it at the chunk barrier.  Dealt evenly the
@@ -1596,7 +1602,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
     auto frags = [&](const WaveEntry& E, int& nfr, int& nfc, int& r0, int& c0) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const int NR = (mi + 15) >> 4, NC = (nj + 15) >> 4;
-        const int frb = (NR + 1) >> 1, fcb = (NC + kBigWC - 1) / kBigWC;
+        const int frb = (NR + kBigWR - 1) / kBigWR, fcb = (NC + kBigWC - 1) / kBigWC;
         r0 = 16 * frb * wr;
         c0 = 16 * fcb * wc;
         nfr = min(frb, max(0, NR - frb * wr));
@@ -1619,9 +1625,9 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
         __builtin_amdgcn_s_setprio(1);
         // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
         // BIG launches on the Flan-class input)
-        double rv[2][4], cv[2][kBigNfc];
+        double rv[2][kBigNfr], cv[2][kBigNfc];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) rv[0][f] = Rb[16 * f];
+        for (int f = 0; f < kBigNfr; ++f) rv[0][f] = Rb[16 * f];
 #pragma unroll
         for (int f = 0; f < kBigNfc; ++f) cv[0][f] = Cb[16 * f];
 #pragma unroll
@@ -1629,19 +1635,19 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
             if (ks < nks) {
                 if (ks + 1 < kBK / 4 && ks + 1 < nks) {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) rv[(ks + 1) & 1][f] = Rb[4 * (ks + 1) * kBLd + 16 * f];
+                    for (int f = 0; f < kBigNfr; ++f) rv[(ks + 1) & 1][f] = Rb[4 * (ks + 1) * kBLd + 16 * f];
 #pragma unroll
                     for (int f = 0; f < kBigNfc; ++f) cv[(ks + 1) & 1][f] = Cb[4 * (ks + 1) * kBLd + 16 * f];
                 }
 #ifdef PARSY_BIGABL_NOMFMA    // (diagnostic build: operands are read from LDS and dropped)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
+                for (int f = 0; f < kBigNfr; ++f) asm volatile("" ::"v"(rv[ks & 1][f]));
 #pragma unroll
                 for (int f = 0; f < kBigNfc; ++f) asm volatile("" ::"v"(cv[ks & 1][f]));
 #else
 #ifdef PARSY_BIGABL_ZEROOPS   // (diagnostic build: the products are formed on all-zero operands -- what the data costs)
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < kBigNfr; ++f)
                     rv[ks & 1][f] = __longlong_as_double(__double_as_longlong(rv[ks & 1][f]) & zmask);
 #pragma unroll
                 for (int f = 0; f < kBigNfc; ++f)
@@ -1651,7 +1657,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
                 for (int fc = 0; fc < kBigNfc; ++fc) {
                     if (fc < nfc) {
 #pragma unroll
-                        for (int fr = 0; fr < 4; ++fr)
+                        for (int fr = 0; fr < kBigNfr; ++fr)
                             if (fr < nfr)
                                 acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[ks & 1][fc], rv[ks & 1][fr], acc[fc][fr], 0, 0, 1);
                     }
@@ -1674,7 +1680,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
 #pragma unroll
         for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
-            for (int fr = 0; fr < 4; ++fr) {
+            for (int fr = 0; fr < kBigNfr; ++fr) {
                 asm volatile("" ::"v"(acc[fc][fr]));
                 acc[fc][fr] = double4_t{0, 0, 0, 0};
             }
@@ -1685,10 +1691,10 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
         // (the index loads are unconditional -- rows past the window re-read its last one -- so that all twelve are
         // in flight together: guarded per lane, the compiler waited for each of them in turn; loading them before the
         // source's last chunk is multiplied, so that they land behind it, cost more in registers than it hid)
-        int prow[4], pcol[kBigNfc][4];
+        int prow[kBigNfr], pcol[kBigNfc][4];
         if (ident) {
 #pragma unroll
-            for (int fr = 0; fr < 4; ++fr) prow[fr] = E.ia + r0 + 16 * fr + l15;
+            for (int fr = 0; fr < kBigNfr; ++fr) prow[fr] = E.ia + r0 + 16 * fr + l15;
 #pragma unroll
             for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
@@ -1697,20 +1703,20 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
             const int32_t* __restrict__ rpi = relpos + (int64_t)E.rel + E.ia;
             const int32_t* __restrict__ rpj = relpos + (int64_t)E.rel + E.ja;
 #pragma unroll
-            for (int fr = 0; fr < 4; ++fr) prow[fr] = rpi[min(r0 + 16 * fr + l15, mi - 1)];
+            for (int fr = 0; fr < kBigNfr; ++fr) prow[fr] = rpi[min(r0 + 16 * fr + l15, mi - 1)];
 #pragma unroll
             for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) pcol[fc][v] = rpj[min(c0 + 16 * fc + kq + 4 * v, nj - 1)];
 #pragma unroll
-            for (int fr = 0; fr < 4; ++fr) prow[fr] -= D.rbias;
+            for (int fr = 0; fr < kBigNfr; ++fr) prow[fr] -= D.rbias;
 #pragma unroll
             for (int fc = 0; fc < kBigNfc; ++fc)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) pcol[fc][v] -= D.rbias;
         }
 #pragma unroll
-        for (int fr = 0; fr < 4; ++fr)
+        for (int fr = 0; fr < kBigNfr; ++fr)
             if (fr >= nfr || r0 + 16 * fr + l15 >= mi) prow[fr] = -1;
 #pragma unroll
         for (int fc = 0; fc < kBigNfc; ++fc)
@@ -1721,7 +1727,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
         for (int fc = 0; fc < kBigNfc; ++fc) {
             if (fc < nfc) {
 #pragma unroll
-                for (int fr = 0; fr < 4; ++fr)
+                for (int fr = 0; fr < kBigNfr; ++fr)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const bool ok = prow[fr] >= 0 && pcol[fc][v] >= 0 && prow[fr] >= pcol[fc][v];
@@ -1729,7 +1735,7 @@ __global__ __launch_bounds__(kBigThreads, kBigWC) void k_chol_big(const SnDesc* 
                     }
             }
 #pragma unroll
-            for (int fr = 0; fr < 4; ++fr) acc[fc][fr] = double4_t{0, 0, 0, 0};
+            for (int fr = 0; fr < kBigNfr; ++fr) acc[fc][fr] = double4_t{0, 0, 0, 0};
         }
     };
 
