@@ -337,6 +337,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     }
     std::vector<int8_t> launch_super((size_t)2 * std::max(S.cnlevels, 1), 1);
     if (env_sr == 0 && !S.solve_only) {
+        // (PARSY_BIG_SUPER_MIN / PARSY_BIG_SUPER_FILL: the two thresholds, diagnostics; fill in percent)
+        const int64_t super_min_tasks = env_int("PARSY_BIG_SUPER_MIN", kBigSuperMinTasks);
+        const double super_max_fill = env_int("PARSY_BIG_SUPER_FILL", (int)(kBigSuperMaxFill * 100 + 0.5)) / 100.0;
         std::vector<int64_t> ltasks(launch_super.size(), 0);
         std::vector<double> lfrag(launch_super.size(), 0.0), lchunks(launch_super.size(), 0.0);
         std::vector<int64_t> keys;
@@ -376,7 +379,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             for (int64_t k : keys) ltasks[(size_t)(k >> 40)]++;
         }
         for (size_t l = 0; l < launch_super.size(); ++l)
-            if (ltasks[l] >= kBigSuperMinTasks && lfrag[l] < kBigSuperMaxFill * 64.0 * lchunks[l]) launch_super[l] = 2;
+            if (ltasks[l] >= super_min_tasks && lfrag[l] < super_max_fill * 64.0 * lchunks[l]) launch_super[l] = 2;
     }
     S.big_super_r = env_sr;
     S.big_super_c = env_sc;
