@@ -175,6 +175,7 @@ void plan_free(parsy_plan* pl) {
         for (void* d : pl->owned) (void)hipFree(d);
         for (void* d : pl->launch_owned) (void)hipFree(d);
         if (pl->xscratch) (void)hipFree(pl->xscratch);
+        if (pl->xt) (void)hipFree(pl->xt);
         if (pl->dinv) (void)hipFree(pl->dinv);
         if (pl->h_values_dev) (void)hipFree(pl->h_values_dev);
         if (pl->h_L_dev) (void)hipFree(pl->h_L_dev);
@@ -267,11 +268,11 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                 }
                 break;
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
-            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, stream); break;
+            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, pl->solve_ldq, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused && nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain)
                     launch_solve_blocks_mrhs(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
-                                             l.jb, pl->solve_wait_bias, stream);
+                                             pl->solve_ldq, l.jb, pl->solve_wait_bias, stream);
                 else if (l.fused)
                     launch_solve_chain(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
                                        pl->epoch, l.jb, pl->solve_wait_bias, stream);
@@ -484,10 +485,27 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
-    const int64_t need = (int64_t)ldx * nrhs;
     // one epoch per pass of right-hand sides (what the chain kernel publishes / waits for)
     const int passes = (nrhs + 7) / 8;
     if (solve_begin(pl, passes, stream) != 0) return -1;
+    // (many right-hand sides: k_solve_blocks_mrhs on the armed buffer; PARSY_OLD_MRHS_CHAIN=1: the flag protocol of rounds 1-2)
+    {
+        const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
+        pl->old_mrhs_chain = e && e[0] == '1';
+    }
+    // From 16 right-hand sides on the solve works on X with the right-hand sides of a row contiguous (transposed in
+    // and out: both kernels a solve of that many takes -- k_solve_small_mrhs, k_solve_blocks_mrhs -- read and write
+    // whole rows then; a supernode's x block was 64 eight-byte pieces per column).  PARSY_XT_MIN=k (0: never).
+    const char* xt_env = std::getenv("PARSY_XT_MIN");
+    const int xt_min = xt_env && *xt_env ? std::atoi(xt_env) : 16;
+    // (measured, 64 right-hand sides: Flan-class 23.1 -> 20.4 ms, nd24k-class 1.31 -> 1.19 ms; parabolic_fem-class 1.72 ->
+    // 1.75 ms -- its factor has 67 entries per row and the two transposes, 0.3 ms, cost what the kernels gain: the layout
+    // is taken from 200 entries of L per row on)
+    const bool use_xt = xt_min > 0 && nrhs >= xt_min && nrhs >= solve_small_mrhs_min() && nrhs >= solve_mrhs_min() &&
+                        !pl->old_mrhs_chain && pl->S.solve_fix_list.empty() &&
+                        (pl->S.xsize >= (int64_t)200 * pl->S.n || (xt_env && *xt_env));
+    const int ldq = use_xt ? (nrhs + 15) & ~15 : 0;
+    const int64_t need = use_xt ? (int64_t)pl->S.n * ldq : (int64_t)ldx * nrhs;
     if (pl->S.n_solve_wide > 0 && pl->xscratch_len < need) {
         // grows only when a larger right-hand-side block shows up (not per call)
         if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
@@ -495,23 +513,29 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
         pl->xscratch_len = need;
     }
+    if (use_xt && pl->xt_len < need) {
+        if (pl->xt) PARSY_HIP(hipFree(pl->xt));
+        pl->xt = nullptr;
+        PARSY_HIP(hipMalloc((void**)&pl->xt, (size_t)need * sizeof(double)));
+        pl->xt_len = need;
+    }
     if (!pl->S.solve_wide_list.empty() && !pl->dinv) {
         const size_t bytes = (size_t)std::max<int64_t>(pl->S.n_dslots, 1) * kTile * kTile * sizeof(double);
         PARSY_HIP(hipMalloc((void**)&pl->dinv, bytes));
         pl->device_bytes += (int64_t)bytes;
     }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
-    // one right-hand side: the chain launches hand x over through xscratch itself
-    // (many right-hand sides: likewise, k_solve_blocks_mrhs; PARSY_OLD_MRHS_CHAIN=1: the flag protocol of rounds 1-2)
-    {
-        const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
-        pl->old_mrhs_chain = e && e[0] == '1';
-    }
+    // the chain launches hand x over through xscratch itself (one right-hand side: k_solve_chain_w; many:
+    // k_solve_blocks_mrhs): every entry holds the armed pattern when the solve starts
     if (nrhs == 1 && pl->S.n_solve_wide > 0) PARSY_HIP(solve_arm_handoff(pl->xscratch, ldx, stream));
     else if (nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain && pl->S.n_solve_wide > 0)
         PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
-    run_launches(pl, pl->S.solve, nullptr, d_L, d_x, nrhs, ldx, stream);
+    pl->solve_ldq = ldq;
+    if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, true, stream);
+    run_launches(pl, pl->S.solve, nullptr, d_L, use_xt ? pl->xt : d_x, nrhs, ldx, stream);
+    if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, false, stream);
+    pl->solve_ldq = 0;
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
     pl->epoch += passes;

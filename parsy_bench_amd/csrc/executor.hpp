@@ -56,6 +56,9 @@ struct parsy_plan {
 
     // optional per-launch profiling (hipEvents on the launch stream)
     bool profile = false;
+    double* xt = nullptr;           // X with the right-hand sides of a row contiguous (forward solves with many of them)
+    int64_t xt_len = 0;
+    int solve_ldq = 0;              // > 0: the running solve works on xt with this row stride
     bool old_mrhs_chain = false;    // PARSY_OLD_MRHS_CHAIN=1: forward chain launches with many right-hand sides by flags
     std::vector<hipEvent_t> pev;
     std::vector<int> pev_kind;

@@ -60,16 +60,18 @@ void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket,
                        hipStream_t stream);
 
 void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
-                        double* x, int nrhs, int ldx, hipStream_t stream);
+                        double* x, int nrhs, int ldx, int ldq, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                         double* x, double* xscratch, int nrhs, int ldx, int epoch0, int ticket, int wait_bias,
                         hipStream_t stream);
 void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                              double* x, double* xscratch, int nrhs, int ldx, int ticket, int wait_bias,
+                              double* x, double* xscratch, int nrhs, int ldx, int ldq, int ticket, int wait_bias,
                               hipStream_t stream);
+void launch_transpose_x(double* x, int64_t ldx, double* xt, int64_t ldq, int n, int nrhs, bool to_rows, hipStream_t stream);
 int solve_mrhs_min();
+int solve_small_mrhs_min();
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);

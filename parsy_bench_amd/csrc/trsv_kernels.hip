@@ -279,7 +279,13 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
                                                                const int32_t* __restrict__ ranges,
                                                                const int32_t* __restrict__ rows,
                                                                const double* __restrict__ L,
-                                                               double* __restrict__ x, int nrhs, int ldx) {
+                                                               double* __restrict__ x, int nrhs, int ldx, int ldq) {
+    // X is addressed as x[row * sr + q * sq]: right-hand-side-major (the interface: sr = 1, sq = ldx) or, inside a
+    // solve with many right-hand sides, row-major with the right-hand sides of a row contiguous (ldq > 0: sr = ldq,
+    // sq = 1 -- a supernode's x block and its write-back are then whole 512-byte rows instead of 64 eight-byte pieces
+    // per column, and the thread -> (column, right-hand side) maps of the copies follow the contiguous index)
+    const bool tr = ldq > 0;
+    const int64_t sr = tr ? ldq : 1, sq = tr ? 1 : ldx;
     constexpr int kLd = WMAX + 1;
     __shared__ double Dg[WMAX * kLd];
     __shared__ double invd[WMAX];
@@ -332,8 +338,8 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
         const int nq = min(kRhsM, nrhs - q0);
         __syncthreads();  // inverses written / xs of the previous pass consumed
         for (int e = tid; e < WMAX * kRhsM; e += kThreads) {
-            const int q = e / WMAX, c = e - q * WMAX;
-            xs[c * kLdXs + q] = (c < w && q < nq) ? ld_x(&x[(int64_t)(q0 + q) * ldx + D.c0 + c]) : 0.0;
+            const int q = tr ? e % kRhsM : e / WMAX, c = tr ? e / kRhsM : e - q * WMAX;
+            xs[c * kLdXs + q] = (c < w && q < nq) ? ld_x(&x[(D.c0 + c) * sr + (q0 + q) * sq]) : 0.0;
         }
         __syncthreads();
         // ---- (A) wave `wave` solves its 16 right-hand sides
@@ -370,8 +376,8 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
         }
         __syncthreads();
         for (int e = tid; e < w * nq; e += kThreads) {
-            const int q = e / w, c = e - q * w;
-            x[(int64_t)(q0 + q) * ldx + D.c0 + c] = xs[c * kLdXs + q];
+            const int q = tr ? e % nq : e / w, c = tr ? e / nq : e - q * w;
+            x[(D.c0 + c) * sr + (q0 + q) * sq] = xs[c * kLdXs + q];
         }
         // ---- (B) rows below the diagonal block
         const int nfrag_n = (nq + 15) >> 4;
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int q = 16 * n + kq + 4 * v;
-                            if (rok && q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + xrow], -acc[v]);
+                            if (rok && q < nq) atomicAdd(&x[xrow * sr + (q0 + q) * sq], -acc[v]);
                         }
                     }
                 }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
 }
 
 void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
-                        double* x, int nrhs, int ldx, hipStream_t stream) {
+                        double* x, int nrhs, int ldx, int ldq, hipStream_t stream) {
     if (count <= 0) return;
     // subtree launch: `first` counts (begin, end) pairs of solve_small_ranges, which index the whole list
     const int32_t* list = subtrees ? P.solve_small_list : P.solve_small_list + first;
@@ -426,13 +432,13 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
     if (nrhs >= mrhs_min()) {
         if (wmax <= 16)
             hipLaunchKernelGGL(k_solve_small_mrhs<16>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
-                               P.rows, L, x, nrhs, ldx);
+                               P.rows, L, x, nrhs, ldx, ldq);
         else if (wmax <= 32)
             hipLaunchKernelGGL(k_solve_small_mrhs<32>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
-                               P.rows, L, x, nrhs, ldx);
+                               P.rows, L, x, nrhs, ldx, ldq);
         else
             hipLaunchKernelGGL(k_solve_small_mrhs<64>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
-                               P.rows, L, x, nrhs, ldx);
+                               P.rows, L, x, nrhs, ldx, ldq);
     } else {
         hipLaunchKernelGGL(k_solve_small, dim3(count, std::min(kPassLanes, (nrhs + kRhs - 1) / kRhs)),
                            dim3(kThreads), 0, stream, P.sn, list, ranges, P.rows, L, x, nrhs, ldx);
@@ -1227,8 +1233,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                                                                    const double* __restrict__ L,
                                                                    const double* __restrict__ dinv,
                                                                    double* __restrict__ x, double* __restrict__ xscratch,
-                                                                   int nrhs, int ldx, int* __restrict__ info,
+                                                                   int nrhs, int ldx, int ldq, int* __restrict__ info,
                                                                    int* __restrict__ ticket, int wait_bias, int ntasks) {
+    // (x and the armed buffer as x[row * sr + q * sq]: k_solve_small_mrhs)
+    const bool tr = ldq > 0;
+    const int64_t sr = tr ? ldq : 1, sq = tr ? 1 : ldx;
     __shared__ double Dg[kTile * kLdDiag];   // block task: inverse diagonal block, Dg[k][row] = inv(L_jj)[row][k]
     __shared__ double ts[kTile * kLdXm];     // block task: T / X_jb as [row][q]; chunk task: the staged X_jb as [col][q]
     __shared__ int32_t s_task, s_ok;
@@ -1285,14 +1294,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
             const int nq = min(kRhsM, nrhs - q0);
             if (16 * wave >= nq) continue;             // (this wave's 16 right-hand sides are not in the pass)
             const bool qok = 16 * wave + l15 < nq;
-            const int64_t qoff = (int64_t)(q0 + min(16 * wave + l15, nq - 1)) * ldx + D.c0;
-            const double* __restrict__ xq = xscratch + qoff;      // this lane's right-hand side in the armed buffer
+            const int64_t qoff = (q0 + min(16 * wave + l15, nq - 1)) * sq + D.c0 * sr;   // this lane's right-hand side, row c0
+            const double* __restrict__ xq = xscratch + qoff;      // ... in the armed buffer
             // B_jb (with every contribution of the levels below): rows 4 st + kq
             double tv[16];
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
                 const int c = 4 * st + kq;
-                const double v = x[qoff + cb + min(c, wbk - 1)];
+                const double v = x[qoff + (cb + min(c, wbk - 1)) * sr];
                 tv[st] = (qok && c < wbk) ? v : 0.0;
             }
             double4_s acc[4];   // [16 rows rg]: lane (q = l15, row = kq + 4 v)
@@ -1316,7 +1325,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                 // only the block right before this one is on the critical path: a workgroup further down the chain
                 // first watches ONE value of X_k lazily, then goes on to the full poll (normally satisfied at once)
                 if (jb - k > 1) {
-                    const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + k * kTile + 63);
+                    const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + (k * kTile + 63) * sr);
                     while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
                         if (give_up(t0, spins)) {
                             ok = false;
@@ -1330,7 +1339,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     bool in = true;
 #pragma unroll
                     for (int st = 0; st < 16; ++st) {
-                        const long long b = __hip_atomic_load(reinterpret_cast<const long long*>(xq + k * kTile + 4 * st + kq),
+                        const long long b = __hip_atomic_load(reinterpret_cast<const long long*>(xq + (k * kTile + 4 * st + kq) * sr),
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         in = in && b != kXArmed;
                         bv[st] = qok ? __longlong_as_double(b) : 0.0;
@@ -1372,8 +1381,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                 for (int v = 0; v < 4; ++v) {
                     const int c = 16 * rg + kq + 4 * v;
                     if (c < wbk && qok) {
-                        __hip_atomic_store(&xscratch[qoff + cb + c], unarmed(out[rg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        x[qoff + cb + c] = out[rg][v];
+                        __hip_atomic_store(&xscratch[qoff + (cb + c) * sr], unarmed(out[rg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        x[qoff + (cb + c) * sr] = out[rg][v];
                     }
                 }
         }
@@ -1419,16 +1428,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
         auto step = [&](int jb, double (&cur)[2][16], double (&nxt)[2][16]) -> bool {
             const int cb = jb * kTile, wbk = min(kTile, w - cb);
             __syncthreads();  // ts of the previous block column is free
-            {   // thread (c = tid & 63, q = (tid >> 6) + 4 u)
+            {   // thread (c, q) = (tid & 63, (tid >> 6) + 4 u) -- or, X row-major, ((tid >> 6) + 4 u, tid & 63): 16 values each
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
-                const int c = tid & 63;
+                const int lo = tid & 63, hi = tid >> 6;
                 double xv[kRhsM / 4];
                 bool ok = true;
-                if (c < wbk) {
+                const bool any = tr ? lo < nq : lo < wbk;
+                if (any) {
                     // (a chunk far behind the chain first watches one value lazily)
+                    const int cw = tr ? min(hi, wbk - 1) : lo, qw = tr ? lo : 0;
                     const long long* __restrict__ watch =
-                        reinterpret_cast<const long long*>(xscratch + (int64_t)q0 * ldx + D.c0 + cb + c);
+                        reinterpret_cast<const long long*>(xscratch + (D.c0 + cb + cw) * sr + (q0 + qw) * sq);
                     while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
                         if (give_up(t0, spins)) {
                             ok = false;
@@ -1440,11 +1451,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                         bool in = true;
 #pragma unroll
                         for (int u = 0; u < kRhsM / 4; ++u) {
-                            const int q = (tid >> 6) + 4 * u;
+                            const int c = tr ? hi + 4 * u : lo, q = tr ? lo : hi + 4 * u;
                             long long b = 0;
-                            if (q < nq)
+                            if (q < nq && c < wbk)
                                 b = __hip_atomic_load(reinterpret_cast<const long long*>(
-                                                          xscratch + (int64_t)(q0 + q) * ldx + D.c0 + cb + c),
+                                                          xscratch + (D.c0 + cb + c) * sr + (q0 + q) * sq),
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             in = in && b != kXArmed;
                             xv[u] = __longlong_as_double(b);
@@ -1462,7 +1473,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     s_ok = 0;
                 }
 #pragma unroll
-                for (int u = 0; u < kRhsM / 4; ++u) TSF(c, (tid >> 6) + 4 * u) = xv[u];
+                for (int u = 0; u < kRhsM / 4; ++u) {
+                    const int c = tr ? hi + 4 * u : lo, q = tr ? lo : hi + 4 * u;
+                    TSF(c, q) = xv[u];
+                }
             }
             __syncthreads();
             if (!s_ok) return false;
@@ -1498,7 +1512,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int q = 16 * nf + kq + 4 * v;
-                        if (q < nq) atomicAdd(&x[(int64_t)(q0 + q) * ldx + xrow], -acc[nf][rf][v]);
+                        if (q < nq) atomicAdd(&x[xrow * sr + (q0 + q) * sq], -acc[nf][rf][v]);
                     }
             }
         }
@@ -1507,16 +1521,56 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
 #undef TSF
 
 void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
-                              double* x, double* xscratch, int nrhs, int ldx, int ticket, int wait_bias,
+                              double* x, double* xscratch, int nrhs, int ldx, int ldq, int ticket, int wait_bias,
                               hipStream_t stream) {
     if (count <= 0) return;
     const int lanes_m = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
     hipLaunchKernelGGL(k_solve_blocks_mrhs, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn, P.solve_mtasks + first,
-                       P.rows, L, dinv, x, xscratch, nrhs, ldx, P.sinfo, P.stickets + ticket, wait_bias, count);
+                       P.rows, L, dinv, x, xscratch, nrhs, ldx, ldq, P.sinfo, P.stickets + ticket, wait_bias, count);
+}
+
+// X between its two layouts: right-hand-side-major a[q * lda + row] <-> row-major b[row * ldb + q] (64 x 64 tiles
+// through LDS: both sides in 512-byte runs).  to_rows: a -> b, otherwise b -> a.
+__global__ __launch_bounds__(kThreads) void k_transpose_x(double* __restrict__ a, int64_t lda, double* __restrict__ b,
+                                                          int64_t ldb, int n, int nrhs, int to_rows) {
+    __shared__ double T[64][65];
+    const int tid = threadIdx.x, lo = tid & 63, hi = tid >> 6;
+    const int row0 = 64 * (int)blockIdx.x, q0 = 64 * (int)blockIdx.y;
+    if (to_rows) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = q0 + hi + 4 * u, row = row0 + lo;
+            T[hi + 4 * u][lo] = (q < nrhs && row < n) ? a[(int64_t)q * lda + row] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int row = row0 + hi + 4 * u, q = q0 + lo;
+            if (row < n && q < nrhs) b[(int64_t)row * ldb + q] = T[lo][hi + 4 * u];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int row = row0 + hi + 4 * u, q = q0 + lo;
+            T[lo][hi + 4 * u] = (row < n && q < nrhs) ? b[(int64_t)row * ldb + q] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = q0 + hi + 4 * u, row = row0 + lo;
+            if (q < nrhs && row < n) a[(int64_t)q * lda + row] = T[hi + 4 * u][lo];
+        }
+    }
+}
+void launch_transpose_x(double* x, int64_t ldx, double* xt, int64_t ldq, int n, int nrhs, bool to_rows, hipStream_t stream) {
+    if (n <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_transpose_x, dim3((n + 63) / 64, (nrhs + 63) / 64), dim3(kThreads), 0, stream, x, ldx, xt, ldq, n,
+                       nrhs, to_rows ? 1 : 0);
 }
 
 // the many-right-hand-side kernels start at this many right-hand sides (the executor arms the hand-off buffer for them)
 int solve_mrhs_min() { return chain_mrhs_min(); }
+int solve_small_mrhs_min() { return mrhs_min(); }
 
 // One right-hand side: the chain launches hand x over through xscratch itself (k_solve_chain_w); every entry must
 // hold the armed pattern when the solve starts.

@@ -72,6 +72,27 @@ def test_solve_matches_oracle(api, oracle, name, nrhs):
     assert oracle.lib().oracle_testTriangular(sym.n, oracle.P(np.ascontiguousarray(X[:, 0]))) == 1
 
 
+@pytest.mark.parametrize("name", ["ex15", "mid3d", "lap30"])
+@pytest.mark.parametrize("nrhs", [6, 16, 19, 64, 70])
+def test_solve_on_row_major_x_matches_oracle(api, oracle, monkeypatch, name, nrhs):
+    """Forward solves with many right-hand sides work on X with the right-hand sides of a row contiguous (transposed in
+    and out; by itself only for factors with >= 200 entries per row and >= 16 right-hand sides): forced here
+    (PARSY_XT_MIN), every column against the oracle, and the result must equal the right-hand-side-major path's to
+    rounding (the scatter into x is made of atomics either way)."""
+    A, sym, plan, lv, lo = _factor_both(api, oracle, name)
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((sym.n, nrhs))
+    monkeypatch.setenv("PARSY_XT_MIN", "0")
+    X0, _ = plan.solve(lo, B)
+    monkeypatch.setenv("PARSY_XT_MIN", "6")
+    X, _ = plan.solve(lo, B)
+    assert plan.solve_status() == 0
+    for q in range(nrhs):
+        xo = oracle.blocked_lsolve(sym, lo, B[:, q], "serial")
+        assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+    assert np.abs(X - X0).max() <= 1e-12 * max(1.0, np.abs(X0).max())
+
+
 @pytest.mark.parametrize("nrhs", [3, 19])
 def test_solve_flag_protocol_chain_matches_oracle(api, oracle, monkeypatch, nrhs):
     """PARSY_OLD_MRHS_CHAIN=1: the chain launches of rounds 1-2 (flags + staged copies per block column; 8 right-hand
