@@ -816,6 +816,24 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             // Group J of a supernode: the walker (J = 0 only: it owns every diagonal tile), the two tiles
             // the walker needs prepared for its step J -- (J+1,J) and (J+1,J+1) -- and then the other
             // tiles of block column J, which wait for diagonal tile J.
+            // On the largest jobs the chain takes two launches per level: the tiles of the diagonal squares with the
+            // walkers first, the tiles of the rows below the squares afterwards.  In one launch those tiles -- hundreds
+            // to thousands per piece of a top separator -- were dispatched long before the walker reached their block
+            // column and waited for it holding a workgroup slot (72 KB of LDS: one of the two k_chol_big workgroups of
+            // the PUSH launch that runs beside the chain cannot be resident on that compute unit meanwhile); in a launch
+            // of their own every diagonal tile is there when they start.  Flan-class input: 371.2 -> 365.8 ms although the
+            // chain launches by themselves take longer (56 -> 62 ms serialised); smaller jobs lose (96^3 grid, pieces
+            // only: 140.9 -> 142.6 ms; nd24k-class: 4.17 -> 4.82 ms: there the chain is the critical path), so the split
+            // is taken from kChainSplitAutoFlops update flops on.  PARSY_CHAIN_SPLIT=0: never; 1: the pieces of split
+            // supernodes only; 2: every tiled supernode (diagnostics).
+            const int chain_split_mode = env_int("PARSY_CHAIN_SPLIT", S.update_flops >= kChainSplitAutoFlops ? 2 : 0);
+            auto splits = [&](int t) {
+                const int real = S.csn_real[t];
+                return chain_split_mode == 2 || (chain_split_mode == 1 && S.piece0[real + 1] - S.piece0[real] > 1);
+            };
+            bool chain_split = false;
+            for (int t : bigs) chain_split = chain_split || splits(t);
+            for (int part = 0; part < (chain_split ? 2 : 1); ++part) {
             Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
             // Walkers stay resident for their whole chain, so the block-column-major interleaving is
             // done per batch of at most walker_batch supernodes: what a walker waits for then lies at most
@@ -832,6 +850,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                     const int nbc = ceil_div(T.w, kTile), nbr = ceil_div(T.r, kTile);
                     if (J >= nbc) continue;
                     auto push = [&](int I, int Jc) {
+                        if (chain_split && ((I < nbc || !splits(t)) != (part == 0))) return;   // square / rows below it
                         const int64_t si = S.tile_split[S.sn_tw0[t] / 2 + (size_t)Jc * nbr + I];
                         S.tiles.push_back(TileDesc{t, I * kTile, Jc * kTile,
                                                    si < 0 ? 0 : S.split_desc[(size_t)si].nparts,
@@ -848,7 +867,9 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                 }
             }
             Lc.count = (int32_t)S.tiles.size() - Lc.first;
-            S.chol.push_back(Lc);
+            if (Lc.count > 0) S.chol.push_back(Lc);
+            else --S.n_chain_launches;
+            }
         }
     }
     // splice the side launches in front of the level before the one that waits for them (stable: PUSH

@@ -704,6 +704,33 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
 
 
 # ---------------------------------------------------------------------------
+# two chain launches per level (the tiles of the diagonal squares with the walkers, then the tiles of the rows below
+# them): what the largest jobs take by themselves, forced here (PARSY_CHAIN_SPLIT).  The same tiles, updates and sums:
+# the factor must be bitwise the one-launch factor.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,piece,mink,mode", [("mid3d", 128, 16, 2), ("lap30", 128, 32, 1), ("lap30", 0, 0, 2),
+                                                  ("nd24k", 0, 0, 2), ("ex15", 128, 16, 2)])
+def test_factor_with_split_chain_launches(api, oracle, monkeypatch, name, piece, mink, mode):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    if piece:
+        monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+        monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_CHAIN_SPLIT", "0")
+    plan0 = api.Plan(sym, 0)
+    lv0, _ = plan0.factor(sym.A2x)
+    assert plan0.status() == 0
+    monkeypatch.setenv("PARSY_CHAIN_SPLIT", str(mode))
+    plan = api.Plan(sym, 0)
+    assert plan.info["chol_launches"] > plan0.info["chol_launches"]
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    assert np.array_equal(lv, lv0)
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok and np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+# ---------------------------------------------------------------------------
 # a hand-off wait of the solve's chain launches that times out is REPORTED: own status word, host
 # conveniences and drop-in solves fail, the factorization's status is untouched
 # ---------------------------------------------------------------------------

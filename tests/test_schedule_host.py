@@ -121,6 +121,29 @@ def test_super_tiles_cover_every_update_once(monkeypatch, name, piece, mink, sup
         N.lib().parsy_plan_destroy(h1)
 
 
+@pytest.mark.parametrize("name,piece,mink,mode", [("mid3d", 128, 16, 2), ("lap30", 128, 32, 1), ("nd24k", 512, 128, 2),
+                                                  ("nd24k", None, None, 2)])
+def test_split_chain_launches_are_consistent(monkeypatch, name, piece, mink, mode):
+    """Two chain launches per level (diagonal squares with the walkers / the rows below them, PARSY_CHAIN_SPLIT): every
+    tile still in exactly one launch, producers before consumers across the two, no deadlock at any residency."""
+    A, perm, sym = problem(name)
+    if piece is not None:
+        monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+        monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_CHAIN_SPLIT", "0")
+    h0, info0 = host_plan(sym)
+    monkeypatch.setenv("PARSY_CHAIN_SPLIT", str(mode))
+    h, info = host_plan(sym)
+    try:
+        assert info["chol_launches"] > info0["chol_launches"]
+        assert N.lib().parsy_plan_check(h) == 0, N.last_error()
+        for slots in (64, 512):
+            assert N.lib().parsy_plan_chain_check(h, slots) == 0
+    finally:
+        N.lib().parsy_plan_destroy(h)
+        N.lib().parsy_plan_destroy(h0)
+
+
 def test_flan_class_plan_takes_super_tiles_by_itself(monkeypatch):
     """BASELINE configs[2] at full size, host only: the launches with many ragged single-tile tasks take 2 x 2
     super-tiles without being told to (a third fewer tasks, a quarter fewer chunks), the plan checks."""
