@@ -816,16 +816,16 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             // Group J of a supernode: the walker (J = 0 only: it owns every diagonal tile), the two tiles
             // the walker needs prepared for its step J -- (J+1,J) and (J+1,J+1) -- and then the other
             // tiles of block column J, which wait for diagonal tile J.
-            // On the largest jobs the chain takes two launches per level: the tiles of the diagonal squares with the
-            // walkers first, the tiles of the rows below the squares afterwards.  In one launch those tiles -- hundreds
-            // to thousands per piece of a top separator -- were dispatched long before the walker reached their block
+            // On large jobs the chain takes two launches per level: the tiles of the diagonal squares with the walkers
+            // first, the tiles of the rows below the squares afterwards.  In one launch those tiles -- hundreds to
+            // thousands per piece of a top separator -- were dispatched long before the walker reached their block
             // column and waited for it holding a workgroup slot (72 KB of LDS: one of the two k_chol_big workgroups of
             // the PUSH launch that runs beside the chain cannot be resident on that compute unit meanwhile); in a launch
             // of their own every diagonal tile is there when they start.  Flan-class input: 371.2 -> 365.8 ms although the
-            // chain launches by themselves take longer (56 -> 62 ms serialised); smaller jobs lose (96^3 grid, pieces
-            // only: 140.9 -> 142.6 ms; nd24k-class: 4.17 -> 4.82 ms: there the chain is the critical path), so the split
-            // is taken from kChainSplitAutoFlops update flops on.  PARSY_CHAIN_SPLIT=0: never; 1: the pieces of split
-            // supernodes only; 2: every tiled supernode (diagnostics).
+            // chain launches by themselves take longer (56 -> 62 ms serialised); 27-point grids 80^3 ... 128 x 128 x 96:
+            // -0.4 ... -1.5 %; 72^3: +0.4 %, 56^3: +3 %, nd24k-class 4.17 -> 4.82 ms (small jobs: the chain is the
+            // critical path), so the split is taken from kChainSplitAutoFlops update flops on.  Splitting only the pieces
+            // of split supernodes loses everywhere (mode 1).  PARSY_CHAIN_SPLIT=0: never; 2: always (diagnostics).
             const int chain_split_mode = env_int("PARSY_CHAIN_SPLIT", S.update_flops >= kChainSplitAutoFlops ? 2 : 0);
             auto splits = [&](int t) {
                 const int real = S.csn_real[t];
