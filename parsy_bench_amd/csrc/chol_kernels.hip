@@ -44,9 +44,15 @@ __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_trace[16 * 512];
 __device__ unsigned long long g_probe[8];
 #define TRACE(J, i) do { if (threadIdx.x == 0 && (J) < 512) g_trace[(J) * 16 + (i)] = wall_clock64(); } while (0)
+// sums over the ordinary tiles of the chain launches (100 MHz ticks): phases 0..5 = tile load + descendants' stream,
+// own block columns, wait for the diagonal tile, its load, TRSM, write + publish; [8] = tiles, [9] = block columns
+__device__ unsigned long long g_tilephase[16];
+#define TPHASE(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); \
+                       atomicAdd(&g_tilephase[i], now_ - tp_last); tp_last = now_; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define TRACE(J, i) do { } while (0)
+#define TPHASE(i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -618,6 +624,13 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one LDS-DMA instruction of the chain launch: 16 bytes per lane from the lane's own global address to lds + 16 * lane,
+// agent scope (sc1) like ld_sc1: the block columns it reads are published inside the launch
+__device__ __forceinline__ void glds16_sc1(const double* g, double* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 16);
+}
+
 __device__ __forceinline__ void lds_sub(double* p, double v) {
     __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -780,6 +793,10 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         else __builtin_amdgcn_s_setprio(1);
     }
 
+#ifdef PARSY_STAMPS
+    unsigned long long tp_last = wall_clock64();
+    const bool tp_on = CHAIN && !walker && !prep_b && !prep_c;
+#endif
     const int wa = wave >> 1, wb = wave & 1;
     const int subrow0 = td.row0 + kSub * wa, subcol0 = td.col0 + kSub * wb;
     const bool wave_on = subrow0 < r && subcol0 < w && subrow0 >= subcol0;
@@ -825,8 +842,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
     };
 
     // ---- this wave's update stream
-    int64_t le = 0, e_end = 0;       // next external entry / end of the list
-    int l_kint = 0, n_int = 0;       // next internal block column / their number (CHAIN)
+    int64_t le = 0, e_end = 0;       // next entry / end of the list
     if (wave_on) {
         if (!CHAIN && split_n > 1) {
             le = split_ranges[td.wp + 2 * wave];
@@ -835,62 +851,14 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             le = wptr[td.wp + wave];
             e_end = wptr[td.wp + wave + 1];
         }
-        if (CHAIN) n_int = prep_c ? tJ - 1 : tJ;  // block column J-1 reaches a diagonal tile through the walker
     }
-    bool gave_up = false;
-    if (le < e_end || n_int > 0) {
+    if (le < e_end) {
         struct Chunk {
             double a0[4], a1[4], b0[4], b1[4];  // MFMA operands of the four k steps
             int32_t rel;                         // this lane's relative index (used with the last chunk)
             int32_t kend, last, mn;              // wave-uniform: valid k in the chunk (0: padding of the
                                                  // stream), last chunk of its entry, window sizes
         };
-        // Internal entries wait for their operands.  kready = number of leading block columns
-        // whose tiles (I,k) and (J,k) are known to be published (acquired).
-        int kready = 0;
-        const int fI = D.tflag0 + tI * nbc, fJ = D.tflag0 + tJ * nbc;  // flags of tiles (I,0..), (J,0..)
-        auto extend_ready = [&]() {  // after a successful wait: take every further published column
-            while (kready < n_int) {
-                const int k = kready + lane;
-                bool ok = false;
-                if (k < n_int) {
-                    ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                    if (!diag_tile)
-                        ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                }
-                const unsigned long long miss = ~__ballot(ok);
-                const int adv = miss ? __builtin_ctzll(miss) : 64;
-                kready += adv;
-                if (adv < 64) break;
-            }
-            // every load of a published tile is an sc1 load: no cache to invalidate; this only keeps
-            // the compiler from moving those loads above the poll
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        auto ensure_ready = [&](int k) {  // block (bounded) until block column k can be read
-            const unsigned long long t0 = wall_clock64();
-            int spins = 0;
-            for (;;) {
-                // one address per wave and poll: the waiting waves must not flood the L2
-                bool ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                if (!diag_tile)
-                    ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                if (ok) break;
-                if ((spins & 15) == 15 &&
-                    (wall_clock64() - t0 > kSpinTicks ||
-                     __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
-                    gave_up = true;
-                    return;
-                }
-                // the last block column of a tile the walker is waiting for is on the critical path:
-                // poll it tightly (few such tiles at any time); everything else polls lazily
-                if (spins < 8 || ((prep_b || prep_c) && k == n_int - 1)) __builtin_amdgcn_s_sleep(4);
-                else __builtin_amdgcn_s_sleep(48);
-                ++spins;
-            }
-            extend_ready();
-        };
-
         // loader state (wave-uniform except the lane offsets).  Every chunk issues the same 16
         // operand loads (+ the relative index): fragments a narrow entry does not have re-read
         // its last row, k steps past a ragged end re-read column K-1 (masked in the multiply),
@@ -904,21 +872,9 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         bool l_live = true;
         auto loader_enter = [&]() {
             WaveEntry E;
-            if (le < e_end) {
-                E = l_next;  // fetched one entry ahead
-                if (le + 1 < e_end) l_next = wents[le + 1];
-                ++le;
-            } else {
-                // block column l_kint of the tile's own supernode, identity row map
-                E.src = D.px + (int64_t)l_kint * kTile * ld;
-                E.rel = 0;
-                E.ld = ld;
-                E.K = kTile;
-                E.ia = subrow0;
-                E.ja = subcol0;
-                E.mn = nrows | (ncols << 8) | (1 << 16);
-                ++l_kint;
-            }
+            E = l_next;  // fetched one entry ahead
+            if (le + 1 < e_end) l_next = wents[le + 1];
+            ++le;
             const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
             l_p = L + E.src;
             l_K = E.K;
@@ -931,12 +887,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             l_oB1 = E.ja + min(16 + l15, nj - 1);
             l_orel = E.rel + (lane < 32 ? E.ia + min(l31, mi - 1) : E.ja + min(l31, nj - 1));
         };
-        // The loader never enters a block column that is not known to be published: it stalls
-        // (the stream runs on padding) and the blocking wait happens at the top of a round.
-        bool l_stalled = false;
-        if (le >= e_end) ensure_ready(0);
-        if (gave_up) l_live = false;
-        else loader_enter();
+        loader_enter();
         auto issue = [&](Chunk& c) {
             const int kend = l_live ? min(kKC, l_K - l_k) : 0;
             c.kend = kend;
@@ -974,12 +925,8 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
 #endif
             c.rel = relpos[l_orel];
             if (c.last) {
-                if (le < e_end || l_kint < kready) {
-                    loader_enter();
-                } else {
-                    l_live = false;
-                    l_stalled = l_kint < n_int;
-                }
+                if (le < e_end) loader_enter();
+                else l_live = false;
             } else if (l_live) {
                 l_k += kKC;
                 l_p += (int64_t)kKC * l_ld;
@@ -1059,21 +1006,6 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         store_subtile();
         bool more = true;
         while (more) {
-            // the loader passes at most kInFlight entries per round: make sure the next block
-            // column of the supernode is published before it gets there
-            if (CHAIN && l_kint < n_int && l_kint >= kready && (l_stalled || e_end - le <= kInFlight)) {
-                ensure_ready(l_kint);
-                if (l_stalled && !gave_up) {
-                    loader_enter();
-                    l_live = true;
-                }
-                l_stalled = false;
-                if (gave_up) {  // abandon the rest of the stream
-                    l_live = false;
-                    l_kint = n_int;
-                    le = e_end;
-                }
-            }
             more = false;
 #pragma unroll
             for (int sidx = 0; sidx < kInFlight; ++sidx) {
@@ -1081,13 +1013,181 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                 issue(q[sidx]);
                 more = more || q[sidx].kend != 0;
             }
-            more = more || l_stalled;
         }
     } else if (wave_on) {
         store_subtile();
     }
-    if (gave_up) atomicMin(info, -1);
     __syncthreads();
+#ifdef PARSY_STAMPS
+    if (tp_on) TPHASE(0);
+#endif
+    // ---------------------------------------------------------------------------------------
+    // CHAIN: the updates by the earlier block columns of the tile's OWN supernode (the reference's
+    // DSYRK/DGEMM inside a supernode; parallel_PB_Cholesky_05.h:160,173 applied per 64-column block),
+    // shared by the workgroup.  Tile -= L(I, 0..n_int) L(J, 0..n_int)': identity row map, so the four
+    // waves keep their quadrants in MFMA accumulators across ALL block columns (initialised with the
+    // tile, products negated by the instruction: tile - p0 - p1 - ... in k order) and the two operand
+    // blocks (64 rows x 16 k each) are staged ONCE per workgroup by LDS-DMA into a ring of four
+    // chunks that takes over the whole LDS of the workgroup (the tile is in registers meanwhile):
+    // 8 flop per fetched byte and 16-byte lanes instead of 4 flop per byte in 8-byte lanes -- the
+    // per-wave streams of round 2 ran these 7e11 flops of the Flan-class input at the L2's request
+    // rate (11 TFLOP/s).  Rows past the panel's end re-read its last row (one element beyond it: a
+    // later column of the same panel follows) and land in cells that are written back as 0.
+    // ---------------------------------------------------------------------------------------
+    bool gave_up = false;
+    const int n_int = CHAIN ? (prep_c ? tJ - 1 : tJ) : 0;  // block column J-1 reaches a diagonal tile through the walker
+    if (CHAIN && n_int > 0) {
+        static_assert(offsetof(TileLds, dgbuf) == sizeof(double) * (4 * kSub * kLdSub + kPotrfScratch) &&
+                          offsetof(TileLds, s_invd) == sizeof(double) * (8 * kSub * kLdSub + kPotrfScratch),
+                      "tile_task: T, colbuf, dgbuf are one contiguous staging area");
+        constexpr int kOp = 8 * 128 + 4 * 16;   // one staged operand block: 8 DMA instructions of 2 k columns x 64 rows,
+                                                // every second one 16 doubles further: k and k + 1 in opposite bank halves
+        constexpr int kSlot = 2 * kOp, kSlots = 4;
+        static_assert(kSlots * kSlot <= 8 * kSub * kLdSub + kPotrfScratch, "tile_task: the staging ring fits the LDS");
+        double* const stg = &T[0][0];
+        double4_t acc[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc[f][g][v] = wave_on ? Tw[(16 * g + l15) * kLdSub + 16 * f + kq + 4 * v] : 0.0;
+        __syncthreads();  // every quadrant is in registers: the LDS is the ring now
+
+        // kready = number of leading block columns whose tiles (I,k) and (J,k) are known to be published
+        int kready = 0;
+        const int fI = D.tflag0 + tI * nbc, fJ = D.tflag0 + tJ * nbc;  // flags of tiles (I,0..), (J,0..)
+        auto extend_ready = [&]() {  // take every further published column
+            while (kready < n_int) {
+                const int k = kready + lane;
+                bool ok = false;
+                if (k < n_int) {
+                    ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                    if (!diag_tile)
+                        ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                }
+                const unsigned long long miss = ~__ballot(ok);
+                const int adv = miss ? __builtin_ctzll(miss) : 64;
+                kready += adv;
+                if (adv < 64) break;
+            }
+            // every read of a published tile is an sc1 access: no cache to invalidate; this only keeps
+            // the compiler from moving those reads above the poll
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto ensure_ready = [&](int k) {  // block (bounded) until block column k can be read
+            const unsigned long long t0 = wall_clock64();
+            int spins = 0;
+            while (kready <= k) {
+                extend_ready();
+                if (kready > k) break;
+                if ((spins & 15) == 15 &&
+                    (wall_clock64() - t0 > kSpinTicks ||
+                     __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                    gave_up = true;     // status < 0 below; go on with whatever is there so that no barrier is missed
+                    kready = n_int;
+                    break;
+                }
+                // the last block column of a tile the walker is waiting for is on the critical path:
+                // poll it tightly (few such tiles at any time); everything else polls lazily
+                if (spins < 8 || ((prep_b || prep_c) && k == n_int - 1)) __builtin_amdgcn_s_sleep(4);
+                else __builtin_amdgcn_s_sleep(48);
+                ++spins;
+            }
+        };
+
+        // DMA: wave w moves k columns 4w .. 4w+3 of both operand blocks of a chunk; instruction 2w takes columns 4w
+        // (lanes 0..31, rows 2 lane, 2 lane + 1) and 4w + 2 (lanes 32..63), instruction 2w + 1 columns 4w + 1 and
+        // 4w + 3, so that the k and k + 1 of one operand read (lanes 0..15 / 16..31) come from different instructions
+        const int dj = lane & 31, dk = 4 * wave + 2 * (lane >> 5);
+        const double* gA = G + (int64_t)dk * ld + min(td.row0 + 2 * dj, r - 1);
+        const double* gB = G + (int64_t)dk * ld + min(td.col0 + 2 * dj, r - 1);
+        double* const ldsA = stg + 272 * wave;
+        const int nch = 4 * n_int;
+        int issued = 0;
+        auto dma = [&]() {  // chunk `issued` -> slot issued & 3
+            double* dst = ldsA + (issued & (kSlots - 1)) * kSlot;
+            glds16_sc1(gA, dst);
+            glds16_sc1(gA + ld, dst + 144);
+            if (!diag_tile) {
+                glds16_sc1(gB, dst + kOp);
+                glds16_sc1(gB + ld, dst + kOp + 144);
+            }
+            gA += (int64_t)kKC * ld;
+            gB += (int64_t)kKC * ld;
+            ++issued;
+        };
+        const bool two_r = nrows > 16, two_c = ncols > 16, up = two_c && !diag_sub;
+        const int oA = (kq & 1) * 144 + (kq >> 1) * 64 + kSub * wa + l15;
+        const int oB = (kq & 1) * 144 + (kq >> 1) * 64 + kSub * wb + l15 + (diag_tile ? 0 : kOp);
+        for (int c = 0; c < nch; ++c) {
+            if (issued <= c) {
+                ensure_ready(c >> 2);
+                dma();
+            }
+            // this wave's part of chunk c has landed when only the DMA of the later chunks is outstanding
+            const int later = issued - c - 1;
+            if (diag_tile) {
+                if (later >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // everybody's part of chunk c is there, and everybody is done with chunk c - 1: its slot takes chunk c + 3
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int lim = min(c + kSlots, nch);
+            while (issued < lim) {
+                if ((issued >> 2) >= kready) {
+                    extend_ready();
+                    if ((issued >> 2) >= kready) break;
+                }
+                dma();
+            }
+            if (wave_on) {
+                const double* __restrict__ As = stg + (c & (kSlots - 1)) * kSlot;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double a0 = As[272 * u + oA], a1 = As[272 * u + oA + 16];
+                    const double b0 = As[272 * u + oB], b1 = As[272 * u + oB + 16];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 1);
+                    if (up) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 1);
+                    if (two_r) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 1);
+                    if (two_r && two_c) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 1);
+                }
+            }
+        }
+        __syncthreads();  // the ring is read: the tile goes back to its place
+        if (wave_on) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int rr = 16 * f + kq + 4 * v, cc = 16 * g + l15;
+                        const bool in = rr < nrows && cc < ncols && (!diag_sub || rr >= cc);
+                        Tw[cc * kLdSub + rr] = in ? acc[f][g][v] : 0.0;
+                    }
+        }
+        if (gave_up) atomicMin(info, -1);
+        __syncthreads();
+    }
+#ifdef PARSY_STAMPS
+    if (tp_on) {
+        TPHASE(1);
+        if (tid == 0) {
+            atomicAdd(&g_tilephase[8], 1ull);
+            atomicAdd(&g_tilephase[9], (unsigned long long)n_int);
+        }
+    }
+#endif
 
     // ---------------------------------------------------------------------------------------
     // After the stream.  Tiles live in LDS in the sub-tile layout of T (4 x 32x33); the tile
@@ -1173,6 +1273,7 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             publish(my_flag);  // (so that nobody else waits for this tile)
             return;
         }
+        TPHASE(2);
         {
             const double* DB = G + (int64_t)td.col0 * ld + td.col0;  // factored diagonal block
             double dtmp[kTile * kTile / kThreads];
@@ -1190,9 +1291,12 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
             if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * ld + tid]) : 1.0;
         }
         __syncthreads();
+        TPHASE(3);
         invert_and_trsm((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, nb);
+        TPHASE(4);
         write_tile(Tflat, td.row0, td.col0, 0);
         publish(my_flag);
+        TPHASE(5);
         return;
     }
 
@@ -1804,6 +1908,13 @@ extern "C" void parsy_debug_probe(unsigned long long* out) {
 }
 extern "C" void parsy_debug_trace(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 16 * 512);
+}
+extern "C" void parsy_debug_tilephase(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tilephase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tilephase), z, sizeof(z));
+    }
 }
 #endif
 
