@@ -660,17 +660,12 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
 // diagonal.  One workgroup barrier is expected before the call, one ends it.  The walker inlines
 // it (values in flight across it); the other two places share one out-of-line copy, which keeps
 // their register allocation apart from the stream's.
-__device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ tile, lds_f64* __restrict__ Dg,
-                                                       lds_f64* __restrict__ invd, int nb) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    auto cell = [&](int i, int c) -> lds_f64& {
-        return tile[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
-    };
-    // inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
-    // transposed into the (unused) strict upper triangle of the same sub-block:
-    // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  The TRSM below is then all products
-    // (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.
+// inverses of the four 16x16 diagonal sub-blocks of Ljj, one column per thread, written
+// transposed into the (unused) strict upper triangle of the same sub-block:
+// Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  A TRSM against Ljj is then all products
+// (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.  Ends with a workgroup barrier.
+__device__ __forceinline__ void invert_diag_blocks(lds_f64* __restrict__ Dg, lds_f64* __restrict__ invd) {
+    const int tid = threadIdx.x;
     if (tid < kTile) {
         const int b16 = (tid >> 4) * 16, c = tid & 15;
         double y[16];
@@ -689,6 +684,15 @@ __device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ til
             if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
     }
     __syncthreads();
+}
+__device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ tile, lds_f64* __restrict__ Dg,
+                                                       lds_f64* __restrict__ invd, int nb) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    auto cell = [&](int i, int c) -> lds_f64& {
+        return tile[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
+    };
+    invert_diag_blocks(Dg, invd);
     // each wave owns 16 rows of the tile for the whole solve: no barrier between blocks
     const int rbase = 16 * wave;
     for (int b16 = 0; b16 < nb; b16 += 16) {
@@ -757,9 +761,32 @@ struct TileLds {  // LDS of one workgroup of the tile kernel
     double s_invd[kTile];             // reciprocals of the diagonal of the block being solved against
     int32_t s_ok, s_task, s_cnt, s_cnt2;
 };
+// one staged operand block of the chain's ring (see tile_task, "finishes in REGISTERS"): 8 DMA instructions of 2 k
+// columns x 64 rows, every second one 16 doubles further: k and k + 1 of an operand read in opposite bank halves
+static constexpr int kRingOp = 8 * 128 + 4 * 16;
+static constexpr int kRingSlot = 2 * kRingOp;   // a chunk: the tile's rows and its columns, 16 k each
+// LDS of a workgroup of the chain's second launch of a level (the rows below the diagonal squares: no walker, no
+// prepared tile): the tile while the descendants' stream runs, then the ring of THREE chunks, then the diagonal
+// block -- one after the other in the same 52 KB, so that three workgroups share a compute unit
+struct RowsLds {
+    double T[4][kSub * kLdSub];
+    double ring_rest[3 * kRingSlot - 4 * kSub * kLdSub];
+    double s_invd[kTile];
+    int32_t s_ok, s_task, s_cnt, s_cnt2;
+};
+static_assert(offsetof(TileLds, dgbuf) == sizeof(double) * (4 * kSub * kLdSub + kPotrfScratch) &&
+                  offsetof(TileLds, s_invd) == sizeof(double) * (8 * kSub * kLdSub + kPotrfScratch) &&
+                  4 * kRingSlot <= 8 * kSub * kLdSub + kPotrfScratch,
+              "TileLds: T, colbuf, dgbuf are one contiguous area that holds a ring of four chunks");
+static_assert(offsetof(RowsLds, s_invd) == sizeof(double) * 3 * kRingSlot && kTile * kLdDiag <= 4 * kSub * kLdSub &&
+                  sizeof(RowsLds) <= 160 * 1024 / 3, "RowsLds: three chunks, three workgroups per compute unit");
+__device__ __forceinline__ double* lds_colbuf(TileLds& S) { return S.colbuf; }
+__device__ __forceinline__ double* lds_colbuf(RowsLds&) { return nullptr; }
+__device__ __forceinline__ double* lds_dgbuf(TileLds& S) { return S.dgbuf; }
+__device__ __forceinline__ double* lds_dgbuf(RowsLds& S) { return &S.T[0][0]; }   // (the tile is in registers by then)
 
-template <bool CHAIN>
-__device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDesc* __restrict__ sn,
+template <bool CHAIN, bool ROWS = false, class LdsT = TileLds>
+__device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc* __restrict__ sn,
                                           const int32_t* __restrict__ relpos,
                                           const WaveEntry* __restrict__ wents,
                                           const int64_t* __restrict__ wptr,
@@ -768,10 +795,10 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
                                           const TileDesc* __restrict__ tiles, double* __restrict__ L,
                                           int* __restrict__ info, int* __restrict__ tflags,
                                           const int nflags_arg, const int epoch) {
-    constexpr int kInFlight = CHAIN ? kInFlightChain : kInFlightTiles;
+    constexpr int kInFlight = (CHAIN && !ROWS) ? kInFlightChain : kInFlightTiles;
     double (&T)[4][kSub * kLdSub] = S.T;
-    double (&colbuf)[kPotrfScratch] = S.colbuf;
-    double (&dgbuf)[4 * kSub * kLdSub] = S.dgbuf;
+    double* const colbuf = lds_colbuf(S);
+    double* const dgbuf = lds_dgbuf(S);
     double (&s_invd)[kTile] = S.s_invd;
     int32_t &s_ok = S.s_ok, &s_cnt = S.s_cnt, &s_cnt2 = S.s_cnt2;
 
@@ -784,9 +811,10 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
     const int tI = td.row0 / kTile, tJ = td.col0 / kTile, nbc = (w + kTile - 1) / kTile;
     const bool diag_tile = td.row0 == td.col0;
     // roles of the chain launch (see the walker below)
-    const bool walker = CHAIN && tI == 0 && tJ == 0;
-    const bool prep_c = CHAIN && diag_tile && tJ > 0;           // diagonal tile (J,J), J >= 1
-    const bool prep_b = CHAIN && tI == tJ + 1 && tI < nbc;      // tile (J+1,J) left of a diagonal tile
+    // (ROWS: the launch holds none of them)
+    const bool walker = CHAIN && !ROWS && tI == 0 && tJ == 0;
+    const bool prep_c = CHAIN && !ROWS && diag_tile && tJ > 0;           // diagonal tile (J,J), J >= 1
+    const bool prep_b = CHAIN && !ROWS && tI == tJ + 1 && tI < nbc;      // tile (J+1,J) left of a diagonal tile
     // the chain's waves go first where they share a SIMD with the side stream's TILES waves (priority 0)
     if (CHAIN) {
         if (walker || prep_b || prep_c) __builtin_amdgcn_s_setprio(3);
@@ -1021,173 +1049,6 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
 #ifdef PARSY_STAMPS
     if (tp_on) TPHASE(0);
 #endif
-    // ---------------------------------------------------------------------------------------
-    // CHAIN: the updates by the earlier block columns of the tile's OWN supernode (the reference's
-    // DSYRK/DGEMM inside a supernode; parallel_PB_Cholesky_05.h:160,173 applied per 64-column block),
-    // shared by the workgroup.  Tile -= L(I, 0..n_int) L(J, 0..n_int)': identity row map, so the four
-    // waves keep their quadrants in MFMA accumulators across ALL block columns (initialised with the
-    // tile, products negated by the instruction: tile - p0 - p1 - ... in k order) and the two operand
-    // blocks (64 rows x 16 k each) are staged ONCE per workgroup by LDS-DMA into a ring of four
-    // chunks that takes over the whole LDS of the workgroup (the tile is in registers meanwhile):
-    // 8 flop per fetched byte and 16-byte lanes instead of 4 flop per byte in 8-byte lanes -- the
-    // per-wave streams of round 2 ran these 7e11 flops of the Flan-class input at the L2's request
-    // rate (11 TFLOP/s).  Rows past the panel's end re-read its last row (one element beyond it: a
-    // later column of the same panel follows) and land in cells that are written back as 0.
-    // ---------------------------------------------------------------------------------------
-    bool gave_up = false;
-    const int n_int = CHAIN ? (prep_c ? tJ - 1 : tJ) : 0;  // block column J-1 reaches a diagonal tile through the walker
-    if (CHAIN && n_int > 0) {
-        static_assert(offsetof(TileLds, dgbuf) == sizeof(double) * (4 * kSub * kLdSub + kPotrfScratch) &&
-                          offsetof(TileLds, s_invd) == sizeof(double) * (8 * kSub * kLdSub + kPotrfScratch),
-                      "tile_task: T, colbuf, dgbuf are one contiguous staging area");
-        constexpr int kOp = 8 * 128 + 4 * 16;   // one staged operand block: 8 DMA instructions of 2 k columns x 64 rows,
-                                                // every second one 16 doubles further: k and k + 1 in opposite bank halves
-        constexpr int kSlot = 2 * kOp, kSlots = 4;
-        static_assert(kSlots * kSlot <= 8 * kSub * kLdSub + kPotrfScratch, "tile_task: the staging ring fits the LDS");
-        double* const stg = &T[0][0];
-        double4_t acc[2][2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc[f][g][v] = wave_on ? Tw[(16 * g + l15) * kLdSub + 16 * f + kq + 4 * v] : 0.0;
-        __syncthreads();  // every quadrant is in registers: the LDS is the ring now
-
-        // kready = number of leading block columns whose tiles (I,k) and (J,k) are known to be published
-        int kready = 0;
-        const int fI = D.tflag0 + tI * nbc, fJ = D.tflag0 + tJ * nbc;  // flags of tiles (I,0..), (J,0..)
-        auto extend_ready = [&]() {  // take every further published column
-            while (kready < n_int) {
-                const int k = kready + lane;
-                bool ok = false;
-                if (k < n_int) {
-                    ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                    if (!diag_tile)
-                        ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                }
-                const unsigned long long miss = ~__ballot(ok);
-                const int adv = miss ? __builtin_ctzll(miss) : 64;
-                kready += adv;
-                if (adv < 64) break;
-            }
-            // every read of a published tile is an sc1 access: no cache to invalidate; this only keeps
-            // the compiler from moving those reads above the poll
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        auto ensure_ready = [&](int k) {  // block (bounded) until block column k can be read
-            const unsigned long long t0 = wall_clock64();
-            int spins = 0;
-            while (kready <= k) {
-                extend_ready();
-                if (kready > k) break;
-                if ((spins & 15) == 15 &&
-                    (wall_clock64() - t0 > kSpinTicks ||
-                     __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
-                    gave_up = true;     // status < 0 below; go on with whatever is there so that no barrier is missed
-                    kready = n_int;
-                    break;
-                }
-                // the last block column of a tile the walker is waiting for is on the critical path:
-                // poll it tightly (few such tiles at any time); everything else polls lazily
-                if (spins < 8 || ((prep_b || prep_c) && k == n_int - 1)) __builtin_amdgcn_s_sleep(4);
-                else __builtin_amdgcn_s_sleep(48);
-                ++spins;
-            }
-        };
-
-        // DMA: wave w moves k columns 4w .. 4w+3 of both operand blocks of a chunk; instruction 2w takes columns 4w
-        // (lanes 0..31, rows 2 lane, 2 lane + 1) and 4w + 2 (lanes 32..63), instruction 2w + 1 columns 4w + 1 and
-        // 4w + 3, so that the k and k + 1 of one operand read (lanes 0..15 / 16..31) come from different instructions
-        const int dj = lane & 31, dk = 4 * wave + 2 * (lane >> 5);
-        const double* gA = G + (int64_t)dk * ld + min(td.row0 + 2 * dj, r - 1);
-        const double* gB = G + (int64_t)dk * ld + min(td.col0 + 2 * dj, r - 1);
-        double* const ldsA = stg + 272 * wave;
-        const int nch = 4 * n_int;
-        int issued = 0;
-        auto dma = [&]() {  // chunk `issued` -> slot issued & 3
-            double* dst = ldsA + (issued & (kSlots - 1)) * kSlot;
-            glds16_sc1(gA, dst);
-            glds16_sc1(gA + ld, dst + 144);
-            if (!diag_tile) {
-                glds16_sc1(gB, dst + kOp);
-                glds16_sc1(gB + ld, dst + kOp + 144);
-            }
-            gA += (int64_t)kKC * ld;
-            gB += (int64_t)kKC * ld;
-            ++issued;
-        };
-        const bool two_r = nrows > 16, two_c = ncols > 16, up = two_c && !diag_sub;
-        const int oA = (kq & 1) * 144 + (kq >> 1) * 64 + kSub * wa + l15;
-        const int oB = (kq & 1) * 144 + (kq >> 1) * 64 + kSub * wb + l15 + (diag_tile ? 0 : kOp);
-        for (int c = 0; c < nch; ++c) {
-            if (issued <= c) {
-                ensure_ready(c >> 2);
-                dma();
-            }
-            // this wave's part of chunk c has landed when only the DMA of the later chunks is outstanding
-            const int later = issued - c - 1;
-            if (diag_tile) {
-                if (later >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // everybody's part of chunk c is there, and everybody is done with chunk c - 1: its slot takes chunk c + 3
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int lim = min(c + kSlots, nch);
-            while (issued < lim) {
-                if ((issued >> 2) >= kready) {
-                    extend_ready();
-                    if ((issued >> 2) >= kready) break;
-                }
-                dma();
-            }
-            if (wave_on) {
-                const double* __restrict__ As = stg + (c & (kSlots - 1)) * kSlot;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double a0 = As[272 * u + oA], a1 = As[272 * u + oA + 16];
-                    const double b0 = As[272 * u + oB], b1 = As[272 * u + oB + 16];
-                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 1);
-                    if (up) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 1);
-                    if (two_r) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 1);
-                    if (two_r && two_c) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 1);
-                }
-            }
-        }
-        __syncthreads();  // the ring is read: the tile goes back to its place
-        if (wave_on) {
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int rr = 16 * f + kq + 4 * v, cc = 16 * g + l15;
-                        const bool in = rr < nrows && cc < ncols && (!diag_sub || rr >= cc);
-                        Tw[cc * kLdSub + rr] = in ? acc[f][g][v] : 0.0;
-                    }
-        }
-        if (gave_up) atomicMin(info, -1);
-        __syncthreads();
-    }
-#ifdef PARSY_STAMPS
-    if (tp_on) {
-        TPHASE(1);
-        if (tid == 0) {
-            atomicAdd(&g_tilephase[8], 1ull);
-            atomicAdd(&g_tilephase[9], (unsigned long long)n_int);
-        }
-    }
-#endif
 
     // ---------------------------------------------------------------------------------------
     // After the stream.  Tiles live in LDS in the sub-tile layout of T (4 x 32x33); the tile
@@ -1256,20 +1117,185 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
     double* __restrict__ invd = s_invd;
     const int my_flag = D.tflag0 + tI * nbc + tJ;
 
-    if (prep_b || prep_c) {
-        // prepared for the walker: every update except the walker's own is in; it goes to the panel
-        // and is announced with the tile's PREP flag
-        write_tile(Tflat, td.row0, td.col0, 0);
-        publish(nflags + my_flag);
-        return;
-    }
-
     if (!walker) {
-        // ---- a tile below the diagonal: wait for the diagonal tile of its block column, TRSM, publish
+        // -----------------------------------------------------------------------------------
+        // Every tile of the chain launch but the walker's first one finishes in REGISTERS.  Wave w takes
+        // rows 16 w .. 16 w + 15 of the tile, all 64 columns: four accumulators of v_mfma_f64_16x16x4_f64 in the
+        // "transposed" form (lane & 15 = row of the tile, (lane >> 4) + 4 reg = column inside a 16-column block),
+        // in which register u of a block IS the operand of k step u of a later product -- the TRSM below never
+        // goes back to LDS with the tile.
+        //   1. the updates by the earlier block columns of the tile's OWN supernode (the reference's DSYRK/DGEMM
+        //      inside a supernode; parallel_PB_Cholesky_05.h:160,173 per 64-column block): tile - L(I,0..) L(J,0..)',
+        //      identity row map, products negated by the instruction and accumulated across ALL block columns
+        //      (tile - p0 - p1 - ... in k order).  The two operand blocks (64 rows x 16 k each) are staged once per
+        //      workgroup by LDS-DMA into a ring of four chunks that takes over the LDS (the tile is in registers):
+        //      8 flop per fetched byte in 16-byte lanes instead of 4 in 8-byte lanes -- the per-wave streams of
+        //      round 2 ran these 7e11 flops of the Flan-class input at the L2's request rate (11 TFLOP/s).  Rows
+        //      past the panel's end re-read its last row (one element beyond it: a later column of the same panel
+        //      follows) and land in cells that are never stored.
+        //   2. prepared tiles (walker's inputs) are stored and announced; the others wait for the diagonal tile
+        //      of their block column, invert its four 16 x 16 diagonal blocks and run the blocked TRSM (what a
+        //      blocked dtrsm does: X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)', reference :218) on the
+        //      accumulators, then store and publish.
+        // -----------------------------------------------------------------------------------
+        constexpr int kOp = kRingOp, kSlot = kRingSlot, kSlots = ROWS ? 3 : 4;
+        const int n_int = prep_c ? tJ - 1 : tJ;  // block column J-1 reaches a diagonal tile through the walker
         const int nb = min(kTile, w - td.col0);
+        const int ng = diag_tile ? min(wave + 1, (nb + 15) >> 4) : (nb + 15) >> 4;   // 16-column blocks this wave holds
+        const bool rows_on = td.row0 + 16 * wave < r;
+        double4_t acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[g][v] = cell(Tflat, 16 * wave + l15, 16 * g + kq + 4 * v);
+        bool gave_up = false;
+        if (n_int > 0) {
+            double* const stg = Tflat;
+            __syncthreads();  // the tile is in registers: the LDS is the ring now
+            // kready = number of leading block columns whose tiles (I,k) and (J,k) are known to be published
+            int kready = 0;
+            const int fI = D.tflag0 + tI * nbc, fJ = D.tflag0 + tJ * nbc;  // flags of tiles (I,0..), (J,0..)
+            auto extend_ready = [&]() {  // take every further published column
+                while (kready < n_int) {
+                    const int k = kready + lane;
+                    bool ok = false;
+                    if (k < n_int) {
+                        ok = __hip_atomic_load(&tflags[fI + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                        if (!diag_tile)
+                            ok = ok && __hip_atomic_load(&tflags[fJ + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                    }
+                    const unsigned long long miss = ~__ballot(ok);
+                    const int adv = miss ? __builtin_ctzll(miss) : 64;
+                    kready += adv;
+                    if (adv < 64) break;
+                }
+                // every read of a published tile is an sc1 access: no cache to invalidate; this only keeps
+                // the compiler from moving those reads above the poll
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+            auto ensure_ready = [&](int k) {  // block (bounded) until block column k can be read
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                while (kready <= k) {
+                    extend_ready();
+                    if (kready > k) break;
+                    if ((spins & 15) == 15 &&
+                        (wall_clock64() - t0 > kSpinTicks ||
+                         __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                        gave_up = true;     // status < 0 below; go on with whatever is there so that no barrier is missed
+                        kready = n_int;
+                        break;
+                    }
+                    // the last block column of a tile the walker is waiting for is on the critical path:
+                    // poll it tightly (few such tiles at any time); everything else polls lazily
+                    if (spins < 8 || ((prep_b || prep_c) && k == n_int - 1)) __builtin_amdgcn_s_sleep(4);
+                    else __builtin_amdgcn_s_sleep(48);
+                    ++spins;
+                }
+            };
+            // DMA: wave w moves k columns 4w .. 4w+3 of both operand blocks of a chunk; instruction 2w takes columns
+            // 4w (lanes 0..31, rows 2 lane, 2 lane + 1) and 4w + 2 (lanes 32..63), instruction 2w + 1 columns 4w + 1
+            // and 4w + 3, so that the k and k + 1 of one operand read (lanes 0..15 / 16..31) come from different
+            // instructions
+            const int dj = lane & 31, dk = 4 * wave + 2 * (lane >> 5);
+            const double* gA = G + (int64_t)dk * ld + min(td.row0 + 2 * dj, r - 1);
+            const double* gB = G + (int64_t)dk * ld + min(td.col0 + 2 * dj, r - 1);
+            double* const ldsA = stg + 272 * wave;
+            const int nch = 4 * n_int;
+            int issued = 0, islot = 0, cslot = 0;   // chunks started / the slot of the next one / of the chunk being multiplied
+            auto dma = [&]() {  // chunk `issued` -> slot issued % kSlots
+                double* dst = ldsA + islot * kSlot;
+                islot = islot + 1 == kSlots ? 0 : islot + 1;
+                glds16_sc1(gA, dst);
+                glds16_sc1(gA + ld, dst + 144);
+                if (!diag_tile) {
+                    glds16_sc1(gB, dst + kOp);
+                    glds16_sc1(gB + ld, dst + kOp + 144);
+                }
+                gA += (int64_t)kKC * ld;
+                gB += (int64_t)kKC * ld;
+                ++issued;
+            };
+            const int oR = (kq & 1) * 144 + (kq >> 1) * 64 + 16 * wave + l15;               // the tile's rows: L(I,k)
+            const int oC = (kq & 1) * 144 + (kq >> 1) * 64 + l15 + (diag_tile ? 0 : kOp);   // its columns: L(J,k)
+            for (int c = 0; c < nch; ++c) {
+                if (issued <= c) {
+                    ensure_ready(c >> 2);
+                    dma();
+                }
+                // this wave's part of chunk c has landed when only the DMA of the later chunks is outstanding
+                const int later = issued - c - 1;
+                if (diag_tile) {
+                    if (kSlots > 3 && later >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    if (kSlots > 3 && later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // everybody's part of chunk c is there, and everybody is done with chunk c - 1: its slot takes chunk
+                // c + kSlots - 1
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int lim = min(c + kSlots, nch);
+                while (issued < lim) {
+                    if ((issued >> 2) >= kready) {
+                        extend_ready();
+                        if ((issued >> 2) >= kready) break;
+                    }
+                    dma();
+                }
+                if (rows_on) {
+                    const double* __restrict__ Ss = stg + cslot * kSlot;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double rv = Ss[272 * u + oR];
+                        double cv[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) cv[g] = Ss[272 * u + oC + 16 * g];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (g < ng) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[g], rv, acc[g], 0, 0, 1);
+                    }
+                }
+                cslot = cslot + 1 == kSlots ? 0 : cslot + 1;
+            }
+        }
+        // the wave's rows go to the panel straight from the accumulators (lanes along the rows: 128-byte segments)
+        auto store_regs = [&]() {
+            const int row = td.row0 + 16 * wave + l15;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int col = td.col0 + 16 * g + kq + 4 * v;
+                    if (row < r && col < w && row >= col) st_sc1(&G[(int64_t)col * ld + row], acc[g][v]);
+                }
+        };
+#ifdef PARSY_STAMPS
+        if (tp_on) {
+            TPHASE(1);
+            if (tid == 0) {
+                atomicAdd(&g_tilephase[8], 1ull);
+                atomicAdd(&g_tilephase[9], (unsigned long long)n_int);
+            }
+        }
+#endif
+        if (gave_up) atomicMin(info, -1);
+        if (prep_b || prep_c) {
+            // prepared for the walker: every update except the walker's own is in; it goes to the panel
+            // and is announced with the tile's PREP flag
+            store_regs();
+            publish(nflags + my_flag);
+            return;
+        }
+        // ---- a tile below the diagonal: wait for the diagonal tile of its block column, TRSM, publish
         const int fd = D.tflag0 + tJ * nbc + tJ;
-        if (!wait_flags(fd, fd)) {
-            write_tile(Tflat, td.row0, td.col0, 0);
+        if (!wait_flags(fd, fd)) {   // (its barrier: the ring is read)
+            store_regs();
             publish(my_flag);  // (so that nobody else waits for this tile)
             return;
         }
@@ -1292,9 +1318,36 @@ __device__ __forceinline__ void tile_task(TileLds& S, const int task, const SnDe
         }
         __syncthreads();
         TPHASE(3);
-        invert_and_trsm((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, nb);
+        invert_diag_blocks((lds_f64*)dgbuf, (lds_f64*)invd);
+        if (rows_on) {
+            const lds_f64* __restrict__ Dg = (const lds_f64*)dgbuf;
+            const lds_f64* __restrict__ iv = (const lds_f64*)invd;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (16 * b < nb) {
+#pragma unroll
+                    for (int p = 0; p < b; ++p)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = 16 * p + kq + 4 * u;
+                            const double lv = Dg[k * kLdDiag + 16 * b + l15];         // L[16 b + j][k]
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, acc[p][u], acc[b], 0, 0, 1);
+                        }
+                    double4_t x = {0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kq + 4 * u, j = l15;
+                        double wv = 0.0;                                            // inv(L_bb)'[k][j] = inv(L_bb)[j][k]
+                        if (j > k) wv = Dg[(16 * b + j) * kLdDiag + 16 * b + k];
+                        else if (j == k) wv = iv[16 * b + k];
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, acc[b][u], x, 0, 0, 0);
+                    }
+                    acc[b] = x;
+                }
+            }
+        }
         TPHASE(4);
-        write_tile(Tflat, td.row0, td.col0, 0);
+        store_regs();
         publish(my_flag);
         TPHASE(5);
         return;
@@ -1546,6 +1599,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_chol_chain(const SnDesc* __rest
     __syncthreads();
     tile_task<true>(S, S.s_task, sn, relpos, wents, wptr, split_ranges, tile_scratch, tiles, L, info, tflags, nflags,
                     epoch);
+}
+// CHAIN, second launch of a level (Launch::fused = 1): the tiles of the rows below the diagonal squares -- every
+// diagonal tile they wait for was published by the first launch.  Three workgroups per compute unit (52 KB of LDS,
+// <= 168 registers): what a tile spends waiting for memory (its own load, the ring's first chunk, the diagonal
+// block, its stores) runs behind the products of two others instead of one.
+__global__ __launch_bounds__(kThreads, 3) void k_chol_chain_rows(const SnDesc* __restrict__ sn,
+                                                                 const int32_t* __restrict__ relpos,
+                                                                 const WaveEntry* __restrict__ wents,
+                                                                 const int64_t* __restrict__ wptr,
+                                                                 const int64_t* __restrict__ split_ranges,
+                                                                 double* __restrict__ tile_scratch,
+                                                                 const TileDesc* __restrict__ tiles,
+                                                                 double* __restrict__ L, int* __restrict__ info,
+                                                                 int* __restrict__ tflags, int nflags,
+                                                                 int* __restrict__ ticket, int epoch) {
+    __shared__ RowsLds S;
+    if (threadIdx.x == 0) S.s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    tile_task<true, true>(S, S.s_task, sn, relpos, wents, wptr, split_ranges, tile_scratch, tiles, L, info, tflags,
+                          nflags, epoch);
 }
 
 // ---------------------------------------------------------------------------
@@ -1937,12 +2010,17 @@ int chain_workgroups_per_cu() {
     return nb;
 }
 
-void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, double* L,
+void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, bool rows, double* L,
                        hipStream_t stream) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_chain, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.wave_entries,
-                       P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L, P.info, P.tflags,
-                       P.n_tflags, P.tickets + ticket, epoch);
+    if (rows)
+        hipLaunchKernelGGL(k_chol_chain_rows, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.wave_entries,
+                           P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L, P.info, P.tflags,
+                           P.n_tflags, P.tickets + ticket, epoch);
+    else
+        hipLaunchKernelGGL(k_chol_chain, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.wave_entries,
+                           P.wave_ptr, P.split_ranges, P.tile_scratch, P.tiles + first, L, P.info, P.tflags,
+                           P.n_tflags, P.tickets + ticket, epoch);
 }
 
 }  // namespace parsy

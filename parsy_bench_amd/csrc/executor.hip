@@ -267,7 +267,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                     launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }
                 break;
-            case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, L, stream); break;
+            case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, l.fused != 0, L, stream); break;
             case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, pl->solve_ldq, stream); break;
             case kLaunchSolvePanel:
                 if (l.fused && nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain)

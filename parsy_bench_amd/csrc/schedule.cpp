@@ -835,6 +835,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             for (int t : bigs) chain_split = chain_split || splits(t);
             for (int part = 0; part < (chain_split ? 2 : 1); ++part) {
             Launch Lc{kLaunchChain, (int32_t)S.tiles.size(), 0, lev, S.n_chain_launches++, 0, 0, 0, -1, 0};
+            Lc.fused = part;   // 1: only tiles below the squares (k_chol_chain_rows: three workgroups per compute unit)
             // Walkers stay resident for their whole chain, so the block-column-major interleaving is
             // done per batch of at most walker_batch supernodes: what a walker waits for then lies at most
             // one batch of tiles ahead of it in ticket order, and the walkers of the batches in flight
@@ -1102,6 +1103,7 @@ int64_t simulate_chain(const Schedule& S, int slots) {
                 if (t.I == 0 && t.J == 0) t.role = 0;
                 else if (t.I == t.J) t.role = 2;
                 else if (t.I == t.J + 1 && t.I < nbc) t.role = 1;
+                if (L.fused != 0 && t.I < nbc) ++stuck;   // a rows launch holds no tile of a diagonal square
                 resident.push_back(t);
                 progress = true;
             }

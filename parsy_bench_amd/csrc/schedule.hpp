@@ -121,7 +121,8 @@ struct Launch {
     int32_t lds_bytes;     // dynamic LDS (SMALL); BACK chain launch: first entry of its workgroups in bsolve_pairs;
                            // SOLVE_PANEL chain launch: first entry of its tasks in solve_mtasks
     int32_t fused;         // SOLVE_PANEL / BACK: 1 = chain launch of the whole level; SMALL, SOLVE_SMALL, BACK:
-                           // 2 = subtree launch (first / count: (begin, end) pairs in the kind's range array)
+                           // 2 = subtree launch (first / count: (begin, end) pairs in the kind's range array);
+                           // CHAIN: 1 = the level's second launch (tiles below the diagonal squares only)
     int32_t side;          // 1: runs on the plan's side stream (TILES), 0: main stream
     int32_t wait_level;    // side launches: wait until this etree level is complete (-1: init only);
                            // BACK chain launch: number of its entries in bsolve_pairs; SOLVE_PANEL chain launch: in solve_mtasks
