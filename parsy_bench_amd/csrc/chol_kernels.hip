@@ -839,8 +839,11 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
     // launch adds, in part order, when it loads the tile.
     const int split_part = CHAIN ? 0 : (td.part & 255);
     const int split_n = CHAIN ? td.part : (td.part >> 8);
+    // A tile of the chain launch with no update list at all (most tiles of the pieces of a top separator: their
+    // descendants went through the BIG and TILES launches) never enters LDS: the panel -> accumulators, below.
+    const bool direct = CHAIN && !walker && split_n <= 1 && wptr[td.wp] == wptr[td.wp + 4];
     double tv[kSub * kSub / 64];
-    if (wave_on) {
+    if (wave_on && !direct) {
 #pragma unroll
         for (int q = 0; q < kSub * kSub / 64; ++q) {
             const int e = q * 64 + lane;
@@ -871,7 +874,7 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
 
     // ---- this wave's update stream
     int64_t le = 0, e_end = 0;       // next entry / end of the list
-    if (wave_on) {
+    if (wave_on && !direct) {
         if (!CHAIN && split_n > 1) {
             le = split_ranges[td.wp + 2 * wave];
             e_end = split_ranges[td.wp + 2 * wave + 1];
@@ -1042,10 +1045,10 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                 more = more || q[sidx].kend != 0;
             }
         }
-    } else if (wave_on) {
+    } else if (wave_on && !direct) {
         store_subtile();
     }
-    __syncthreads();
+    if (!direct) __syncthreads();
 #ifdef PARSY_STAMPS
     if (tp_on) TPHASE(0);
 #endif
@@ -1144,10 +1147,36 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
         const int ng = diag_tile ? min(wave + 1, (nb + 15) >> 4) : (nb + 15) >> 4;   // 16-column blocks this wave holds
         const bool rows_on = td.row0 + 16 * wave < r;
         double4_t acc[4];
+        if (direct) {
+            const int row = td.row0 + 16 * wave + l15;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[g][v] = cell(Tflat, 16 * wave + l15, 16 * g + kq + 4 * v);
+                for (int v = 0; v < 4; ++v) {
+                    const int col = td.col0 + 16 * g + kq + 4 * v;
+                    acc[g][v] = (row < r && col < w && row >= col) ? G[(int64_t)col * ld + row] : 0.0;
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[g][v] = cell(Tflat, 16 * wave + l15, 16 * g + kq + 4 * v);
+        }
+        // ROWS: the diagonal tile of the block column was published by the level's first launch -- no flag to wait
+        // for, and its values are fetched now, behind everything that follows
+        double dtmp[kTile * kTile / kThreads];
+        double dinv_pre = 1.0;
+        auto fetch_diag = [&]() {
+            const double* DB = G + (int64_t)td.col0 * ld + td.col0;  // factored diagonal block
+#pragma unroll
+            for (int q = 0; q < kTile * kTile / kThreads; ++q) {
+                const int e = q * kThreads + tid;
+                const int c = e >> 6, i = e & 63;
+                dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * ld + i]) : 0.0;
+            }
+            if (tid < kTile) dinv_pre = (tid < nb) ? ld_sc1(&DB[(int64_t)tid * ld + tid]) : 1.0;
+        };
+        if (ROWS) fetch_diag();
         bool gave_up = false;
         if (n_int > 0) {
             double* const stg = Tflat;
@@ -1294,27 +1323,24 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
         }
         // ---- a tile below the diagonal: wait for the diagonal tile of its block column, TRSM, publish
         const int fd = D.tflag0 + tJ * nbc + tJ;
-        if (!wait_flags(fd, fd)) {   // (its barrier: the ring is read)
-            store_regs();
-            publish(my_flag);  // (so that nobody else waits for this tile)
-            return;
-        }
-        TPHASE(2);
-        {
-            const double* DB = G + (int64_t)td.col0 * ld + td.col0;  // factored diagonal block
-            double dtmp[kTile * kTile / kThreads];
-#pragma unroll
-            for (int q = 0; q < kTile * kTile / kThreads; ++q) {
-                const int e = q * kThreads + tid;
-                const int c = e >> 6, i = e & 63;
-                dtmp[q] = (c < nb && i < nb && i >= c) ? ld_sc1(&DB[(int64_t)c * ld + i]) : 0.0;
+        if (ROWS) {
+            __syncthreads();   // the ring is read
+        } else {
+            if (!wait_flags(fd, fd)) {   // (its barrier: the ring is read)
+                store_regs();
+                publish(my_flag);  // (so that nobody else waits for this tile)
+                return;
             }
+            TPHASE(2);
+            fetch_diag();
+        }
+        {
 #pragma unroll
             for (int q = 0; q < kTile * kTile / kThreads; ++q) {
                 const int e = q * kThreads + tid;
                 dgbuf[(e >> 6) * kLdDiag + (e & 63)] = dtmp[q];
             }
-            if (tid < kTile) invd[tid] = (tid < nb) ? 1.0 / ld_sc1(&DB[(int64_t)tid * ld + tid]) : 1.0;
+            if (tid < kTile) invd[tid] = 1.0 / dinv_pre;
         }
         __syncthreads();
         TPHASE(3);
