@@ -821,11 +821,13 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             // thousands per piece of a top separator -- were dispatched long before the walker reached their block
             // column and waited for it holding a workgroup slot (72 KB of LDS: one of the two k_chol_big workgroups of
             // the PUSH launch that runs beside the chain cannot be resident on that compute unit meanwhile); in a launch
-            // of their own every diagonal tile is there when they start.  Flan-class input: 371.2 -> 365.8 ms although the
-            // chain launches by themselves take longer (56 -> 62 ms serialised); 27-point grids 80^3 ... 128 x 128 x 96:
-            // -0.4 ... -1.5 %; 72^3: +0.4 %, 56^3: +3 %, nd24k-class 4.17 -> 4.82 ms (small jobs: the chain is the
-            // critical path), so the split is taken from kChainSplitAutoFlops update flops on.  Splitting only the pieces
-            // of split supernodes loses everywhere (mode 1).  PARSY_CHAIN_SPLIT=0: never; 2: always (diagnostics).
+            // of their own every diagonal tile is there when they start, no flag is waited for, and the kernel of the
+            // second launch (k_chol_chain_rows: no walker, no prepared tile) gets by with 52 KB of LDS: three workgroups
+            // per compute unit.  Flan-class input: 371.2 -> 365.8 ms with the same kernel for both launches, 347.6 ms
+            // with k_chol_chain_rows; 27-point grids 56^3 ... 80^3: -3 ... -6 %; 48^3: +-0, 40^3: +9 %, nd24k-class
+            // 3.92 -> 4.21 ms (small jobs without BIG launches: the chain is the critical path), so the split is taken
+            // from kChainSplitAutoFlops update flops on.  Splitting only the pieces of split supernodes loses everywhere
+            // (mode 1).  PARSY_CHAIN_SPLIT=0: never; 2: always (diagnostics).
             const int chain_split_mode = env_int("PARSY_CHAIN_SPLIT", S.update_flops >= kChainSplitAutoFlops ? 2 : 0);
             auto splits = [&](int t) {
                 const int real = S.csn_real[t];

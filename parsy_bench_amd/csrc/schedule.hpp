@@ -140,7 +140,7 @@ constexpr int kPieceWidth = 512;          // supernodes wider than 1.5 x this ar
                                           // of this many columns (PARSY_PIECE_WIDTH; 0: never split)
 constexpr double kBigAutoFlops = 1e11;    // update flops of a pattern from which the BIG launches are used ...
 constexpr double kPieceAutoFlops = 2e12;  // ... and from which the very wide supernodes are cut into pieces
-constexpr double kChainSplitAutoFlops = 1e12;   // jobs from this many update flops on: two chain launches per level (square / rows below)
+constexpr double kChainSplitAutoFlops = 1e11;   // jobs from this many update flops on: two chain launches per level (square / rows below)
 constexpr int kBigSuperMinTasks = 12288;    // BIG launches with at least this many single-tile tasks ...
 constexpr double kBigSuperMaxFill = 0.85;   // ... whose windows hold less than this share of their 8 x 8 fragments take 2 x 2 super-tiles
 constexpr int kBigGroup = 8;               // BIG launches: edge of the super-tiles whose tasks share an XCD (PARSY_BIG_GROUP)
