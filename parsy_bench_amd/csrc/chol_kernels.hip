@@ -678,13 +678,18 @@ __device__ __forceinline__ void invert_diag_blocks(lds_f64* __restrict__ Dg, lds
             for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
             y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
         }
-        __builtin_amdgcn_s_waitcnt(0);  // all reads of the sub-block precede the in-place writes
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of the sub-block precede the in-place writes
 #pragma unroll
         for (int rr = 1; rr < 16; ++rr)
             if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
     }
-    __syncthreads();
+    // a barrier for LDS alone: vector-memory loads the caller has in flight (the walker's next diagonal tile) stay
+    // in flight (__syncthreads() would wait for them: 1.5 us of the walker's step)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
+template <bool INVERT = true>
 __device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ tile, lds_f64* __restrict__ Dg,
                                                        lds_f64* __restrict__ invd, int nb) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -692,7 +697,7 @@ __device__ __forceinline__ void invert_and_trsm_inline(lds_f64* __restrict__ til
     auto cell = [&](int i, int c) -> lds_f64& {
         return tile[((i >> 5) * 2 + (c >> 5)) * (kSub * kLdSub) + (c & 31) * kLdSub + (i & 31)];
     };
-    invert_diag_blocks(Dg, invd);
+    if (INVERT) invert_diag_blocks(Dg, invd);   // (false: the caller has done it)
     // each wave owns 16 rows of the tile for the whole solve: no barrier between blocks
     const int rbase = 16 * wave;
     for (int b16 = 0; b16 < nb; b16 += 16) {
@@ -1534,9 +1539,26 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
             __syncthreads();  // Ljj and the tile are in LDS
             TRACE(J, 3);
             load_c();  // lands behind the TRSM
-            invert_and_trsm_inline((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, kTile);
+            invert_diag_blocks((lds_f64*)dgbuf, (lds_f64*)invd);
+            TRACE(J, 10);
+            invert_and_trsm_inline<false>((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, kTile);
             TRACE(J, 5);
-            write_tile(Tflat, row1, col0, 0);  // X = final tile (J+1,J)
+            {   // X = final tile (J+1,J): this wave's quadrant, all LDS reads first, then the stores
+                const int sr = row1 + kSub * wa, nr = min(kSub, r - sr), scx = col0 + kSub * wb;
+                double xq[kSub * kSub / 64];
+#pragma unroll
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    xq[q] = Tw[(e >> 5) * kLdSub + (e & 31)];
+                }
+#pragma unroll
+                for (int q = 0; q < kSub * kSub / 64; ++q) {
+                    const int e = q * 64 + lane;
+                    const int cc = e >> 5, rr = e & 31;
+                    if (rr < nr) st_sc1(&G[(int64_t)(scx + cc) * ld + sr + rr], xq[q]);
+                }
+            }
+            TRACE(J, 11);
             // X is published the same way (drain half way through the SYRK below).
             auto publish_x_wave = [&]() {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1567,8 +1589,10 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                             s10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, s10, 0, 0, 0);
                             s11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, s11, 0, 0, 0);
                         }
-                        if (half == 0) publish_x_wave();
+                        if (half == 0) TRACE(J, 12);
                     }
+                    TRACE(J, 13);
+                    publish_x_wave();   // (after the products: the stores of X have landed by now, the drain costs nothing)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int r0 = kq + 4 * v;

@@ -28,6 +28,9 @@ for J in range(nbc):
     print("%3d | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f | %6.1f  %d" % (
         J, d[0] - t0, d[2] - t0, d[4] - t0, d[3] - t0, d[5] - t0, d[6] - t0, step, int(tr.reshape(512, 16)[J, 7])))
     prev = d[0]
+    if J in (3, 4, 9):
+        print("      after potrf: +%.1f prep seen, +%.1f diag published, +%.1f inverted, +%.1f solved, +%.1f X stored, +%.1f half SYRK + X flag, +%.1f SYRK products, +%.1f subtracted + barrier" % (
+            d[4] - d[2], d[3] - d[4], d[10] - d[3], d[5] - d[10], d[11] - d[5], d[12] - d[11], d[13] - d[12], d[6] - d[13]))
     if J == 5:
         raw = tr.reshape(512, 16)[J]
         cyc = float(raw[9]) - float(raw[8])
