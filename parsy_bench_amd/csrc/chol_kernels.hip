@@ -1829,11 +1829,39 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
     auto frags = [&](const WaveEntry& E, int& nfr, int& nfc, int& r0, int& c0) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         const int NR = (mi + 15) >> 4, NC = (nj + 15) >> 4;
-        const int frb = (NR + kBigWR - 1) / kBigWR, fcb = (NC + kBigWC - 1) / kBigWC;
-        r0 = 16 * frb * wr;
-        c0 = 16 * fcb * wc;
-        nfr = min(frb, max(0, NR - frb * wr));
-        nfc = min(fcb, max(0, NC - fcb * wc));
+        // The grid the waves form over the entry's fragments is chosen PER ENTRY among the shapes a wave's 4 x 2
+        // accumulators allow -- 2 x 4 (any entry), 1 x 8 (<= 4 fragment rows), 4 x 2 (<= 4 fragment columns), 8 x 1
+        // (<= 2) -- for the fewest fragments in the busiest wave: 5 x 8 fragments are 3 x 2 = 6 per wave as 2 x 4 but
+        // 5 x 1 = 5 as 1 x 8; over the Flan-class input the busiest waves issue 4.2 % fewer products
+        // (tools/big_stats.py; dealing single fragments round-robin would make it 6.9 % but needs every accumulator's
+        // operands addressed on their own: registers the kernel does not have).
+        int wrs = 1;                                   // log2 of the waves along the rows: 2 x 4
+        int best = ((NR + 1) >> 1) * ((NC + 3) >> 2);
+        if (kBigWR == 2 && kBigWC == 4) {
+            if (NR <= 4 && NR * ((NC + 7) >> 3) < best) {            // 1 x 8
+                best = NR * ((NC + 7) >> 3);
+                wrs = 0;
+            }
+            if (NC <= 4 && ((NR + 3) >> 2) * ((NC + 1) >> 1) < best) {   // 4 x 2
+                best = ((NR + 3) >> 2) * ((NC + 1) >> 1);
+                wrs = 2;
+            }
+            if (NC <= 2 && ((NR + 7) >> 3) * NC < best) {            // 8 x 1
+                best = ((NR + 7) >> 3) * NC;
+                wrs = 3;
+            }
+        }
+        static_assert(kBigWaves == 8 || (kBigWR != 2 || kBigWC != 4), "k_chol_big: the entry grids are shapes of 8 waves");
+        const int wcs = (kBigWR == 2 && kBigWC == 4) ? 3 - wrs : 0;
+        const int WR = (kBigWR == 2 && kBigWC == 4) ? 1 << wrs : kBigWR, WC = (kBigWR == 2 && kBigWC == 4) ? 1 << wcs : kBigWC;
+        const int gwr = (kBigWR == 2 && kBigWC == 4) ? wave >> wcs : wr;
+        const int gwc = (kBigWR == 2 && kBigWC == 4) ? wave & (WC - 1) : wc;   // (for 2 x 4: wr, wc)
+        const int frb = (kBigWR == 2 && kBigWC == 4) ? (NR + WR - 1) >> wrs : (NR + WR - 1) / WR;
+        const int fcb = (kBigWR == 2 && kBigWC == 4) ? (NC + WC - 1) >> wcs : (NC + WC - 1) / WC;
+        r0 = 16 * frb * gwr;
+        c0 = 16 * fcb * gwc;
+        nfr = min(frb, max(0, NR - frb * gwr));
+        nfc = min(fcb, max(0, NC - fcb * gwc));
         // a block whose rows all precede its columns in the source's row order lies strictly above the diagonal of
         // the target (both windows count the source's rows from the same first row)
         if (E.ia + r0 + 16 * nfr - 1 < E.ja + c0) nfr = 0;
