@@ -642,6 +642,23 @@ def main():
                                "backward_solve_ms": db1 / 20 * 1e3, "solve_max_abs_err_vs_ones": e1,
                                "forward_backward_max_abs_err_vs_ones": eb1}
             del pl1
+            # configs[0] ex15-class (the reference's own CPU-runnable case; its 1-thread CPU figures: cpu_baseline.ex15_1_thread)
+            A0, p0 = M.workload("ex15")
+            s0 = I.analyze(A0, p0)
+            pl0 = api.Plan(s0, local_rank)
+            v0 = torch.from_numpy(np.ascontiguousarray(s0.A2x)).to(dev)
+            L0 = L_big[: int(s0.xsize)]
+            d0 = timed(lambda: pl0.factor_device(v0.data_ptr(), L0.data_ptr(), stream), 5, 50, collective=False)
+            if pl0.status() != 0:
+                raise RuntimeError(f"ex15 factorization status {pl0.status()}")
+            ds0, db0, e0, _, eb0 = measure_solves(pl0, s0, L0, 1, 5, 50)
+            extras["ex15"] = {"workload": "ex15-class stand-in (configs[0]): 83 x 83 5-point grid", "n": s0.n,
+                              "flops_F": s0.flops_colcount, "factorizations_per_sec": 50 / d0,
+                              "ms_per_factorization": d0 / 50 * 1e3, "solves_per_sec": 50 / ds0,
+                              "solve_ms": ds0 / 50 * 1e3, "backward_solve_ms": db0 / 50 * 1e3,
+                              "solve_max_abs_err_vs_ones": e0, "forward_backward_max_abs_err_vs_ones": eb0,
+                              "note": "a job of a few launch latencies: 20 launches per factorization"}
+            del pl0
             # configs[3] parabolic_fem-class: BCSC lower-triangular solve only, many right-hand sides
             A3, p3 = M.workload("parabolic_fem")
             s3 = I.analyze(A3, p3)
