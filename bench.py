@@ -18,7 +18,10 @@ right-hand sides) inputs are measured after it and reported as extra objects, ne
 `value`.  N > 1: the same matrix, ONE factorization over the ranks (strong scaling, as north_star
 describes it): etree subtrees below a cut on one rank each, the pieces of the separators above it
 dealt over all ranks, finished pieces sent point to point (RCCL over xGMI) after every level to
-the ranks that read them (csrc/dist.cpp, multigpu.py).
+the ranks that read them (csrc/dist.cpp, multigpu.py).  The N > 1 path is correct by construction (gloo tests
+with 2 and 4 ranks, N ranks sharing the one device: bitwise the single-device factor) but its RCCL messages between
+DISTINCT devices have not run on hardware yet -- the builder's box has one GPU; the line it prints carries
+`ranks_seen` and per-rank busy times so that a reader can tell.
 
 PyTorch is plumbing here: device buffers, the HIP stream, torch.distributed.  All
 numerics run in libparsy_amd.so through its C ABI.
@@ -152,9 +155,9 @@ def granted_cpus():
 def cpu_baseline_ex15(threads: int = 1):
     """configs[0]: the reference's own CPU-runnable case (ex15-class), as scripts/eval.sh:5-21 times it:
     chunk = 1, costParam = threads, levelParam in {2,1,0,-1,-2}, finalSeqNode in {2,4}; per setting 5
-    factorizations, the median; the best setting is reported.  The H-level partitions come from the
-    reference's own LBC partitioner (oracle/_ref, where it was built); otherwise every supernode is its own
-    w-partition (the factor is schedule independent)."""
+    factorizations, the median; the best setting is reported.  The H-level partitions are the reference's own
+    LBC partitioner's output, read from a committed fixture; without one for this thread count every supernode is
+    its own w-partition (the factor is schedule independent)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as O
     from parsy_bench_amd import inspector as I, matrices as M
@@ -162,14 +165,18 @@ def cpu_baseline_ex15(threads: int = 1):
     blas = O.bind_system_blas()
     A, perm = M.workload("ex15")
     sym = I.analyze(A, perm)
+    # The partitions are a committed fixture (tests/golden/lbc_ex15.npz, written by tests/golden/make_golden.py from
+    # the reference's getCoarseLevelSet_6 in the build container): nothing compiled from the reference is loaded here.
     settings = []
-    if O.have_ref():
-        try:
-            for lev in (2, 1, 0, -1, -2):
-                for fin in (2, 4):
-                    settings.append(((lev, fin), O.ref_hlevel(A, perm, threads, lev, fin)))
-        except Exception:
-            settings = []
+    fixture = ROOT / "tests" / "golden" / "lbc_ex15.npz"
+    if fixture.exists():
+        g = np.load(fixture)
+        for lev in (2, 1, 0, -1, -2):
+            for fin in (2, 4):
+                key = f"c{threads}_l{lev}_f{fin}"
+                if key + "_levelPtr" in g:
+                    settings.append(((lev, fin), (int(g[key + "_nLevels"][0]), g[key + "_levelPtr"], g[key + "_parPtr"],
+                                                  g[key + "_partition"])))
     lbc = bool(settings)
     if not settings:
         settings = [((None, None), I.trivial_hlevel(sym))]
@@ -195,8 +202,8 @@ def cpu_baseline_ex15(threads: int = 1):
     O.unbind_blas()
     return {"workload": "ex15-class stand-in (83x83 5-point grid, n = 6 889)", "threads": threads,
             "factorizations_per_sec": 1.0 / best["median_s"], "median_of": 5, "dense_kernels": blas or "built-in loops",
-            "schedule": ("reference LBC partitions (getCoarseLevelSet_6 via oracle/_ref), sweep of scripts/eval.sh, best of"
-                         if lbc else "one w-partition per supernode (oracle/_ref not present)"),
+            "schedule": ("reference LBC partitions (getCoarseLevelSet_6; committed fixture tests/golden/lbc_ex15.npz), sweep of scripts/eval.sh, best of"
+                         if lbc else "one w-partition per supernode (no fixture for this thread count)"),
             "best": best, "sweep": sweep,
             "solves_per_sec": 1.0 / ts_solve, "solve_max_abs_err": float(np.abs(x - 1.0).max())}
 

@@ -372,7 +372,11 @@ int parsy_order_nd(int n, const int* Ap, const int* Ai, int leaf, int* perm);
  * `devices` lists one HIP device per rank; a device may appear more than once (several ranks share it: how the
  * path is exercised on a node with fewer GPUs).  Every rank keeps its own lValues; finished pieces travel as
  * device-to-device copies (peer access over xGMI between different devices) of exactly the segments of the
- * parsy_dist messages, ordered by events.  values: host, nnz(A2) doubles. */
+ * parsy_dist messages, ordered by events.  values: host, nnz(A2) doubles.
+ * STATUS: verified bit for bit with several ranks sharing ONE device (tests/test_gpu_parity.py::test_distributed_*).
+ * The distinct-device branch -- hipDeviceEnablePeerAccess, hipStreamWaitEvent on another device's event, the copy
+ * kernel reading a peer's buffer -- has NOT run on hardware yet: no node with two GPUs was available to the builder
+ * (tests/test_multigpu_gpu.py::test_two_distinct_devices_* run it wherever two devices are visible). */
 typedef struct parsy_mg parsy_mg;
 parsy_mg* parsy_mg_create(const parsy_symbolic* sym, int nranks, const int* devices, int block);
 void parsy_mg_destroy(parsy_mg* mg);

@@ -1998,6 +1998,9 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
     // (started right after the barrier that ended the reads of that buffer; __syncthreads() waits for this wave's
     // DMA -- it counts as vector memory traffic -- before the barrier)
     int kcur = fetch(0);
+    // (explicit: the LDS-DMA of this wave has landed before the barrier -- the compiler emits the same wait for
+    // __syncthreads() today, but the memory model does not oblige it to: ADVICE round 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int nfr, nfc, r0, c0;
     frags(CE, nfr, nfc, r0, c0);
@@ -2031,6 +2034,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
         if (knext == 0) break;
         kcur = knext;
 #ifndef PARSY_BIGABL_NOBARRIER   // (diagnostic build: waves race through the staged chunks -- wrong results)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next chunk and its tile adds
         __syncthreads();
 #endif
         BIGSTAMP(5);

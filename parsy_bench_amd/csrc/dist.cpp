@@ -58,7 +58,8 @@ void build_dist(const Schedule& S, int nranks, int block, Dist& D) {
     // first, give no rank more than its share of the whole job (the pieces above the cut then even the ranks
     // out).  A subtree that one workgroup walks (Schedule::chol_subtree) is never opened.
     std::vector<double> sub((size_t)ns, 0.0);
-    std::vector<int32_t> size((size_t)ns, 1);
+    std::vector<int32_t> size((size_t)ns, 1), lowest((size_t)ns);
+    for (int s = 0; s < ns; ++s) lowest[(size_t)s] = s;
     std::vector<std::vector<int32_t>> children((size_t)ns);
     for (int s = 0; s < ns; ++s)
         for (int p = S.piece0[(size_t)s]; p < S.piece0[(size_t)s + 1]; ++p) sub[(size_t)s] += D.cost[(size_t)p];
@@ -66,10 +67,20 @@ void build_dist(const Schedule& S, int nranks, int block, Dist& D) {
         const int p = S.sparent[(size_t)s];
         if (p < 0) continue;
         if (p <= s) throw std::runtime_error("dist: the supernodal etree is not postordered");
+        // (children come before their parent, so lowest[s] / size[s] are final here) a subtree is handed out below as
+        // the index range [s - size + 1, s]: that needs a true postorder -- every subtree contiguous -- not merely
+        // parent > child
+        if (lowest[(size_t)s] != s - size[(size_t)s] + 1)
+            throw std::runtime_error("dist: the supernodal etree is topologically ordered but not postordered "
+                                     "(the subtree of supernode " + std::to_string(s) + " is not a contiguous index range)");
         sub[(size_t)p] += sub[(size_t)s];
         size[(size_t)p] += size[(size_t)s];
+        lowest[(size_t)p] = std::min(lowest[(size_t)p], lowest[(size_t)s]);
         children[(size_t)p].push_back(s);
     }
+    for (int s = 0; s < ns; ++s)
+        if (S.sparent[(size_t)s] < 0 && lowest[(size_t)s] != s - size[(size_t)s] + 1)
+            throw std::runtime_error("dist: the supernodal etree is not postordered (root " + std::to_string(s) + ")");
     using Item = std::pair<double, int32_t>;
     std::priority_queue<Item> heap;
     for (int s = 0; s < ns; ++s)
@@ -210,6 +221,17 @@ int64_t check_dist(const Schedule& S, const Dist& D, std::string& what) {
             else if (st_owner[(size_t)st] != o) fail("subtree " + std::to_string(st) + " of narrow supernodes is split over ranks");
         }
     }
+    // the part below the cut is descendant-closed per rank: a supernode marked in_subtree has every child marked too
+    // and owned by the same rank (what the sharded solves rely on when they take in_subtree as "my subtrees")
+    if ((int)D.in_subtree.size() == nc)
+        for (int t = 0; t < S.nsuper; ++t) {
+            const int par = S.sparent[(size_t)t];
+            if (par < 0 || !D.in_subtree[(size_t)S.piece0[(size_t)par]]) continue;
+            if (!D.in_subtree[(size_t)S.piece0[(size_t)t]])
+                fail("supernode " + std::to_string(par) + " lies below the cut but its child " + std::to_string(t) + " does not");
+            else if (D.owner[(size_t)S.piece0[(size_t)t]] != D.owner[(size_t)S.piece0[(size_t)par]])
+                fail("supernode " + std::to_string(par) + " and its child " + std::to_string(t) + " lie below the cut on different ranks");
+        }
     // delivered[(piece, rank)] = first row delivered to that rank, from the messages of the piece's level
     std::vector<int32_t> delivered((size_t)nc * nr, INT_MAX);
     std::vector<int32_t> col2piece;  // per real supernode: piece of every column (built on demand below)

@@ -469,6 +469,19 @@ int plan_factor_end(parsy_plan* pl, hipStream_t stream) {
     return 0;
 }
 
+// Error path of a caller that enqueues a factorization step by step: whatever was enqueued is allowed to finish
+// (caller's stream and the plan's side stream), then the plan is closed again so that a later factorization starts
+// clean.  The factor in d_L is partial.
+void plan_factor_abort(parsy_plan* pl, hipStream_t stream) {
+    if (!pl) return;
+    (void)hipStreamSynchronize(stream);
+    if (pl->side_stream != nullptr) (void)hipStreamSynchronize(pl->side_stream);
+    (void)hipGetLastError();
+    if (pl->factor_open) run_end(pl, stream);
+    pl->factor_open = false;
+    pl->factor_next_level = 0;
+}
+
 int plan_factor(parsy_plan* pl, const double* d_values, double* d_L, hipStream_t stream, bool init) {
     if (plan_factor_begin(pl, d_values, d_L, stream, init) != 0) return -1;
     if (plan_factor_levels(pl, 0, pl->S.cnlevels, d_L, stream) != 0) return -1;

@@ -83,6 +83,7 @@ int plan_factor(parsy_plan* plan, const double* d_values, double* d_L, hipStream
 int plan_factor_begin(parsy_plan* plan, const double* d_values, double* d_L, hipStream_t stream, bool init);
 int plan_factor_levels(parsy_plan* plan, int level0, int level1, double* d_L, hipStream_t stream);
 int plan_factor_end(parsy_plan* plan, hipStream_t stream);
+void plan_factor_abort(parsy_plan* plan, hipStream_t stream);   // error path: drain, close the open factorization
 int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
                hipStream_t stream);
 int plan_backsolve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream);

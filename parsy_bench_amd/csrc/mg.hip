@@ -196,11 +196,7 @@ int parsy_mg_set_values(parsy_mg* mg, const double* values) {
     return 0;
 }
 
-int parsy_mg_factor(parsy_mg* mg, double* seconds) {
-    if (!mg || !mg->have_values) {
-        set_last_error("parsy_mg_factor: null handle or no values (parsy_mg_set_values first)");
-        return -1;
-    }
+static int mg_factor_enqueue(parsy_mg* mg, double* seconds) {
     const parsy::Dist& D = parsy_dist_cxx(mg->dist);
     const int nr = mg->nranks;
     for (int r = 0; r < nr; ++r) {
@@ -258,15 +254,32 @@ int parsy_mg_factor(parsy_mg* mg, double* seconds) {
     return 0;
 }
 
-int parsy_mg_profile(parsy_mg* mg, double* main_ms, double* side_ms, double* copy_ms) {
+// One cleanup path for the step-by-step drivers below: on any error every rank's streams are drained,
+// an open factorization is closed, and profile mode is switched off, so that the handle stays usable.
+static void mg_abort(parsy_mg* mg) {
+    for (int r = 0; r < mg->nranks; ++r) {
+        (void)hipSetDevice(mg->device[(size_t)r]);
+        parsy::plan_factor_abort(mg->plan[(size_t)r], mg->stream[(size_t)r]);
+        parsy_plan_profile(mg->plan[(size_t)r], 0);
+    }
+    (void)hipGetLastError();
+}
+
+int parsy_mg_factor(parsy_mg* mg, double* seconds) {
     if (!mg || !mg->have_values) {
-        set_last_error("parsy_mg_profile: null handle or no values (parsy_mg_set_values first)");
+        set_last_error("parsy_mg_factor: null handle or no values (parsy_mg_set_values first)");
         return -1;
     }
+    const int rc = mg_factor_enqueue(mg, seconds);
+    if (rc < 0) mg_abort(mg);   // (rc > 0: a non-positive pivot -- the run completed)
+    return rc;
+}
+
+static int mg_profile_run(parsy_mg* mg, double* main_ms, double* side_ms, double* copy_ms, std::vector<hipEvent_t>& c0,
+                          std::vector<hipEvent_t>& c1) {
     const parsy::Dist& D = parsy_dist_cxx(mg->dist);
     const int nr = mg->nranks, nl = D.nlevels;
     if (copy_ms) std::fill(copy_ms, copy_ms + (size_t)nr * nl, 0.0);
-    std::vector<hipEvent_t> c0((size_t)nr), c1((size_t)nr);
     for (int r = 0; r < nr; ++r) {
         MG_HIP(hipSetDevice(mg->device[(size_t)r]), -1);
         MG_HIP(hipStreamSynchronize(mg->stream[(size_t)r]), -1);
@@ -314,12 +327,26 @@ int parsy_mg_profile(parsy_mg* mg, double* main_ms, double* side_ms, double* cop
         parsy_plan_profile_levels(mg->plan[(size_t)r], main_ms ? main_ms + (size_t)r * nl : nullptr,
                                   side_ms ? side_ms + (size_t)r * nl : nullptr);
         parsy_plan_profile(mg->plan[(size_t)r], 0);
-        (void)hipEventDestroy(c0[(size_t)r]);
-        (void)hipEventDestroy(c1[(size_t)r]);
         const int st = parsy_factor_status(mg->plan[(size_t)r]);
         if (st != 0 && status == 0) status = st;
     }
     return status;
+}
+
+int parsy_mg_profile(parsy_mg* mg, double* main_ms, double* side_ms, double* copy_ms) {
+    if (!mg || !mg->have_values) {
+        set_last_error("parsy_mg_profile: null handle or no values (parsy_mg_set_values first)");
+        return -1;
+    }
+    std::vector<hipEvent_t> c0((size_t)mg->nranks, nullptr), c1((size_t)mg->nranks, nullptr);
+    const int rc = mg_profile_run(mg, main_ms, side_ms, copy_ms, c0, c1);
+    if (rc < 0) mg_abort(mg);
+    for (int r = 0; r < mg->nranks; ++r) {
+        (void)hipSetDevice(mg->device[(size_t)r]);
+        if (c0[(size_t)r]) (void)hipEventDestroy(c0[(size_t)r]);
+        if (c1[(size_t)r]) (void)hipEventDestroy(c1[(size_t)r]);
+    }
+    return rc;
 }
 
 int parsy_mg_rank_ms(parsy_mg* mg, double* rank_ms) {

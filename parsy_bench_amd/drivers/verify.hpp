@@ -22,8 +22,11 @@ inline bool verify_requested() {
 }
 
 // One HIP device per rank from PARSY_DEVICES ("0,1,2,3"; a device may repeat); empty: single-device run.
-inline std::vector<int> device_list() {
+// PARSY_DEVICES=0,1,..: device ordinals, non-negative decimal integers separated by commas.  `ok` (if given) is
+// cleared when an entry is anything else ("a,b" must not silently become devices 0,0).
+inline std::vector<int> device_list(bool* ok = nullptr) {
     std::vector<int> d;
+    if (ok) *ok = true;
     const char* e = std::getenv("PARSY_DEVICES");
     if (!e) return d;
     std::string s(e);
@@ -31,7 +34,15 @@ inline std::vector<int> device_list() {
     while (p < s.size()) {
         size_t q = s.find(',', p);
         if (q == std::string::npos) q = s.size();
-        if (q > p) d.push_back(std::atoi(s.substr(p, q - p).c_str()));
+        if (q > p) {
+            const std::string tok = s.substr(p, q - p);
+            const bool numeric = tok.find_first_not_of("0123456789") == std::string::npos && tok.size() <= 4;
+            if (!numeric) {
+                if (ok) *ok = false;
+                return {};
+            }
+            d.push_back(std::atoi(tok.c_str()));
+        }
         p = q + 1;
     }
     return d;

@@ -111,6 +111,26 @@ def dense_kernel_cases():
     print("dense kernels:", len(out), "arrays")
 
 
+def lbc_ex15_cases():
+    """The reference's own LBC partitions (getCoarseLevelSet_6, cholesky/InspectionLevel_06.h:18) of the ex15-class
+    stand-in for the sweep of scripts/eval.sh:5-21 (levelParam in {2,1,0,-1,-2}, finalSeqNode in {2,4}) at
+    costParam = 1, 4, 8, 16 threads: what bench.py's cpu_baseline_ex15 schedules the CPU port by."""
+    A, perm = M.workload("ex15")
+    out = {}
+    for cost in (1, 4, 8, 16):
+        for lev in (2, 1, 0, -1, -2):
+            for fin in (2, 4):
+                nl, levelPtr, parPtr, partition = O.ref_hlevel(A, perm, cost, lev, fin)
+                key = f"c{cost}_l{lev}_f{fin}"
+                out[key + "_nLevels"] = np.array([nl], np.int32)
+                out[key + "_levelPtr"] = levelPtr
+                out[key + "_parPtr"] = parPtr
+                out[key + "_partition"] = partition
+    np.savez_compressed(OUT / "lbc_ex15.npz", **out)
+    print("lbc_ex15:", len(out) // 4, "settings")
+
+
 if __name__ == "__main__":
     inspector_cases()
     dense_kernel_cases()
+    lbc_ex15_cases()
