@@ -410,6 +410,28 @@ def main():
         raise SystemExit(f"factorization failed: status {status} (> 0: non-positive pivot at that column; "
                          f"< 0: a hand-off wait inside a launch timed out)")
 
+    # ---- N > 1: who took part (evidence for the reader of the line: ranks seen by a collective, their devices,
+    # what each rank's device spent on the last factorization, what each rank sent) -----
+    multi = None
+    if world > 1:
+        import socket
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{socket.gethostname()}/cuda:{dev_index}/{getattr(props, 'uuid', '')}/{props.name}"
+        mine = torch.tensor([float(rank), float(dev_index), float(int(hashlib.sha256(ident.encode()).hexdigest()[:12], 16)),
+                             float(plan.last_factor_ms()), float(DF.sent_elements * 8)], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [t.cpu().tolist() for t in allr]
+        multi = {"ranks_seen": len({int(r[0]) for r in rows}),
+                 "distinct_devices": len({(int(r[1]), int(r[2])) for r in rows}),
+                 "rank_device_index": [int(r[1]) for r in rows],
+                 "rank_device_ms_last_factorization": [round(r[3], 3) for r in rows],
+                 "rank_bytes_sent_per_factorization": [int(r[4]) for r in rows],
+                 "backend": backend + (" (= RCCL)" if backend == "nccl" else " (rehearsal: host-staged messages)"),
+                 "note": "device ms = hipEvents around the rank's own launches and exchanges of the last timed factorization; "
+                         "distinct_devices < ranks_seen means ranks shared a GPU (a rehearsal, not a scaling measurement)"}
+
     # ---- two independent factorizations in flight (reported beside `value`, never as `value`) -----
     pipelined = None
     if world == 1 and args.in_flight > 1 and int(sym.xsize) * 8 * args.in_flight < 64e9:
@@ -496,8 +518,15 @@ def main():
                 torch.cuda.synchronize()
                 plan.profile_collect()
             prof_s = plan.profile_get()
+            plan.profile(2)
+            for _ in range(args.profile_steps):
+                X.copy_(B)
+                plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+                torch.cuda.synchronize()
+                plan.profile_collect()
+            prof_b = plan.profile_get()
         plan.profile(0)
-        prof = (prof_f, prof_s)
+        prof = (prof_f, prof_s, prof_b if BX is not None else None)
 
     if rank != 0:
         if world > 1:
@@ -528,7 +557,7 @@ def main():
             "n": sym.n, "nnz_A_lower": int(sym.nnzA), "nsuper": sym.nsuper, "nnz_L": int(sym.nnzL),
             "xsize": int(sym.xsize), "flops_F": sym.flops_colcount, "flops_executed": sym.flops_stored,
             "etree_levels": sym.nlevels, "cholesky_view": {k: info[k] for k in (
-                "n_pieces", "chol_levels", "piece_width", "big_min_k", "big_tasks", "big_entries")},
+                "n_pieces", "chol_levels", "piece_width", "big_min_k", "big_tasks", "big_entries", "dense_entries", "dense_tasks")},
             "launches_per_factorization": info["chol_launches"],
             "parallelism": "1 GPU" if world == 1 else (
                 f"{world} GPUs: etree subtrees below a cut on one rank each, the pieces of the separators above it dealt "
@@ -543,12 +572,13 @@ def main():
         "backward_solve_ms": (dt_b / args.steps * 1e3) if dt_b else None,
         "forward_backward_max_abs_err_vs_ones": back_err,
         "throughput_in_flight": pipelined,
+        "multi_gpu": multi,
         "sharded_solves": sharded,
         "inspect_seconds": t_inspect, "plan_seconds": t_plan,
     }
 
     if prof is not None:
-        pf, ps = prof
+        pf, ps, pb = prof
         runs = pf["runs"]
         kinds = {k: v / runs for k, v in pf["ms"].items() if v > 0}
         launches = {k: v // runs for k, v in pf["launches"].items() if v > 0}
@@ -559,12 +589,32 @@ def main():
                  "algorithmic_flops_per_factorization": tile_flops, "kernel_ms_per_factorization_serialized": tile_ms}
         tiles["frac"] = tiles["achieved"] / FP64_MFMA_PEAK_TFLOPS
         big_ms, big_n = kinds.get("BIG", 0.0), launches.get("BIG", 0)
-        if big_ms > 0 and info["big_flops"] >= tile_flops:
-            # dominant kernel: k_chol_big.  Algorithmic flops = the reference's DSYRK + DGEMM counts of the updates
-            # it applies: K n1 (n1 + 1) + 2 K (m - n1) n1 per (target, descendant) pair, exact from the schedule
+        dense_ms, dense_n = kinds.get("DENSE", 0.0), launches.get("DENSE", 0)
+        ragged_flops = info["big_flops"] - info["dense_flops"]
+        # the two kernels of the BIG updates side by side (algorithmic flops = the reference's DSYRK + DGEMM counts of
+        # the updates they apply: K n1 (n1 + 1) + 2 K (m - n1) n1 per (target, descendant) pair, exact from the schedule,
+        # split by entry: full 128 x 128 blocks -> k_chol_dense, the ragged rest -> k_chol_big)
+        big_kernels = {
+            "k_chol_dense": {"ms_per_factorization_serialized": dense_ms, "launches": int(dense_n), "algorithmic_flops": info["dense_flops"],
+                             "achieved": info["dense_flops"] / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0},
+            "k_chol_big": {"ms_per_factorization_serialized": big_ms, "launches": int(big_n), "algorithmic_flops": ragged_flops,
+                           "achieved": ragged_flops / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0},
+            "both": {"ms_per_factorization_serialized": big_ms + dense_ms, "algorithmic_flops": info["big_flops"],
+                     "achieved": info["big_flops"] / ((big_ms + dense_ms) * 1e-3) / 1e12 if big_ms + dense_ms > 0 else 0.0},
+        }
+        for v in big_kernels.values():
+            v["frac"] = v["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        if dense_ms > big_ms and dense_ms > tile_ms:
+            # dominant kernel: k_chol_dense
+            name, dom_ms, dom_n, dom_flops = ("k_chol_dense (the full 128x128 blocks of the reference's DSYRK/DGEMM of wide "
+                                              "descendants and between the pieces of split supernodes: 4-slot LDS-DMA ring, "
+                                              "FP64 MFMA, software-pipelined operand reads)"), dense_ms, dense_n, info["dense_flops"]
+            key = "k_chol_dense"
+        elif big_ms > 0 and info["big_flops"] >= tile_flops:
+            # dominant kernel: k_chol_big
             name, dom_ms, dom_n, dom_flops = ("k_chol_big (LDS-staged 128x128 FP64-MFMA update tiles: the reference's "
                                               "DSYRK/DGEMM of wide descendants and between the pieces of split "
-                                              "supernodes)"), big_ms, big_n, info["big_flops"]
+                                              "supernodes)"), big_ms, big_n, ragged_flops
             key = "k_chol_big"
         else:
             name, dom_ms, dom_n, dom_flops, key = tiles["kernel"], tile_ms, launches.get("TILES", 0) + launches.get(
@@ -598,6 +648,7 @@ def main():
             "whole_job": {"flops_F": sym.flops_colcount, "achieved": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12,
                           "frac": sym.flops_colcount / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "kind_ms_per_factorization_serialized": kinds,
+            "big_update_kernels": big_kernels,
             "tile_kernel": tiles,
         }
         if ps is not None:
@@ -624,6 +675,33 @@ def main():
                 "algorithmic_bytes_per_solve": solve_bytes, "traffic": solve_traffic,
                 "traffic_unit": "HBM-side bytes per forward solve (k_diag_inverse + k_solve_tiny + k_solve_small + k_solve_chain_w, same PMC summary)",
                 "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
+            }
+
+        if pb is not None:
+            bruns = pb["runs"]
+            back_traffic = None
+            try:
+                pmc = json.load(open(ROOT / "profiles" / f"{PMC_ROUND}_{args.workload}_pmc_traffic.json"))
+                if pmc.get("kernel_source_hash") == kernel_source_hash() and nrhs == 1:
+                    ks = pmc["kernels"]
+                    bwd = [v for k, v in ks.items() if k.startswith("k_bsolve")]
+                    nsolves = pmc["factorizations_in_the_profiled_run"]
+                    back_traffic = (sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in bwd) / max(nsolves, 1)
+                                    + ks["k_diag_inverse"]["hbm_bytes_per_launch"])
+            except (OSError, ValueError, KeyError):
+                pass
+            # the backward solve L' x = y reads the same bytes as the forward one: every stored value of L once, the
+            # row ids once, x read and written once per right-hand side
+            back_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
+            b_ms = sum(pb["ms"].values()) / bruns
+            out["roofline_backsolve"] = {
+                "bound": "hbm", "achieved": back_bytes / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (back_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if b_ms > 0 else 0.0,
+                "algorithmic_bytes_per_solve": back_bytes, "traffic": back_traffic,
+                "traffic_unit": "HBM-side bytes per backward solve (k_diag_inverse + k_bsolve_*, same PMC summary)",
+                "ms_per_solve_serialized": b_ms,
+                "kind_ms_per_solve": {k: v / bruns for k, v in pb["ms"].items() if v > 0},
             }
 
     # ---- extra objects: the other single-GPU configurations of BASELINE.json (never `value`) ----

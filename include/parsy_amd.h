@@ -146,6 +146,9 @@ typedef struct parsy_plan_info {
     int32_t chol_subtrees, chol_subtree_supernodes;
     int32_t solve_subtrees, solve_subtree_supernodes;
     int32_t backsolve_launches;    /* kernel launches per backward solve */
+    int32_t dense_tasks;           /* workgroups of the DENSE launches (k_chol_dense) per factorization */
+    double dense_flops;            /* part of big_flops in dense entries (full 128 x 128 blocks below the diagonal): k_chol_dense */
+    int64_t dense_entries;
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

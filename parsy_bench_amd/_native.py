@@ -55,7 +55,8 @@ class PlanInfo(C.Structure):
         ("big_min_k", C.c_int32),
         ("chol_subtrees", C.c_int32), ("chol_subtree_supernodes", C.c_int32),
         ("solve_subtrees", C.c_int32), ("solve_subtree_supernodes", C.c_int32),
-        ("backsolve_launches", C.c_int32),
+        ("backsolve_launches", C.c_int32), ("dense_tasks", C.c_int32),
+        ("dense_flops", C.c_double), ("dense_entries", C.c_int64),
     ]
 
     def as_dict(self):

@@ -330,6 +330,10 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     for (size_t b = 0; b + 1 < S.solve_small_ranges.size(); b += 2)
         o->solve_subtree_supernodes += S.solve_small_ranges[b + 1] - S.solve_small_ranges[b];
     o->backsolve_launches = (int32_t)S.bsolve.size();
+    for (const parsy::Launch& l : S.chol)
+        if (l.kind == parsy::kLaunchDense) o->dense_tasks += l.count;
+    o->dense_flops = S.dense_flops;
+    o->dense_entries = S.n_dense_entries;
     return 0;
 }
 
@@ -412,6 +416,24 @@ int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap)
             o[6] = E.ia - E.ja;
         }
         ++t;
+    }
+    return n;
+}
+
+// Diagnostics: the tasks of the DENSE launches in launch order as rows of (launch index, 8-wide k chunks).
+int64_t parsy_debug_dense_tasks(const parsy_plan* pl, int32_t* out, int64_t cap) {
+    if (!pl) return -1;
+    const parsy::Schedule& S = pl->S;
+    int64_t n = 0;
+    int li = 0;
+    for (const parsy::Launch& l : S.chol) {
+        if (l.kind != parsy::kLaunchDense) continue;
+        for (int q = l.first; q < l.first + l.count; ++q, ++n)
+            if (out && n < cap) {
+                out[2 * n] = li;
+                out[2 * n + 1] = S.big_tasks[(size_t)q].part;
+            }
+        ++li;
     }
     return n;
 }

@@ -1744,6 +1744,17 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
     const int ld = D.ld;
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
+#if defined(PARSY_BIG_DEPHASE) || defined(PARSY_BIG_PRIO_TG)
+    // (experiments) the workgroups resident on one compute unit are told apart by HW_ID.TG_ID (bits 19:16)
+    const int tg_id = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4);
+#endif
+#ifdef PARSY_BIG_DEPHASE
+    // the first residents of a launch start together and -- tasks of equal length -- stay in step: both stage, both
+    // multiply.  The odd one of a compute unit starts half a chunk period late.
+    if ((int)blockIdx.x < 512 && (tg_id & 1)) {
+        __builtin_amdgcn_s_sleep(PARSY_BIG_DEPHASE);
+    }
+#endif
 #ifdef PARSY_BIGABL_ZEROOPS
     const long long zmask = td.part == 12345 ? -1ll : 0ll;   // (0 at run time; the compiler cannot know)
 #endif
@@ -1877,7 +1888,12 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
         const double* __restrict__ Cb = &S.C[b][kq * kBLd + c0 + l15];
         // the multiplying waves win the issue arbitration over the waves that write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
+#ifdef PARSY_BIG_PRIO_TG
+        if (tg_id & 1) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+#else
         __builtin_amdgcn_s_setprio(1);
+#endif
         // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
         // BIG launches on the Flan-class input)
         double rv[2][kBigNfr], cv[2][kBigNfc];
@@ -2043,6 +2059,325 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
 #endif
     }
 }
+
+// ---------------------------------------------------------------------------
+// DENSE: the BIG entries that are full 128 x 128 blocks of a source's rows (70 % of the BIG launches' products on the
+// Flan-class input; the reference hands these to DGEMM:
+// parallel_PB_Cholesky_05.h:173, and to threaded BLAS-3 in its root phase, :269-411).  A kernel of its own, not a
+// second path of k_chol_big: no ragged window, so no wave-uniform branch per product, no clamp per load; and a loop
+// built so that a wave alone keeps its matrix pipe busy --
+//   * 4 waves (256 threads), each a 64 x 64 block of the product (16 accumulators of v_mfma_f64_16x16x4_f64 in
+//     AGPRs: 8 LDS operand reads per 16 products), two workgroups per compute unit;
+//   * k chunks of 8 in a RING OF FOUR LDS slots (the same 72 KB as k_chol_big's two chunks of 16), filled by LDS-DMA
+//     three chunks ahead; a wave waits for ITS OWN DMA of the next chunk (s_waitcnt vmcnt(4): the chunk after that may
+//     stay in flight) and then meets the others at ONE s_barrier per chunk, placed between the chunk's two k steps:
+//     the operands of the second k step are in registers by then, and the barrier that makes chunk n + 1 visible also
+//     frees the slot of chunk n - 1 for the DMA of chunk n + 3 -- so the first operands of chunk n + 1 are read while
+//     the second k step of chunk n is multiplied, and nothing waits at the chunk boundary;
+//   * a source's ragged last chunk: the DMA re-reads its last column for the columns it does not have and the lanes of
+//     those k positions multiply by zero (a select on the operand, no branch).
+// The product is formed negated and added to the tile with no-return FP64 atomic adds as in k_chol_big (a block that
+// straddles the target's diagonal is multiplied whole and its upper part dropped here).  A task's dense entries come
+// first in its entry list, in update order; the launch of the ragged rest (k_chol_big) follows on the same stream, so
+// the order of sums per entry of L is fixed: dense entries, then ragged ones, each in the reference's update order.
+// ---------------------------------------------------------------------------
+static constexpr int kDK = 8;                        // k extent of a chunk
+static constexpr int kDSlots = 4;                    // ring depth
+static constexpr int kDOp = kDK * kBLd;              // doubles of one operand of a chunk (k stride kBLd: see kBLd)
+static constexpr int kDSlot = 2 * kDOp;              // a slot: the block's rows (R), then its columns (C)
+static constexpr int kDenseThreads = 256;
+#ifdef PARSY_DENSESTAMPS
+// (diagnostic build) shader clocks per phase of the chunk loop, summed over every wave of every dense launch
+__device__ unsigned long long g_densephase[16];
+// (PARSY_DENSESTAMPS is a bit mask of the probes that are compiled in: every probe is a scalar memory operation with a
+// wait for everything the wave has in flight at the LDS, so few probes distort less)
+#define DSTAMP(i) do { if ((PARSY_DENSESTAMPS >> (i)) & 1) { const unsigned long long now_ = __builtin_readcyclecounter(); dph[i] += now_ - dlast; dlast = now_; } } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* __restrict__ sn,
+                                                                const int32_t* __restrict__ relpos,
+                                                                const WaveEntry* __restrict__ ents,
+                                                                const TileDesc* __restrict__ tasks,
+                                                                double* __restrict__ L) {
+    // (+ one 1-KiB landing area per wave for the placeholder DMA of the last iterations: below)
+    __shared__ __attribute__((aligned(16))) double S[kDSlots * kDSlot + 4 * 128];
+    {
+        int agpr_hint = 0;
+        asm volatile("; accumulators in AGPRs %0" ::"a"(agpr_hint));
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int r0 = 64 * (wave >> 1), c0 = 64 * (wave & 1);   // this wave's block of the 128 x 128 product
+    const TileDesc td = tasks[blockIdx.x];
+    const int64_t e_begin = td.wp, e_end = td.sp;
+    if (e_begin >= e_end) return;
+    const SnDesc D = sn[td.sn];
+    double* __restrict__ G = L + D.px;
+    const int ld = D.ld;
+    const int total = td.part;     // chunks of the task: sum over its entries of ceil(K / 8) (host)
+
+    // ---- loader: wave w moves columns k = w, w + 4 of both operands of a chunk (lane l: rows 2l, 2l + 1: one
+    // 1-KiB column per instruction), always four instructions per chunk, so that vmcnt counts chunks.  The four are
+    // issued one by one BETWEEN the products of the chunk's second k step (issue(slot, 0..3), then advance()): a
+    // vector-memory instruction that finds the memory pipeline's queue full blocks its wave, and a wave that has just
+    // issued four products leaves the matrix pipe busy meanwhile.
+    int64_t le = e_begin;
+    int lk = 0;
+    WaveEntry LE = ents[le];
+    // this lane's rows in column (lk + wave) of the two windows.  (A window of fewer than 128 rows -- the few ragged
+    // entries a launch hands to this kernel rather than to a launch of their own -- re-reads its last row, at most one
+    // row beyond it as in k_chol_big; those products are formed and never stored.)
+    auto lane_ptr = [&](const WaveEntry& E, bool cols) {
+        const int rows = cols ? (E.mn >> 8) & 255 : E.mn & 255;
+        return L + E.src + (cols ? E.ja : E.ia) + min(2 * lane, rows - 1) + (int64_t)wave * E.ld;
+    };
+    const double* __restrict__ lpR = lane_ptr(LE, false);
+    const double* __restrict__ lpC = lane_ptr(LE, true);
+    // (live = false: the task has no chunk n + 3 -- the instruction is issued all the same, from a valid address into
+    // the wave's landing area, so that every iteration issues exactly four and the loop is ONE path: a second copy of
+    // the product block for the last iterations made the register allocator move the accumulators through scratch)
+    auto issue = [&](int slot, int i, bool live) {
+        double* __restrict__ dst = live ? &S[slot * kDSlot + (i & 1) * kDOp + (wave + 4 * (i >> 1)) * kBLd]
+                                        : &S[kDSlots * kDSlot + wave * 128];
+        const double* __restrict__ src = (i & 1) ? lpC : lpR;
+        // a source's ragged last chunk re-reads its last column for the columns it does not have (their products are
+        // masked out): klast = last column it has, counted from lk
+        const int klast = LE.K - 1 - lk;
+        int64_t off = (i >> 1) ? 4 * (int64_t)LE.ld : 0;
+        if (klast < kDK - 1) off = (int64_t)(min(wave + 4 * (i >> 1), klast) - wave) * LE.ld;
+        if (!live) {
+            src = G + 2 * lane;
+            off = 0;
+        }
+#if defined(PARSY_DENSEABL_NODMA)        // (diagnostic builds: wrong results) no staging at all: what the loop costs without it
+        (void)src; (void)off; (void)dst;
+#elif defined(PARSY_DENSEABL_SAMECHUNK)  // every chunk re-reads the task's first one: staging from cache hits
+        glds16(L + ents[e_begin].src + ((i & 1) ? ents[e_begin].ja : ents[e_begin].ia) + 2 * lane, dst);
+#else
+        glds16(src + off, dst);
+#endif
+    };
+    auto advance = [&]() {
+        lk += kDK;
+        lpR += (int64_t)kDK * LE.ld;
+        lpC += (int64_t)kDK * LE.ld;
+        if (lk >= LE.K) {
+            lk = 0;
+            ++le;
+            if (le < e_end) {
+                LE = ents[le];
+                lpR = lane_ptr(LE, false);
+                lpC = lane_ptr(LE, true);
+            }
+        }
+    };
+    auto fetch = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue(slot, i, true);
+        advance();
+    };
+
+    // ---- consumer
+    int64_t ce = e_begin;
+    int ck = 0;
+    WaveEntry CE = LE;
+    double4_t acc[4][4];   // [16-row fragment of the column window (C)][... of the row window (R)]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
+    // The operand reads and their waits are written out (inline assembly): the compiler waits for EVERY outstanding
+    // LDS read whenever it needs one of them (s_waitcnt lgkmcnt(0) at the loop header and before each product block --
+    // a full LDS round trip twice per chunk); here each wait names how many younger reads may stay in flight.  The
+    // registers a read fills pass through the wait statement ("+v"), so that no use can be scheduled ahead of it.
+    struct Ops { double2_t r01, r23, c01, c23; };   // 16-row fragments 0..3 of the wave's rows (R) and columns (C), one k each
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)(&S[0]);
+    const unsigned roff = lds0 + 8u * (unsigned)(kq * kBLd + r0 + l15), coff = lds0 + 8u * (unsigned)(kDOp + kq * kBLd + c0 + l15);
+    auto read_ops = [&](int slot, int kstep, Ops& o) {
+        const unsigned so = (unsigned)(slot * kDSlot + 4 * kstep * kBLd) * 8u;
+        const unsigned ar = roff + so, ac = coff + so;
+        asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(o.r01) : "v"(ar));
+        asm volatile("ds_read2_b64 %0, %1 offset0:32 offset1:48" : "=v"(o.r23) : "v"(ar));
+        asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(o.c01) : "v"(ac));
+        asm volatile("ds_read2_b64 %0, %1 offset0:32 offset1:48" : "=v"(o.c23) : "v"(ac));
+    };
+#define PARSY_DENSE_WAIT(o, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(o.r01), "+v"(o.r23), "+v"(o.c01), "+v"(o.c23))
+    // a source's ragged last chunk: lanes of k positions it does not have multiply by zero
+    auto mask_ops = [&](Ops& o, bool ok) {
+        o.r01 = ok ? o.r01 : double2_t{0, 0};
+        o.r23 = ok ? o.r23 : double2_t{0, 0};
+        o.c01 = ok ? o.c01 : double2_t{0, 0};
+        o.c23 = ok ? o.c23 : double2_t{0, 0};
+    };
+    // the four products of column fragment fc
+    auto products4 = [&](const Ops& o, int fc) {
+        const double rv[4] = {o.r01[0], o.r01[1], o.r23[0], o.r23[1]};
+        const double cv[4] = {o.c01[0], o.c01[1], o.c23[0], o.c23[1]};
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+            acc[fc][fr] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[fc], rv[fr], acc[fc][fr], 0, 0, 1);
+    };
+    auto products = [&](const Ops& o) {
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) products4(o, fc);
+    };
+    auto epilogue = [&](const WaveEntry& E) {
+        const bool ident = (E.mn >> 16) != 0;
+        const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+        int prow[4], pcol[4][4];
+        if (ident) {
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) prow[fr] = E.ia + r0 + 16 * fr + l15;
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] = E.ja + c0 + 16 * fc + kq + 4 * v;
+        } else {
+            // (unconditional loads, rows past a ragged window re-read its last index: all twenty in flight together)
+            const int32_t* __restrict__ rpi = relpos + (int64_t)E.rel + E.ia;
+            const int32_t* __restrict__ rpj = relpos + (int64_t)E.rel + E.ja;
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) prow[fr] = rpi[min(r0 + 16 * fr + l15, mi - 1)];
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] = rpj[min(c0 + 16 * fc + kq + 4 * v, nj - 1)];
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) prow[fr] -= D.rbias;
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pcol[fc][v] -= D.rbias;
+        }
+        // rows / columns the window does not have; the part of a block above the target's diagonal
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+            if (r0 + 16 * fr + l15 >= mi) prow[fr] = -1;
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (c0 + 16 * fc + kq + 4 * v >= nj) pcol[fc][v] = 0x7fffffff;
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc) {
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (prow[fr] >= pcol[fc][v])
+                        unsafeAtomicAdd(&G[(int64_t)pcol[fc][v] * ld + prow[fr]], acc[fc][fr][v]);
+                acc[fc][fr] = double4_t{0, 0, 0, 0};
+            }
+        }
+    };
+
+    // ---- prologue: chunks 0, 1, 2 on their way; chunk 0 landed and visible; the operands of its two k steps read
+    fetch(0);
+    if (total > 1) fetch(1);
+    else
+        for (int i = 0; i < 4; ++i) issue(0, i, false);
+    if (total > 2) fetch(2);
+    else
+        for (int i = 0; i < 4; ++i) issue(0, i, false);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+#ifdef PARSY_DENSESTAMPS
+    unsigned long long dph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dlast = __builtin_readcyclecounter();
+#endif
+    Ops A, B;
+    read_ops(0, 0, A);
+    read_ops(0, 1, B);
+    PARSY_DENSE_WAIT(A, 4);
+    if (CE.K < 4) mask_ops(A, kq < CE.K);
+    // Software pipeline over the k steps: every LDS read is issued one whole k step (16 products) before its
+    // operands are needed, into the registers the products issued just before have finished reading, so that a wave
+    // never waits for the LDS.  State at the top of iteration n: A = the operands of chunk n's first k step, landed
+    // and masked; B = those of its second k step, on their way.
+    for (int n = 0; n < total; ++n) {
+        const int kend = CE.K - ck;            // columns the source has from this chunk on (>= 1)
+        const int nslot = (n + 1) & (kDSlots - 1);   // (after the last chunk: reads of a stale slot, never used)
+        DSTAMP(0);
+        __builtin_amdgcn_s_setprio(1);   // (the multiplying waves win the issue arbitration, as in k_chol_big)
+        products(A);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        DSTAMP(1);
+        // chunk n + 1: this wave's part has landed (the four instructions of chunk n + 2 -- or their placeholders --
+        // may stay in flight), then everybody's
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        DSTAMP(2);
+        asm volatile("s_barrier" ::: "memory");
+        DSTAMP(3);
+        DSTAMP(4);
+        read_ops(nslot, 0, A);
+        PARSY_DENSE_WAIT(B, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        DSTAMP(5);
+        if (kend < kDK) mask_ops(B, kq + 4 < kend);   // (only a source's last chunk can be ragged)
+        {
+            const bool live = n + 3 < total;
+            const int fslot = (n + 3) & (kDSlots - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                products4(B, g);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(fslot, g, live);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (live) advance();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DSTAMP(6);
+        ck += kDK;
+        if (ck >= CE.K) {
+            epilogue(CE);
+            // the adds of this source are performed before the next barrier: the next source's adds into the same
+            // entries of L may come from other waves (another row map), and the order of sums must not depend on timing
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ck = 0;
+            ++ce;
+            if (ce < e_end) {
+                CE = ents[ce];
+                // (waited for HERE: a scalar load still pending at the loop header would make the compiler wait for
+                // every outstanding LDS read there)
+                asm volatile("" ::"s"(CE.K), "s"(CE.mn), "s"(CE.ia), "s"(CE.ja), "s"(CE.rel));
+            }
+            DSTAMP(7);
+        }
+        read_ops(nslot, 1, B);
+        PARSY_DENSE_WAIT(A, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (CE.K - ck < 4) mask_ops(A, kq < CE.K - ck);
+        DSTAMP(8);
+    }
+#ifdef PARSY_DENSESTAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_densephase[i], dph[i]);
+        atomicAdd(&g_densephase[9], (unsigned long long)total);
+    }
+#endif
+#undef PARSY_DENSE_WAIT
+}
+
+void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_chol_dense, dim3(count), dim3(kDenseThreads), 0, stream, P.csn, P.relpos, P.big_entries,
+                       P.big_tasks + first, L);
+}
+
+#ifdef PARSY_DENSESTAMPS
+extern "C" void parsy_debug_densephase(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_densephase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_densephase), z, sizeof(z));
+    }
+}
+#endif
 
 #ifdef PARSY_BIGSTAMPS
 extern "C" void parsy_debug_bigstamp_cfg(int grid, int block) {

@@ -237,12 +237,12 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
         const bool on_side = overlap && l.side;
         if (!on_side) {
             // everything enqueued so far on the main stream belongs to levels < l.level
-            if (overlap && l.kind <= kLaunchBig) record_levels_below(l.level);
+            if (overlap && is_chol_launch(l.kind)) record_levels_below(l.level);
             // A main-stream launch that touches level t's tiles (NEXT, CHAIN) comes after every side launch
             // enqueued so far whose targets can be at level t: those with a level field <= t (a PUSH writes
             // into EVERY level from its field upwards).  The side stream runs in order, so the latest of them
             // covers the earlier ones; PUSH(t - 1) / TILES(t + 1) (field t + 1) stay free to overlap.
-            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig)) {
+            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig || l.kind == kLaunchDense)) {
                 int lw = std::min<int>(l.level, (int)early_seen.size() - 1);
                 while (lw >= 0 && !early_seen[lw]) --lw;
                 if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
@@ -253,16 +253,20 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchSmall: launch_chol_small(pl->dp, l.first, l.count, l.lds_bytes, l.jb, l.fused == 2, L, stream); break;
             case kLaunchTiles:
             case kLaunchBig:
+            case kLaunchDense:
                 if (on_side) {
                     record_levels_below(l.wait_level + 1);
                     (void)hipStreamWaitEvent(pl->side_stream,
                                              l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
                     if (l.kind == kLaunchBig) launch_chol_big(pl->dp, l.first, l.count, L, pl->side_stream);
+                    else if (l.kind == kLaunchDense) launch_chol_dense(pl->dp, l.first, l.count, L, pl->side_stream);
                     else launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
                     (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
                     early_seen[l.level] = 1;
                 } else if (l.kind == kLaunchBig) {
                     launch_chol_big(pl->dp, l.first, l.count, L, stream);
+                } else if (l.kind == kLaunchDense) {
+                    launch_chol_dense(pl->dp, l.first, l.count, L, stream);
                 } else {
                     launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }
@@ -381,7 +385,7 @@ int plan_collect_profile(parsy_plan* pl) {
             pl->kind_launches[k] += 1;
         }
         // factorization launches also per level of the Cholesky view and stream (main / side)
-        if (k >= 0 && k <= kLaunchBig && i < pl->pev_level.size() && pl->pev_level[i] >= 0) {
+        if (is_chol_launch(k) && i < pl->pev_level.size() && pl->pev_level[i] >= 0) {
             const size_t slot = (size_t)pl->pev_level[i];
             if (pl->level_ms.size() <= slot) pl->level_ms.resize(slot + 1, 0.0);
             pl->level_ms[slot] += ms;

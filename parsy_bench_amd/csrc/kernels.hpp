@@ -54,6 +54,7 @@ void launch_scatter_a(const double* values, const int64_t* a_dst, double* L, int
 void launch_chol_small(const DevicePattern& P, int first, int count, int lds_bytes, int stage_cap, bool subtrees,
                        double* L, hipStream_t stream);
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
+void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, bool rows, double* L,

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <algorithm>
+#include <queue>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -540,17 +541,88 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     if (!bigk.empty()) {
         std::stable_sort(bigk.begin(), bigk.end(),
                          [](const BigKeyed& a, const BigKeyed& b) { return a.launch_tile < b.launch_tile; });
+        // Dense entries: full 128 x 128 blocks of the source's rows (on or below the target's diagonal; a block that
+        // straddles it -- the diagonal blocks of the pushes between a separator's pieces -- is multiplied whole and its
+        // upper part dropped when the tile is updated: 1.4 % more products there, and no ragged launch of a few hundred
+        // diagonal blocks behind every such push).  A launch hands them to k_chol_dense when
+        // they carry at least kDenseMinShare of its products; decided per launch over ALL targets, so that the order of
+        // sums does not depend on which pieces a rank owns.
+        auto is_full = [](const WaveEntry& E) {
+            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+            return mi == kBigTile && nj == kBigTile && E.K >= kDenseChunk;
+        };
+        const int dense_mode = env_int("PARSY_BIG_DENSE", 1);
+        std::vector<double> lprod(launch_super.size(), 0.0), ldense(launch_super.size(), 0.0);
+        auto products_of = [](const WaveEntry& E) {
+            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+            return (double)ceil_div(E.K, 4) * ceil_div(mi, 16) * ceil_div(nj, 16);
+        };
+        for (const BigKeyed& b : bigk) {
+            const size_t l = (size_t)(b.launch_tile >> 40);
+            lprod[l] += products_of(b.e);
+            if (is_full(b.e)) ldense[l] += products_of(b.e);
+        }
+        // per launch: 0 = k_chol_big only; 1 = full blocks to k_chol_dense, the rest to k_chol_big; 2 = everything to
+        // k_chol_dense (it multiplies a ragged window as a whole block and drops what the window does not have) --
+        // where the ragged rest is so small (the last, partial row block of the pushes between a separator's pieces: a
+        // handful of tasks) that a launch of its own would cost more than the wasted products: measured 0.07 - 0.1 ms
+        // per such launch, 110 of them per Flan-class factorization
+        std::vector<uint8_t> launch_dense(launch_super.size(), 0);
+        for (size_t l = 0; l < launch_dense.size(); ++l) {
+            if (dense_mode == 4) {   // (tests: every entry of every launch through k_chol_dense, ragged windows and all)
+                launch_dense[l] = lprod[l] > 0 ? 2 : 0;
+                continue;
+            }
+            if (dense_mode == 0 || ldense[l] <= 0) continue;
+            if (dense_mode >= 2 || ldense[l] >= kDenseMinShare * lprod[l]) launch_dense[l] = 1;
+            if (launch_dense[l] && lprod[l] - ldense[l] <= kDenseAllShare * lprod[l] && dense_mode != 3) launch_dense[l] = 2;
+        }
+        // (PARSY_DENSE_MIN_SHARE / PARSY_DENSE_ALL_SHARE / PARSY_DENSE_FILL, percent: the thresholds, diagnostics)
+        const double min_share = env_int("PARSY_DENSE_MIN_SHARE", (int)(kDenseMinShare * 100 + 0.5)) / 100.0;
+        const double all_share = env_int("PARSY_DENSE_ALL_SHARE", (int)(kDenseAllShare * 100 + 0.5)) / 100.0;
+        const int fill_min = env_int("PARSY_DENSE_FILL", (int)(kDenseMinFill * 100 + 0.5)) * kBigTile * kBigTile / 100;
+        for (size_t l = 0; l < launch_dense.size(); ++l) {   // (re-decide with the thresholds of the environment)
+            if (dense_mode == 4 || dense_mode == 0 || ldense[l] <= 0) continue;
+            launch_dense[l] = (dense_mode >= 2 || ldense[l] >= min_share * lprod[l]) ? 1 : 0;
+            if (launch_dense[l] && lprod[l] - ldense[l] <= all_share * lprod[l] && dense_mode != 3) launch_dense[l] = 2;
+        }
+        // mode 1: full blocks, and windows filled well enough that a whole-block product beats the ragged kernel's rate
+        auto is_dense = [&](const WaveEntry& E, int mode) {
+            if (mode == 2) return E.K >= kDenseChunk;
+            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+            return mode == 1 && E.K >= kDenseChunk && mi * nj >= fill_min;
+        };
         S.big_entries.resize(bigk.size());
         int t = 0;
         for (size_t i = 0; i < bigk.size();) {
             size_t j = i;
-            int64_t weight = 0;
-            while (j < bigk.size() && bigk[j].launch_tile == bigk[i].launch_tile) {
-                S.big_entries[j] = bigk[j].e;
-                weight += ceil_div(bigk[j].e.K, 16) + 4;
-                ++j;
-            }
+            while (j < bigk.size() && bigk[j].launch_tile == bigk[i].launch_tile) ++j;
             const int64_t launch = bigk[i].launch_tile >> 40, tile = bigk[i].launch_tile & ((1LL << 40) - 1);
+            // dense entries first, each part in update order
+            size_t at = i;
+            int64_t weight = 0, dweight = 0, dchunks = 0;
+            const int lmode = launch_dense[(size_t)launch];
+            if (lmode)
+                for (size_t q = i; q < j; ++q)
+                    if (is_dense(bigk[q].e, lmode)) {
+                        S.big_entries[at++] = bigk[q].e;
+                        dchunks += ceil_div(bigk[q].e.K, kDenseChunk);
+                        dweight += ceil_div(bigk[q].e.K, 16) + 2;
+                        {   // (the pairs (i, j), i >= j, of the block: a block that straddles the diagonal has fewer)
+                            const WaveEntry& E = bigk[q].e;
+                            const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
+                            double pairs = 0;
+                            for (int jj = E.ja; jj < E.ja + nj; ++jj) pairs += std::max(0, E.ia + mi - std::max(E.ia, jj));
+                            S.dense_flops += 2.0 * E.K * pairs;
+                        }
+                    }
+            const size_t mid = at;
+            for (size_t q = i; q < j; ++q)
+                if (!is_dense(bigk[q].e, lmode)) {
+                    S.big_entries[at++] = bigk[q].e;
+                    weight += ceil_div(bigk[q].e.K, 16) + 4;
+                }
+            S.n_dense_entries += (int64_t)(mid - i);
             while (t + 1 < nc && big_tile0[t + 1] <= tile) ++t;   // tiles ascend within a launch ...
             if (tile < big_tile0[t]) {                             // ... and start over with the next one
                 t = 0;
@@ -561,7 +633,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.big_all.push_back(Schedule::BigTask{t, (int32_t)(local % nbr128) * kBigTile,
                                                   (int32_t)(local / nbr128) * kBigTile,
                                                   (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
-                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), bigk[i].sr, bigk[i].sc});
+                                                  (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), bigk[i].sr, bigk[i].sc,
+                                                  (int64_t)mid, (int32_t)std::min<int64_t>(dweight, INT32_MAX),
+                                                  (int32_t)std::min<int64_t>(dchunks, INT32_MAX)});
             i = j;
         }
     }
@@ -620,10 +694,18 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     // which return at once).  Small launches keep the plain heaviest-first order.  PARSY_BIG_GROUP=g
     // (0: never group).
     const int big_group = env_int("PARSY_BIG_GROUP", kBigGroup);
-    auto emit_big = [&](std::vector<const Schedule::BigTask*>& v, Launch L) {
+    // (dense: the tasks' dense parts for k_chol_dense -- TileDesc::part = its 8-wide k chunks --, else their ragged rests)
+    auto emit_big = [&](const std::vector<const Schedule::BigTask*>& all, Launch L, bool dense) {
+        std::vector<const Schedule::BigTask*> v;
+        for (const Schedule::BigTask* b : all)
+            if (dense ? b->em > b->e0 : b->e1 > b->em) v.push_back(b);
         if (v.empty()) return L;
         L.first = (int32_t)S.big_tasks.size();
-        auto by_weight = [](const Schedule::BigTask* a, const Schedule::BigTask* b) { return a->weight > b->weight; };
+        auto wt = [dense](const Schedule::BigTask* b) { return dense ? b->dweight : b->weight; };
+        auto desc = [dense](const Schedule::BigTask* b) {
+            return dense ? TileDesc{b->sn, b->row0, b->col0, b->dchunks, b->e0, b->em} : TileDesc{b->sn, b->row0, b->col0, 0, b->em, b->e1};
+        };
+        auto by_weight = [&](const Schedule::BigTask* a, const Schedule::BigTask* b) { return wt(a) > wt(b); };
         // group edge: as large as leaves every XCD at least kBigGroupsPerXcd groups to balance with
         int g = big_group;
         // (a group of g x g tiles holds g * g / (sr * sc) tasks)
@@ -632,7 +714,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         if (g < std::max(v[0]->sr, v[0]->sc)) g = 1;
         if (g <= 1) {
             std::stable_sort(v.begin(), v.end(), by_weight);
-            for (const Schedule::BigTask* b : v) S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
+            for (const Schedule::BigTask* b : v) S.big_tasks.push_back(desc(b));
             L.count = (int32_t)v.size();
             return L;
         }
@@ -654,7 +736,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                 for (const Schedule::BigTask* b : rest) {
                     const int x = least();
                     seq[x].push_back(b);
-                    load[x] += b->weight;
+                    load[x] += wt(b);
                 }
                 break;
             }
@@ -670,8 +752,8 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                 if (groups.empty() || groups.back().key != kb.first) groups.push_back(Group{kb.first, 0, 0, {}});
                 Group& G = groups.back();
                 G.tasks.push_back(kb.second);
-                G.weight += kb.second->weight;
-                G.maxw = std::max(G.maxw, kb.second->weight);
+                G.weight += wt(kb.second);
+                G.maxw = std::max(G.maxw, wt(kb.second));
             }
             std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {
                 return a.maxw != b.maxw ? a.maxw > b.maxw : a.weight > b.weight;
@@ -695,8 +777,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         for (size_t s = 0; s < len; ++s)
             for (int x = 0; x < 8; ++x) {
                 if (s < seq[x].size()) {
-                    const Schedule::BigTask* b = seq[x][s];
-                    S.big_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->e0, b->e1});
+                    S.big_tasks.push_back(desc(seq[x][s]));
                 } else {
                     S.big_tasks.push_back(TileDesc{0, 0, 0, 0, 0, 0});  // padding: no entries
                 }
@@ -773,11 +854,15 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         // ---- PUSH(lev): this level's wide supernodes update everything at least two levels up (side
         // stream, once the level is complete); NEXT(lev - 1): the level below updates this level's tiles
         if (lev + 2 < S.cnlevels) {
-            Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1});
+            Launch Ld = emit_big(big_push[lev], Launch{kLaunchDense, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, true);
+            if (Ld.count > 0) early_launches.push_back(Ld);
+            Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, false);
             if (Lp.count > 0) early_launches.push_back(Lp);
         }
         if (lev > 0) {
-            Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0});
+            Launch Ld = emit_big(big_next[lev - 1], Launch{kLaunchDense, 0, 0, lev, 0, 0, 0, 0, -1, 0}, true);
+            if (Ld.count > 0) S.chol.push_back(Ld);
+            Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0}, false);
             if (Ln.count > 0) S.chol.push_back(Ln);
         }
         if (!bigs.empty()) {
@@ -1407,37 +1492,65 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
         }
     }
     {
-        // the BIG launches hold every task of an active target exactly once, under its (source level, kind);
-        // padding tasks (XCD sequences of unequal length) have no entries
-        std::vector<int64_t> e0s;
+        // the BIG / DENSE launches hold every non-empty part (dense: [e0, em), ragged: [em, e1)) of every task of an
+        // active target exactly once, under its (source level, kind), the dense part in a launch enqueued BEFORE the
+        // one that holds the ragged part; padding tasks (XCD sequences of unequal length) have no entries
+        std::vector<int64_t> starts;
+        std::vector<int64_t> dense_pos(S.big_all.size(), -1), ragged_pos(S.big_all.size(), -1);
+        int64_t li = 0;
         for (const Launch& l : S.chol) {
-            if (l.kind != kLaunchBig) continue;
+            ++li;
+            if (l.kind != kLaunchBig && l.kind != kLaunchDense) continue;
+            const bool dense = l.kind == kLaunchDense;
+            const bool side = l.side != 0;
+            auto find_task = [&](int64_t e) -> const Schedule::BigTask* {   // the task whose entry range holds big_entries[e]
+                auto it = std::upper_bound(S.big_all.begin(), S.big_all.end(), e,
+                                           [](int64_t v, const Schedule::BigTask& b) { return v < b.e0; });
+                if (it == S.big_all.begin()) return nullptr;
+                --it;
+                return e < it->e1 ? &*it : nullptr;
+            };
+            auto right_launch = [&](const Schedule::BigTask& b) {
+                return side != (b.next != 0) && (side ? l.wait_level : l.level - 1) == b.src_level;
+            };
             for (int q = l.first; q < l.first + l.count; ++q) {
                 const TileDesc& td = S.big_tasks[(size_t)q];
                 if (td.wp >= td.sp) {
                     if (td.wp != td.sp) fail("BIG launch task " + std::to_string(q) + " has a negative entry range");
                     continue;
                 }
-                auto it = std::lower_bound(S.big_all.begin(), S.big_all.end(), td.wp,
-                                           [](const Schedule::BigTask& b, int64_t e) { return b.e0 < e; });
-                if (it == S.big_all.end() || it->e0 != td.wp || it->e1 != td.sp || it->sn != td.sn ||
-                    it->row0 != td.row0 || it->col0 != td.col0) {
+                const Schedule::BigTask* it = find_task(td.wp);
+                const bool ok = it && (dense ? (it->e0 == td.wp && it->em == td.sp && td.part == it->dchunks)
+                                             : (it->em == td.wp && it->e1 == td.sp));
+                if (!ok || it->sn != td.sn || it->row0 != td.row0 || it->col0 != td.col0) {
                     fail("BIG launch task " + std::to_string(q) + " is not a task of the plan");
                     continue;
                 }
-                const bool side = l.side != 0;
-                if (side == (it->next != 0) || (side ? l.wait_level : l.level - 1) != it->src_level)
-                    fail("BIG launch task " + std::to_string(q) + " runs in the launch of another source level");
-                e0s.push_back(td.wp);
+                if (!right_launch(*it)) fail("BIG launch task " + std::to_string(q) + " runs in the launch of another source level");
+                (dense ? dense_pos : ragged_pos)[(size_t)(it - S.big_all.data())] = li;
+                starts.push_back(td.wp);
             }
         }
-        std::sort(e0s.begin(), e0s.end());
-        if (std::adjacent_find(e0s.begin(), e0s.end()) != e0s.end()) fail("a BIG task is launched twice");
+        std::sort(starts.begin(), starts.end());
+        if (std::adjacent_find(starts.begin(), starts.end()) != starts.end()) fail("a BIG task is launched twice");
         int64_t want = 0;
-        for (const Schedule::BigTask& b : S.big_all)
-            if (S.active_piece[b.sn]) ++want;
-        if ((int64_t)e0s.size() != want)
-            fail("BIG launches hold " + std::to_string(e0s.size()) + " tasks, the active targets have " + std::to_string(want));
+        for (size_t k = 0; k < S.big_all.size(); ++k) {
+            const Schedule::BigTask& b = S.big_all[k];
+            if (b.em < b.e0 || b.em > b.e1) fail("BIG task " + std::to_string(k) + " has a bad dense / ragged split");
+            int64_t dch = 0;
+            for (int64_t e = b.e0; e < b.em; ++e) {
+                const WaveEntry& E = S.big_entries[(size_t)e];
+                if (E.K < kDenseChunk) fail("BIG entry " + std::to_string(e) + " is filed as dense but is narrower than a chunk");
+                dch += ceil_div(E.K, kDenseChunk);
+            }
+            if (dch != b.dchunks) fail("BIG task " + std::to_string(k) + " has a wrong dense chunk count");
+            if (!S.active_piece[b.sn]) continue;
+            want += (b.em > b.e0) + (b.e1 > b.em);
+            if (b.em > b.e0 && b.e1 > b.em && !(dense_pos[k] > 0 && ragged_pos[k] > dense_pos[k]))
+                fail("BIG task " + std::to_string(k) + ": the ragged part is not launched after the dense part");
+        }
+        if ((int64_t)starts.size() != want)
+            fail("BIG launches hold " + std::to_string(starts.size()) + " task parts, the active targets have " + std::to_string(want));
     }
     for (int t = 0; t < nc; ++t) {
         const SnDesc& T = S.csn[t];

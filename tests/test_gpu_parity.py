@@ -690,6 +690,8 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
     monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
     monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
     monkeypatch.setenv("PARSY_BIG_SUPER", "1")
+    # (which entries are dense blocks depends on the windows: the dense / ragged order of sums is tested below)
+    monkeypatch.setenv("PARSY_BIG_DENSE", "0")
     plan1 = api.Plan(sym, 0)
     lv1, _ = plan1.factor(sym.A2x)
     assert plan1.status() == 0
@@ -701,6 +703,58 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
     assert np.array_equal(lv, lv1), f"{name} super {sup}: the factor differs from the single-tile one"
     ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
     assert ok and np.abs(lv - lo).max() <= FACTOR_TOL * np.abs(lo).max()
+
+
+# ---------------------------------------------------------------------------
+# DENSE launches (k_chol_dense): the full 128 x 128 blocks among a BIG task's entries go through a
+# kernel of their own, launched right before the task's ragged rest.  PARSY_BIG_DENSE=2 takes it wherever a dense
+# entry exists, 4 hands EVERY entry to it (it multiplies a ragged window as a whole block and drops what the window
+# does not have: what launches with a tiny ragged rest do by themselves), 0 never; the order of sums per entry of L differs between the two (dense entries first), so the
+# factors agree to rounding, each is bitwise reproducible, and both agree with the oracle.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,piece,mink,sup,mode", [("mid3d", 128, 16, "0", 2), ("lap30", 128, 32, "0", 2), ("lap30", 128, 32, "2", 2),
+                                                      ("lap30", 256, 64, "2x1", 2), ("nd24k", 0, 64, "0", 2), ("nd24k", 256, 64, "2", 2),
+                                                      ("nd24k", 200, 24, "0", 2),
+                                                      # mode 4: EVERY entry through k_chol_dense -- ragged windows, K tails
+                                                      ("small3d", 128, 16, "0", 4), ("mid3d", 128, 16, "0", 4), ("mid3d", 0, 32, "2", 4),
+                                                      ("lap30", 128, 32, "0", 4), ("ex15", 128, 16, "0", 4), ("nd24k", 200, 24, "2", 4)])
+def test_factor_with_dense_launches(api, oracle, monkeypatch, name, piece, mink, sup, mode):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    if sup != "0":
+        monkeypatch.setenv("PARSY_BIG_SUPER", sup)
+    monkeypatch.setenv("PARSY_BIG_DENSE", "0")
+    plan0 = api.Plan(sym, 0)
+    assert plan0.info["dense_entries"] == 0 and plan0.info["dense_tasks"] == 0
+    lv0, _ = plan0.factor(sym.A2x)
+    assert plan0.status() == 0
+    monkeypatch.setenv("PARSY_BIG_DENSE", str(mode))
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    assert info["dense_entries"] > 0 and info["dense_tasks"] > 0 and 0 < info["dense_flops"] <= info["big_flops"]
+    if mode == 4:
+        # (all but the updates narrower than one 8-wide k chunk: narrow descendants of a split supernode's pieces)
+        assert info["dense_entries"] >= 0.9 * info["big_entries"] and info["dense_flops"] >= 0.9 * info["big_flops"]
+    assert info["big_flops"] == plan0.info["big_flops"] and plan.check() == 0
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok
+    scale = np.abs(lo).max()
+    assert np.abs(lv - lo).max() <= FACTOR_TOL * scale, f"{name}: dense launches vs oracle {np.abs(lv - lo).max() / scale:.3e}"
+    assert np.abs(lv - lv0).max() <= FACTOR_TOL * scale
+    for _ in range(2):
+        lv2, _ = plan.factor(sym.A2x)
+        assert np.array_equal(lv, lv2)   # fixed summation order: bitwise reproducible
+    # padding above the diagonal of every diagonal block stays exactly zero
+    for sn in range(sym.nsuper):
+        c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
+        r = int(sym.i_ptr[c1] - sym.i_ptr[c0]) if c1 < sym.n else int(sym.ssize - sym.i_ptr[c0])
+        base = int(sym.p[c0])
+        for c in range(1, min(c1 - c0, 8)):
+            assert not lv[base + c * r: base + c * r + c].any()
 
 
 # ---------------------------------------------------------------------------
