@@ -167,10 +167,12 @@ class Plan:
             raise RuntimeError(N.last_error())
 
     # host-buffer conveniences -------------------------------------------------
-    def factor(self, values):
-        """Returns (lValues, device_seconds). Raises on a HIP failure; check `status()`."""
+    def factor(self, values, out=None):
+        """Returns (lValues, device_seconds). Raises on a HIP failure; check `status()`.  out: a float64 array of
+        xsize entries to receive lValues (every entry is written)."""
         vals = _f64(values)
-        lValues = np.zeros(int(self.sym.xsize), dtype=np.float64)
+        lValues = np.zeros(int(self.sym.xsize), dtype=np.float64) if out is None else out
+        assert lValues.dtype == np.float64 and lValues.size == int(self.sym.xsize) and lValues.flags.c_contiguous
         sec = C.c_double(0)
         if N.lib().parsy_factor_host(self._h, N.ptr(vals), N.ptr(lValues), C.byref(sec)) != 0:
             raise RuntimeError("parsy_factor_host failed: " + N.last_error())

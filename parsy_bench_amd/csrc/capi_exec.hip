@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -567,6 +569,50 @@ int parsy_plan_profile_levels(parsy_plan* pl, double* main_ms, double* side_ms) 
     return nl;
 }
 
+// The bands of levels of the pipelined host factorization and, per band, the runs of lValues that are final once
+// the band is complete (a piece is final after the chain launch of its own level: everything that updates it comes
+// from lower levels and is applied before that launch).  Pieces are in column order = lValues order, so consecutive
+// pieces of one band are one run; runs separated by less than 128 K doubles are merged (the gap is copied early and
+// again with its own band: harmless).  Built once per plan.
+static void build_download_bands(parsy_plan* pl) {
+    const parsy::Schedule& S = pl->S;
+    const int nl = S.cnlevels, np = (int)S.csn.size();
+    // band boundaries: a band ends with the level at which another eighth of the factor's bytes has become final
+    // (few bands = few, long runs: every copy from device to pageable host memory has a fixed cost), the last band
+    // with the last level
+    {
+        std::vector<double> bytes((size_t)nl, 0.0);
+        for (int p = 0; p < np; ++p) bytes[(size_t)S.level_of[(size_t)p]] += 8.0 * S.csn[(size_t)p].w * S.csn[(size_t)p].ld;   // (ld = rows of the supernode)
+        const double total = 8.0 * (double)S.xsize;
+        pl->h_band_level.clear();
+        double run = 0, next = total / 8;
+        for (int l = 0; l < nl; ++l) {
+            run += bytes[(size_t)l];
+            if (l == nl - 1 || run >= next) {
+                pl->h_band_level.push_back(l);
+                while (next <= run) next += total / 8;
+            }
+        }
+    }
+    const size_t nb = pl->h_band_level.size();
+    pl->h_band_runs.assign(nb, {});
+    std::vector<int> band_of((size_t)nl, 0);
+    for (size_t b = 0, l = 0; b < nb; ++b)
+        for (; (int)l <= pl->h_band_level[b]; ++l) band_of[l] = (int)b;
+    const int64_t gap = 131072;
+    for (int p = 0; p < np; ++p) {
+        const parsy::SnDesc& C = S.csn[(size_t)p];
+        const parsy::SnDesc& R = S.sn[(size_t)S.csn_real[(size_t)p]];
+        // (a piece's columns are whole columns of its supernode's panel)
+        const int64_t a = R.px + (int64_t)C.rbias * R.r, e = R.px + (int64_t)(C.rbias + C.w) * R.r;
+        auto& runs = pl->h_band_runs[(size_t)band_of[(size_t)S.level_of[(size_t)p]]];
+        if (!runs.empty() && a - (runs.back().first + runs.back().second) <= gap && a >= runs.back().first)
+            runs.back().second = std::max(runs.back().second, e - runs.back().first);
+        else
+            runs.push_back({a, e - a});
+    }
+}
+
 int parsy_factor_host(parsy_plan* pl, const double* values, double* lValues, double* seconds) {
     if (!pl || !values || !lValues) {
         set_last_error("parsy_factor_host: null argument");
@@ -581,10 +627,80 @@ int parsy_factor_host(parsy_plan* pl, const double* values, double* lValues, dou
     if (!pl->h_values_dev) CAPI_HIP(hipMalloc((void**)&pl->h_values_dev, std::max<int64_t>(S.nnzA, 1) * 8), -1);
     if (!pl->h_L_dev) CAPI_HIP(hipMalloc((void**)&pl->h_L_dev, std::max<int64_t>(S.xsize, 1) * 8), -1);
     CAPI_HIP(hipMemcpy(pl->h_values_dev, values, (size_t)S.nnzA * 8, hipMemcpyHostToDevice), -1);
-    if (parsy::plan_factor(pl, pl->h_values_dev, pl->h_L_dev, nullptr) != 0) return -1;
-    CAPI_HIP(hipDeviceSynchronize(), -1);
+    // Small factors: kernels, then one download.  Large ones (PARSY_HOST_PIPELINE=0: never): the download of every
+    // band of levels runs BEHIND the kernels of the levels above it -- a worker thread copies the runs of lValues
+    // that a band has made final while this thread's stream goes on (Flan-class: 19.4 GB at PCIe speed take as long
+    // as the kernels; one after the other the call was 0.78 s).
+    // (read per call: the tests switch it; PARSY_HOST_PIPELINE=2 takes the pipelined path whatever the size)
+    const char* pe = std::getenv("PARSY_HOST_PIPELINE");
+    const bool pipeline_on = !(pe && pe[0] == '0'), pipeline_forced = pe && pe[0] == '2';
+    if (!pipeline_on || (!pipeline_forced && S.xsize * 8 < (int64_t)256 << 20) || pl->profile || S.cnlevels < 1) {
+        if (parsy::plan_factor(pl, pl->h_values_dev, pl->h_L_dev, nullptr) != 0) return -1;
+        CAPI_HIP(hipDeviceSynchronize(), -1);
+        if (seconds) *seconds = parsy_last_factor_ms(pl) * 1e-3;
+        CAPI_HIP(hipMemcpy(lValues, pl->h_L_dev, (size_t)S.xsize * 8, hipMemcpyDeviceToHost), -1);
+        return 0;
+    }
+    if (!pl->h_stream) {
+        CAPI_HIP(hipStreamCreateWithFlags(&pl->h_stream, hipStreamNonBlocking), -1);
+        CAPI_HIP(hipStreamCreateWithFlags(&pl->h_copy, hipStreamNonBlocking), -1);
+        build_download_bands(pl);
+        pl->h_band_ev.resize(pl->h_band_level.size());
+        for (hipEvent_t& e : pl->h_band_ev) CAPI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), -1);
+    }
+    const size_t nb = pl->h_band_level.size();
+    std::atomic<int> recorded{0};
+    std::atomic<int> failed{0};
+    double* const dL = pl->h_L_dev;
+    const int device = pl->device;
+    std::thread worker([&, dL, device] {
+        if (hipSetDevice(device) != hipSuccess) {
+            failed = 1;
+            return;
+        }
+        for (size_t b = 0; b < nb; ++b) {
+            while (recorded.load(std::memory_order_acquire) <= (int)b && !failed.load()) std::this_thread::yield();
+            if (failed.load()) return;
+            if (hipEventSynchronize(pl->h_band_ev[b]) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+            for (const auto& r : pl->h_band_runs[b])
+                if (hipMemcpyAsync(lValues + r.first, dL + r.first, (size_t)r.second * 8, hipMemcpyDeviceToHost, pl->h_copy) !=
+                    hipSuccess) {
+                    failed = 1;
+                    return;
+                }
+            if (hipStreamSynchronize(pl->h_copy) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+        }
+    });
+    int rc = parsy::plan_factor_begin(pl, pl->h_values_dev, dL, pl->h_stream, true);
+    size_t b = 0;
+    for (int lev = 0; rc == 0 && lev < S.cnlevels; ++lev) {
+        rc = parsy::plan_factor_levels(pl, lev, lev + 1, dL, pl->h_stream);
+        if (rc == 0 && b < nb && pl->h_band_level[b] == lev) {
+            if (hipEventRecord(pl->h_band_ev[b], pl->h_stream) != hipSuccess) rc = -1;
+            ++b;
+            recorded.store((int)b, std::memory_order_release);
+        }
+    }
+    if (rc == 0) rc = parsy::plan_factor_end(pl, pl->h_stream);
+    if (rc != 0) {
+        failed = 1;
+        worker.join();
+        parsy::plan_factor_abort(pl, pl->h_stream);
+        return -1;
+    }
+    const hipError_t es = hipStreamSynchronize(pl->h_stream);
+    worker.join();
+    if (es != hipSuccess || failed.load()) {
+        set_last_error("parsy_factor_host: the pipelined download failed");
+        return -1;
+    }
     if (seconds) *seconds = parsy_last_factor_ms(pl) * 1e-3;
-    CAPI_HIP(hipMemcpy(lValues, pl->h_L_dev, (size_t)S.xsize * 8, hipMemcpyDeviceToHost), -1);
     return 0;
 }
 

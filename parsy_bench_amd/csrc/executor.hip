@@ -187,6 +187,9 @@ void plan_free(parsy_plan* pl) {
         for (hipEvent_t e : pl->ev_early_done) (void)hipEventDestroy(e);
         if (pl->ev_init) (void)hipEventDestroy(pl->ev_init);
         if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
+        if (pl->h_stream) (void)hipStreamDestroy(pl->h_stream);
+        if (pl->h_copy) (void)hipStreamDestroy(pl->h_copy);
+        for (hipEvent_t e : pl->h_band_ev) (void)hipEventDestroy(e);
     }
     delete pl;
 }

@@ -35,6 +35,12 @@ struct parsy_plan {
     double* h_values_dev = nullptr;
     double* h_L_dev = nullptr;
     double* h_x_dev = nullptr;
+    // host-buffer factorization with the download behind the kernels (capi_exec.hip, parsy_factor_host): its own
+    // streams, one event per band of levels, the (offset, length) runs of lValues that are final after each band
+    hipStream_t h_stream = nullptr, h_copy = nullptr;
+    std::vector<hipEvent_t> h_band_ev;
+    std::vector<int> h_band_level;                                    // last level of every band
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> h_band_runs;
     int64_t h_x_len = 0;
 
     // side stream of the TILES_EARLY launches + the events that order it against the main stream

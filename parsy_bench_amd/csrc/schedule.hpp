@@ -151,7 +151,7 @@ constexpr int kBigTailGroups = 16;         // ... the lightest groups are dealt 
 constexpr int kDenseChunk = 8;             // k extent of k_chol_dense's chunks (TileDesc::part counts them)
 constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense when at least this share of its products is dense
                                            // (PARSY_BIG_DENSE=0: never, 2: wherever there is a dense entry)
-constexpr double kDenseMinFill = 1.0;      // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
+constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...

@@ -706,6 +706,31 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
 
 
 # ---------------------------------------------------------------------------
+# host buffers in and out (parsy_factor_host, what the drop-in operators call): large factors are downloaded band of
+# levels by band of levels BEHIND the kernels of the levels above (a worker thread; PARSY_HOST_PIPELINE=0: kernels, then
+# one download; 2: pipelined whatever the size).  Same kernels, same order: the factors must be bitwise equal, and
+# every entry of lValues must have been downloaded (the buffer is poisoned first).
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,env", [("lap30", {}), ("mid3d", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16"}),
+                                      ("nd24k", {}), ("tiny2d", {})])
+def test_host_factorization_with_pipelined_download(api, monkeypatch, name, env):
+    A, perm, sym = problem(name)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PARSY_HOST_PIPELINE", "0")
+    plan = api.Plan(sym, 0)
+    ref, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    monkeypatch.setenv("PARSY_HOST_PIPELINE", "2")
+    for _ in range(2):
+        out = np.full(int(sym.xsize), np.nan)
+        got, _ = plan.factor(sym.A2x, out=out)
+        assert plan.status() == 0
+        assert not np.isnan(got).any(), "a part of lValues was never downloaded"
+        assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------------------
 # DENSE launches (k_chol_dense): the full 128 x 128 blocks among a BIG task's entries go through a
 # kernel of their own, launched right before the task's ragged rest.  PARSY_BIG_DENSE=2 takes it wherever a dense
 # entry exists, 4 hands EVERY entry to it (it multiplies a ragged window as a whole block and drops what the window
