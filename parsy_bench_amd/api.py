@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _native as N
 
-KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "--", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP", "BACK_BLOCK", "DENSE"]
+KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "BACK_BELOW", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP", "BACK_BLOCK", "DENSE"]
 
 
 def device_count() -> int:

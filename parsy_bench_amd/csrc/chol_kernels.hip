@@ -2310,7 +2310,9 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         // may stay in flight), then everybody's
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         DSTAMP(2);
+#ifndef PARSY_DENSEABL_NOBARRIER   // (diagnostic build: waves race through the ring -- wrong results)
         asm volatile("s_barrier" ::: "memory");
+#endif
         DSTAMP(3);
         DSTAMP(4);
         read_ops(nslot, 0, A);
@@ -2334,7 +2336,17 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         DSTAMP(6);
         ck += kDK;
         if (ck >= CE.K) {
+#ifndef PARSY_DENSEABL_NOEPI        // (diagnostic build: the products are dropped)
             epilogue(CE);
+#else
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    asm volatile("" ::"v"(acc[a][b]));
+                    acc[a][b] = double4_t{0, 0, 0, 0};
+                }
+#endif
             // the adds of this source are performed before the next barrier: the next source's adds into the same
             // entries of L may come from other waves (another row map), and the order of sums must not depend on timing
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

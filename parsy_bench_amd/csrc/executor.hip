@@ -53,6 +53,11 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.solve_fix_list, pl->dp.solve_fix_list, true)) return -1;
     if (upload(pl, S.solve_wide_list, pl->dp.solve_wide_list, true)) return -1;
     if (upload(pl, S.bsolve_blocks, pl->dp.bsolve_blocks, true)) return -1;
+    if (upload(pl, S.bsolve_below, pl->dp.bsolve_below, true)) return -1;
+    if (pl->dp.bpart) {   // (sized by the launch lists)
+        (void)hipFree(pl->dp.bpart);
+        pl->dp.bpart = nullptr;
+    }
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
     {
         void* d = nullptr;
@@ -177,6 +182,7 @@ void plan_free(parsy_plan* pl) {
         if (pl->xscratch) (void)hipFree(pl->xscratch);
         if (pl->xt) (void)hipFree(pl->xt);
         if (pl->dinv) (void)hipFree(pl->dinv);
+        if (pl->dp.bpart) (void)hipFree(pl->dp.bpart);
         if (pl->h_values_dev) (void)hipFree(pl->h_values_dev);
         if (pl->h_L_dev) (void)hipFree(pl->h_L_dev);
         if (pl->h_x_dev) (void)hipFree(pl->h_x_dev);
@@ -289,6 +295,9 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchSolveFixup:
                 launch_solve_fixup(pl->dp, l.first, l.count, x, pl->xscratch, nrhs, ldx, stream);
                 break;
+            case kLaunchBackBelow:
+                if (nrhs == 1) launch_bsolve_below(pl->dp, l.first, l.count, Lc, x, stream);
+                break;
             case kLaunchBackBlock:
                 if (l.fused == 1 && nrhs == 1) {   // one right-hand side: the wave dataflow over block-column pairs
                     launch_bsolve_chain_w(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, l.jb,
@@ -357,6 +366,11 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     if (!pl->S.solve_wide_list.empty() && !pl->dinv) {
         const size_t bytes = (size_t)std::max<int64_t>(pl->S.n_dslots, 1) * kTile * kTile * sizeof(double);
         PARSY_HIP(hipMalloc((void**)&pl->dinv, bytes));
+        pl->device_bytes += (int64_t)bytes;
+    }
+    if (nrhs == 1 && pl->S.n_bpart_slots > 0 && !pl->dp.bpart) {
+        const size_t bytes = (size_t)pl->S.n_bpart_slots * kTile * sizeof(double);
+        PARSY_HIP(hipMalloc((void**)&pl->dp.bpart, bytes));
         pl->device_bytes += (int64_t)bytes;
     }
     PARSY_HIP(hipEventRecord(pl->ev_s0, stream));

@@ -35,6 +35,8 @@ struct DevicePattern {           // device copies of Schedule arrays
     const int32_t* solve_fix_list = nullptr;
     const int32_t* solve_wide_list = nullptr;   // (supernode, block column) pairs: diagonal blocks to invert
     const PanelDesc* bsolve_pairs = nullptr;   // backward chain launches, one right-hand side: block-column pairs
+    const PanelDesc* bsolve_below = nullptr;   // k_bsolve_below tasks
+    double* bpart = nullptr;                   // their partial sums (64 doubles per slot; allocated by the first backward solve)
     const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
@@ -78,6 +80,7 @@ void launch_diag_inverse(const DevicePattern& P, int count, const double* L, dou
                          hipStream_t stream);
 void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                            double* x, double* xscratch, int ticket, int wait_bias, hipStream_t stream);
+void launch_bsolve_below(const DevicePattern& P, int first, int count, const double* L, const double* x, hipStream_t stream);
 void launch_bsolve_block(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
                          double* x, double* xscratch, int nrhs, int ldx, int mode, int tiny, int ticket,
                          int wait_bias, hipStream_t stream);

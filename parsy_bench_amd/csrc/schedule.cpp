@@ -1072,6 +1072,10 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     // supernodes of a single block; when the chain would not be resident, one launch per block-column
     // index from the last one down.
     S.bsolve.clear();
+    S.bsolve_below.clear();
+    S.n_bpart_slots = 0;
+    // PARSY_BSOLVE_BELOW=0: never split the rows below off; 2: for every wide supernode with rows below (tests)
+    const int below_mode = env_int("PARSY_BSOLVE_BELOW", 1);
     auto in_level_launches = [&](int t) { return S.active[t] && S.bsolve_subtree[t] < 0; };
     // the supernodes of one block column of a level: the tiny ones (one wave each: Launch::early = 1) in a launch
     // of their own when there are enough of them, the others one workgroup each
@@ -1113,14 +1117,39 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         if (wide_blocks > 0 && wide_blocks <= max_chain) {
             Launch Lc{kLaunchBackBlock, (int32_t)S.bsolve_blocks.size(), 0, lev, S.n_solve_chain_launches++,
                       (int32_t)S.bsolve_pairs.size(), 1, 0, -1, 0};
+            // One right-hand side: a block column's sums over the rows BELOW the supernode's own columns (x final there)
+            // need no hand-off, but in the chain launch only the block column's own four waves stream them -- a level of
+            // few, tall supernodes (the separators below the root: 53 workgroups for 0.9 GB of panel) ran at 1.2 TB/s.
+            // There the rows below go to a launch of their own, 512-row chunks over the whole device, partial sums into
+            // slots that the chain adds up in a fixed order (bitwise reproducible).
+            int64_t groups_here = 0;
+            for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
+                const int t = S.levelSet[q];
+                if (S.active[t] && S.sn[t].w > kTile) groups_here += ceil_div(ceil_div(S.sn[t].w, kTile), kBackGroup);
+            }
+            const bool below_level = below_mode >= 2 || (below_mode == 1 && groups_here <= kBelowMaxGroups);
+            Launch Lw{kLaunchBackBelow, (int32_t)S.bsolve_below.size(), 0, lev, 0, 0, 0, 0, -1, 0};
             for (int q = S.levelPtr[lev]; q < S.levelPtr[lev + 1]; ++q) {
                 const int t = S.levelSet[q];
                 const int nbc = ceil_div(S.sn[t].w, kTile);
                 if (!S.active[t] || nbc < 2) continue;
+                const int below = S.sn[t].r - S.sn[t].w;
+                int32_t slot1 = 0;
+                if (below_level && below >= (below_mode >= 2 ? 1 : kBelowRows) &&
+                    S.n_bpart_slots + (int64_t)nbc * ceil_div(below, kBelowRows) < 0x7fffffffLL) {
+                    const int nch = ceil_div(below, kBelowRows);
+                    slot1 = (int32_t)S.n_bpart_slots + 1;
+                    for (int jb = 0; jb < nbc; ++jb)
+                        for (int c = 0; c < nch; ++c)
+                            S.bsolve_below.push_back(PanelDesc{t, jb, S.sn[t].w + c * kBelowRows, (int32_t)(S.n_bpart_slots + (int64_t)jb * nch + c)});
+                    S.n_bpart_slots += (int64_t)nbc * nch;
+                }
                 for (int jb = nbc - 1; jb >= 0; --jb) S.bsolve_blocks.push_back(PanelDesc{t, jb, 0, 0});
                 for (int jb = nbc - 1; jb >= 0; jb -= kBackGroup)
-                    S.bsolve_pairs.push_back(PanelDesc{t, jb, std::min(kBackGroup, jb + 1), 0});
+                    S.bsolve_pairs.push_back(PanelDesc{t, jb, std::min(kBackGroup, jb + 1), slot1});
             }
+            Lw.count = (int32_t)S.bsolve_below.size() - Lw.first;
+            if (Lw.count > 0) S.bsolve.push_back(Lw);
             Lc.count = (int32_t)S.bsolve_blocks.size() - Lc.first;
             Lc.wait_level = (int32_t)S.bsolve_pairs.size() - Lc.lds_bytes;
             S.bsolve.push_back(Lc);
@@ -1342,6 +1371,38 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
     {
         std::vector<int> seen(ns, 0);
         std::vector<int64_t> blocks(ns, 0), grouped(ns, 0);
+        {
+            // k_bsolve_below: every slot written exactly once, by the task of its (supernode, block column, chunk); a
+            // chain group that names slots finds all of its supernode's there, and the launch that fills them comes first
+            std::vector<uint8_t> slot_seen((size_t)S.n_bpart_slots, 0);
+            for (const PanelDesc& pd : S.bsolve_below) {
+                const SnDesc& T = S.sn[(size_t)pd.sn];
+                if (pd.pad < 0 || pd.pad >= S.n_bpart_slots || slot_seen[(size_t)pd.pad]++) fail("backward solve: a partial-sum slot is written twice or out of range");
+                if (pd.row0 < T.w || pd.row0 >= T.r || (pd.row0 - T.w) % kBelowRows || pd.jb < 0 || pd.jb * kTile >= T.w)
+                    fail("backward solve: a k_bsolve_below task has a bad chunk");
+            }
+            for (uint8_t v : slot_seen)
+                if (v != 1) fail("backward solve: a partial-sum slot is never written");
+            int64_t below_done = 0;
+            for (const Launch& l : S.bsolve) {
+                if (l.kind == kLaunchBackBelow) below_done += l.count;
+                if (l.kind != kLaunchBackBlock || l.fused != 1) continue;
+                for (int g = l.lds_bytes; g < l.lds_bytes + l.wait_level; ++g) {
+                    const PanelDesc& pd = S.bsolve_pairs[(size_t)g];
+                    if (pd.pad <= 0) continue;
+                    const SnDesc& T = S.sn[(size_t)pd.sn];
+                    const int nch = ceil_div(T.r - T.w, kBelowRows), nbc = ceil_div(T.w, kTile);
+                    const int64_t last = (int64_t)(pd.pad - 1) + (int64_t)nbc * nch;
+                    if (T.r <= T.w || last > S.n_bpart_slots) fail("backward solve: a chain group names partial sums that do not exist");
+                    // the tasks of this supernode are the slots [pad - 1, last): all before this launch
+                    if (last > 0 && below_done < (int64_t)S.bsolve_below.size()) {
+                        bool found = false;
+                        for (int64_t q = 0; q < below_done && !found; ++q) found = S.bsolve_below[(size_t)q].pad == last - 1;
+                        if (!found) fail("backward solve: a chain launch runs before the launch that forms its partial sums");
+                    }
+                }
+            }
+        }
         for (const Launch& l : S.bsolve) {
             if (l.kind != kLaunchBackBlock) continue;
             if (l.fused == 2) {

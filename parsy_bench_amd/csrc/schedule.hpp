@@ -46,6 +46,9 @@ constexpr int kTile = 64;             // tile edge of the tiled path / block-col
 constexpr int kSub = 32;              // per-wave sub-tile edge
 constexpr int kSmallMaxEntries = 6144; // panel entries the SMALL kernel keeps in LDS (48 KiB)
 constexpr int kSmallMaxWidth = 64;
+constexpr int kBelowRows = 512;       // backward solve: rows of a k_bsolve_below chunk
+constexpr int kBelowMaxGroups = 512;  // ... used by the chain launches of at most this many workgroups (the top of the tree: few,
+                                      // tall panels -- a block column's rows below are otherwise streamed by its own four waves only)
 constexpr int kBackGroup = 2;         // backward chain, one right-hand side: block columns per workgroup
 constexpr int kTinyWidth = 16;        // solves: supernodes this narrow are solved by one wave each (and walked in
                                       // subtrees); kTinyWidth2: second width class of the one-wave kernels
@@ -109,7 +112,10 @@ struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
 };
 
 enum LaunchKind : int32_t {
-    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,  // 4: retired (FIXUP)
+    kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,
+    kLaunchBackBelow = 4,   // backward solve, one right-hand side: the part of a tall wide supernode's sums that comes from
+                            // the rows below its own columns, in 512-row chunks over the whole device (k_bsolve_below),
+                            // right before the level's chain launch
     kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
     kLaunchDense = 9,   // the dense entries of a BIG launch's tasks (k_chol_dense), right before that launch's ragged rest
 };
@@ -242,6 +248,10 @@ struct Schedule {
                                            // blocks = 1 .. kBackGroup) per workgroup, from a supernode's last block
                                            // column up
     std::vector<PanelDesc> bsolve_blocks;
+    std::vector<PanelDesc> bsolve_below;   // k_bsolve_below tasks: (supernode, block column, first panel row of the chunk,
+                                           // pad = slot of its 64 partial sums); the chain's groups name the supernode's
+                                           // first slot + 1 in pad (0: the chain streams those rows itself)
+    int64_t n_bpart_slots = 0;             // 64 doubles each
     std::vector<Launch> bsolve;
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)

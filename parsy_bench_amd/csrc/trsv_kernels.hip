@@ -2418,6 +2418,68 @@ __global__ __launch_bounds__(64, 4) void k_bsolve_tiny_mrhs(const SnDesc* __rest
     }
 }
 
+// Backward solve, one right-hand side: the sums of a wide supernode's block column over the rows BELOW the supernode's
+// own columns (x of the ancestors: final when the level starts), for the chain launches of few, tall supernodes.
+// One workgroup (4 waves) per (supernode, block column, chunk of kBelowRows rows): wave q carries columns 16 q .. 16 q + 15
+// of the block, lanes along the rows (coalesced), the lanes' parts added up through LDS as in k_bsolve_chain_w; the 64
+// sums of the chunk go to its slot of `part`.  The chain adds the slots of a block column in chunk order.
+__global__ __launch_bounds__(kThreads) void k_bsolve_below(const SnDesc* __restrict__ sn, const PanelDesc* __restrict__ tasks,
+                                                           const int32_t* __restrict__ rows, const double* __restrict__ L,
+                                                           const double* __restrict__ x, double* __restrict__ part) {
+    constexpr int kCols = 16, kLdR = 65;
+    __shared__ double s_red[kThreads / 64][kCols * kLdR];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const PanelDesc pd = tasks[blockIdx.x];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w;
+    const int cb = pd.jb * kTile, wbk = min(kTile, w - cb);
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    const double* __restrict__ colp[kCols];
+#pragma unroll
+    for (int ci = 0; ci < kCols; ++ci) colp[ci] = G + (int64_t)(cb + min(kCols * wave + ci, wbk - 1)) * r;
+    double acc[kCols];
+#pragma unroll
+    for (int ci = 0; ci < kCols; ++ci) acc[ci] = 0.0;
+    const int k1 = min(pd.row0 + kBelowRows, r);
+    for (int k0 = pd.row0 + lane; k0 < k1; k0 += 128) {   // two 64-row pieces in flight
+        const int ka = k0, kb = min(k0 + 64, r - 1);
+        const int xa = ri[ka], xb = ri[kb];
+        double la[kCols], lb[kCols];
+#pragma unroll
+        for (int ci = 0; ci < kCols; ++ci) la[ci] = colp[ci][ka];
+#pragma unroll
+        for (int ci = 0; ci < kCols; ++ci) lb[ci] = colp[ci][kb];
+        const double va = x[xa], vb = (k0 + 64 < k1) ? x[xb] : 0.0;
+#pragma unroll
+        for (int ci = 0; ci < kCols; ++ci) acc[ci] = fma(la[ci], va, acc[ci]);
+#pragma unroll
+        for (int ci = 0; ci < kCols; ++ci) acc[ci] = fma(lb[ci], vb, acc[ci]);
+    }
+    double* __restrict__ red = s_red[wave];
+#pragma unroll
+    for (int ci = 0; ci < kCols; ++ci) red[ci * kLdR + lane] = acc[ci];
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane % kCols, g = lane / kCols;   // 4 row groups of 16 parts per column
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        v0 += red[c * kLdR + 16 * g + i];
+        v1 += red[c * kLdR + 16 * g + i + 1];
+    }
+    double v = v0 + v1;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (g == 0) part[(int64_t)pd.pad * kTile + kCols * wave + c] = v;
+}
+
+void launch_bsolve_below(const DevicePattern& P, int first, int count, const double* L, const double* x, hipStream_t stream) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_bsolve_below, dim3(count), dim3(kThreads), 0, stream, P.sn, P.bsolve_below + first, P.rows, L, x,
+                       P.bpart);
+}
+
 // Backward chain for ONE right-hand side: the counterpart of k_solve_chain_w.  A workgroup = eight waves = up to
 // kBackGroup (2) consecutive block columns of a wide supernode (the highest one first), taken by ticket from a list
 // that runs from the last block column of a supernode to its first; four waves share a block column, 16 columns
@@ -2446,7 +2508,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
                                                                      const double* __restrict__ dinv,
                                                                      double* __restrict__ x, double* __restrict__ xscratch,
                                                                      int* __restrict__ info, int* __restrict__ ticket,
-                                                                     int wait_bias) {
+                                                                     int wait_bias, const double* __restrict__ part) {
     __shared__ double s_inv[kBackBlocks][kInvPacked + 1];   // column c of the inverse from row c on (as k_solve_chain_w)
     __shared__ double s_t[kBackBlocks][kTile];              // t of a block: its waves' column sums
     __shared__ double s_pub[kBackBlocks][kTile];            // x of a block, for the blocks below it in this workgroup
@@ -2507,8 +2569,16 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
 #pragma unroll
         for (int ci = 0; ci < kBackCols; ++ci) lv[u][ci] = colp[ci][k];
     };
-    // ---- rows below the supernode's own columns: x is final
-    for (int k0 = w + lane; k0 < r; k0 += 64 * kBackAhead) {
+    // ---- rows below the supernode's own columns: x is final.  Summed by k_bsolve_below before this launch (pd.pad =
+    // the supernode's first slot + 1: one slot of 64 sums per block column and 512-row chunk) or streamed here.
+    // Lane (c, g) of the final reduction adds the chunks g, g + 4, .. of its column, in that order: loaded now, used then.
+    double below = 0.0;
+    if (pd.pad > 0) {
+        const int nch = (r - w + kBelowRows - 1) / kBelowRows;
+        const double* __restrict__ mine = part + ((int64_t)(pd.pad - 1) + (int64_t)jb * nch) * kTile + kBackCols * qw + lane % kBackCols;
+        for (int ch = lane / kBackCols; ch < nch; ch += 64 / kBackCols) below += mine[(int64_t)ch * kTile];
+    }
+    for (int k0 = w + lane; k0 < r && pd.pad <= 0; k0 += 64 * kBackAhead) {
         int xr[kBackAhead];
 #pragma unroll
         for (int u = 0; u < kBackAhead; ++u) {
@@ -2581,7 +2651,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_bsolve_chain_w(const SnDes
             v0 += red[c * kLdRed + kPer * g + i];
             v1 += red[c * kLdRed + kPer * g + i + 1];
         }
-        double v = v0 + v1;
+        double v = v0 + v1 + below;
 #pragma unroll
         for (int off = kBackCols; off < 64; off <<= 1) v += __shfl_xor(v, off);
         if (g == 0) s_t[b][kBackCols * qw + c] = v;
@@ -2625,7 +2695,7 @@ void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const d
                            double* x, double* xscratch, int ticket, int wait_bias, hipStream_t stream) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_bsolve_chain_w, dim3(count), dim3(kChainThreads), 0, stream, P.sn, P.bsolve_pairs + first,
-                       P.rows, L, dinv, x, xscratch, P.sinfo, P.stickets + ticket, wait_bias);
+                       P.rows, L, dinv, x, xscratch, P.sinfo, P.stickets + ticket, wait_bias, P.bpart);
 }
 
 // mode: Launch::fused -- 0: one workgroup per block, 1: chain launch (tickets), 2: subtree launch (`first` counts

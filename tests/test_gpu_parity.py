@@ -605,6 +605,33 @@ def test_backward_solve_matches_checker(api, oracle, name, nrhs):
         assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
 
 
+@pytest.mark.parametrize("name", ["ex15", "mid3d", "lap30", "nd24k"])
+def test_backward_solve_with_the_rows_below_summed_first(api, oracle, monkeypatch, name):
+    """One right-hand side: the sums of a wide supernode's block columns over the rows below its own columns go to
+    k_bsolve_below (512-row chunks over the whole device, partial sums added up by the chain in a fixed order) where a
+    level's chain launch has few workgroups; PARSY_BSOLVE_BELOW=2 takes that path for every wide supernode, 0 never.
+    Each against the checker, bitwise reproducible, and the plan check covers the slots."""
+    A, perm, sym = problem(name)
+    rng = np.random.default_rng(12)
+    y = rng.standard_normal(sym.n)
+    got = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PARSY_BSOLVE_BELOW", mode)
+        plan = api.Plan(sym, 0)
+        assert plan.check() == 0
+        lo, _ = plan.factor(sym.A2x)
+        assert plan.status() == 0
+        x1, _ = plan.solve2(lo, y, forward=False)
+        x2, _ = plan.solve2(lo, y, forward=False)
+        assert plan.solve_status() == 0 and np.array_equal(x1, x2)
+        xo = oracle.blocked_ltsolve(sym, lo, y)
+        assert np.abs(x1.ravel() - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+        got[mode] = (x1, plan.info["backsolve_launches"])
+    if sym.maxSupWid > 64:
+        assert got["2"][1] >= got["0"][1]         # (the extra launches, where a wide supernode has rows below)
+    assert np.abs(got["2"][0] - got["0"][0]).max() <= 1e-12 * max(1.0, np.abs(got["0"][0]).max())
+
+
 @pytest.mark.parametrize("name,nrhs", [("lap30", 64), ("mid3d", 19), ("nd24k", 70)])
 def test_backward_solve_many_rhs_without_the_chain(api, oracle, monkeypatch, name, nrhs):
     """The per-block-column form (PARSY_FORCE_UNFUSED: what runs where a chain launch is not wanted) of the many-
