@@ -112,7 +112,13 @@ def cpu_baseline(sym, threads: int, budget_s: float = 8.0):
     cal = pick(max(total * 1e-3, min(total, 3e10)))
     run(cal, 1)
     rate = sub[cal] / run(cal, 1)
-    root = pick(max(sub[cal], rate * budget_s))
+    # The sample is the SAME subtree in every run (a sample sized from the measured rate moved from run
+    # to run): the largest subtree of at most 1.2e12 executed flops (about 8 s at the 150 GFLOP/s this port reaches on
+    # 16 cores), halved only while the calibration says it would take more than 4 x the budget on this host.
+    limit = 1.2e12
+    while limit > sub[cal] and limit / rate > 4.0 * budget_s:
+        limit *= 0.5
+    root = pick(max(sub[cal], limit))
     whole = sub[root] >= 0.999 * total
     secs = run(root, 3)
     sample = (f"{'the whole matrix' if whole else 'one etree subtree'}: supernodes {int(first[root])}..{root} of "

@@ -1744,17 +1744,6 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
     const int ld = D.ld;
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
-#if defined(PARSY_BIG_DEPHASE) || defined(PARSY_BIG_PRIO_TG)
-    // (experiments) the workgroups resident on one compute unit are told apart by HW_ID.TG_ID (bits 19:16)
-    const int tg_id = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4);
-#endif
-#ifdef PARSY_BIG_DEPHASE
-    // the first residents of a launch start together and -- tasks of equal length -- stay in step: both stage, both
-    // multiply.  The odd one of a compute unit starts half a chunk period late.
-    if ((int)blockIdx.x < 512 && (tg_id & 1)) {
-        __builtin_amdgcn_s_sleep(PARSY_BIG_DEPHASE);
-    }
-#endif
 #ifdef PARSY_BIGABL_ZEROOPS
     const long long zmask = td.part == 12345 ? -1ll : 0ll;   // (0 at run time; the compiler cannot know)
 #endif
@@ -1888,12 +1877,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
         const double* __restrict__ Cb = &S.C[b][kq * kBLd + c0 + l15];
         // the multiplying waves win the issue arbitration over the waves that write back (-1.7 % of the BIG
         // launches on the Flan-class input: 375 -> 369 ms, profiles/r03_big_ablation.txt)
-#ifdef PARSY_BIG_PRIO_TG
-        if (tg_id & 1) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(1);
-#else
         __builtin_amdgcn_s_setprio(1);
-#endif
         // the operands of k step ks + 1 are read from LDS before the products of k step ks are issued (363 -> 357 ms of
         // BIG launches on the Flan-class input)
         double rv[2][kBigNfr], cv[2][kBigNfc];
