@@ -2095,6 +2095,10 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int r0 = 64 * (wave >> 1), c0 = 64 * (wave & 1);   // this wave's block of the 128 x 128 product
+#ifdef PARSY_DENSESTAMPS
+    unsigned long long dph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dlast = __builtin_readcyclecounter();
+#endif
     const TileDesc td = tasks[blockIdx.x];
     const int64_t e_begin = td.wp, e_end = td.sp;
     if (e_begin >= e_end) return;
@@ -2268,15 +2272,12 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         for (int i = 0; i < 4; ++i) issue(0, i, false);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-#ifdef PARSY_DENSESTAMPS
-    unsigned long long dph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dlast = __builtin_readcyclecounter();
-#endif
     Ops A, B;
     read_ops(0, 0, A);
     read_ops(0, 1, B);
     PARSY_DENSE_WAIT(A, 4);
     if (CE.K < 4) mask_ops(A, kq < CE.K);
+    DSTAMP(10);   // (entry -> first products: descriptors, the first chunk's round trip)
     // Software pipeline over the k steps: every LDS read is issued one whole k step (16 products) before its
     // operands are needed, into the registers the products issued just before have finished reading, so that a wave
     // never waits for the LDS.  State at the top of iteration n: A = the operands of chunk n's first k step, landed
@@ -2354,6 +2355,8 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     if (lane == 0) {
         for (int i = 0; i < 9; ++i) atomicAdd(&g_densephase[i], dph[i]);
         atomicAdd(&g_densephase[9], (unsigned long long)total);
+        atomicAdd(&g_densephase[10], dph[10]);
+        atomicAdd(&g_densephase[11], 1ull);   // (waves x tasks)
     }
 #endif
 #undef PARSY_DENSE_WAIT

@@ -28,3 +28,7 @@ tot = float(out[:9].sum())
 print(f"chunks (wave x chunk): {chunks:.3e}; clocks per chunk and wave: {tot / chunks:.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {float(out[i]) / chunks:8.1f}  {float(out[i]) / tot:6.3f}")
+wt = float(out[11])
+if wt > 0:
+    print(f"tasks (wave x task): {wt:.3e}; chunks per task {chunks / wt:.1f}; clocks from kernel entry to the first products, per task: "
+          f"{float(out[10]) / wt:.0f}; in-loop clocks per task {tot / wt:.0f}")

@@ -27,7 +27,7 @@ nfact = rf.get("k_scatter_a", {}).get("launches", 1)
 out = {
     "workload": workload, "kernel_source_hash": khash,
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 tools/one_factor.py <workload> 2 2 "
-               "(one pass per counter; tools/collect_r03.sh)",
+               "(one pass per counter; tools/collect_r04.sh)",
     "calibration_bytes_per_count": {"FETCH_SIZE, 8-B lanes contiguous (k_chol_big staging, solve rows)": u_read8,
                                     "FETCH_SIZE, 8-B lanes in 128-B segments (wave streams)": u_read8m,
                                     "FETCH_SIZE, 16-B lanes contiguous": u_read16,
@@ -36,7 +36,7 @@ out = {
                                     "WRITE_SIZE, 8-B sc1 stores": u_write8s},
     "factorizations_in_the_profiled_run": nfact, "kernels": {},
 }
-shape = {"k_chol_big": (u_dma16, u_write8), "k_chol_tiles": (u_read8m, u_write8), "k_chol_chain": (u_read8m, u_write8s),
+shape = {"k_chol_big": (u_dma16, u_write8), "k_chol_dense": (u_dma16, u_write8), "k_bsolve_below": (u_read8, u_write8), "k_chol_tiles": (u_read8m, u_write8), "k_chol_chain": (u_read8m, u_write8s),
          "k_chol_small": (u_read8, u_write8), "k_scatter_a": (u_read8, u_write8)}
 for name in sorted(set(rf) | set(rw)):
     if not name.startswith("k_"):
