@@ -20,7 +20,6 @@
 
 using parsy::set_last_error;
 
-static_assert(PARSY_PROFILE_KINDS == kProfileKinds, "profile kinds");
 namespace {
 
 #define CAPI_HIP(call, ret)                                                          \
@@ -335,10 +334,6 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->backsolve_launches = (int32_t)S.bsolve.size();
     for (const parsy::Launch& l : S.chol)
         if (l.kind == parsy::kLaunchDense) o->dense_tasks += l.count;
-    for (const parsy::Launch& l : S.chol)
-        if (l.kind == parsy::kLaunchThin) o->thin_tasks += l.count;
-    o->thin_flops = S.thin_flops;
-    o->thin_entries = (int64_t)S.thin_entries.size();
     o->dense_flops = S.dense_flops;
     o->dense_entries = S.n_dense_entries;
     return 0;
@@ -544,7 +539,7 @@ int parsy_plan_profile(parsy_plan* pl, int enable) {
     if (!pl) return -1;
     pl->profile = enable != 0;
     if (enable == 2) {  // reset the accumulators
-        for (int k = 0; k < PARSY_PROFILE_KINDS; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
+        for (int k = 0; k < 10; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
         pl->profiled_runs = 0;
         pl->level_ms.clear();
     }
@@ -555,7 +550,7 @@ int parsy_plan_profile_collect(parsy_plan* pl) { return pl ? parsy::plan_collect
 
 int parsy_plan_profile_get(parsy_plan* pl, double* kind_ms, int* kind_launches, int* runs) {
     if (!pl) return -1;
-    for (int k = 0; k < PARSY_PROFILE_KINDS; ++k) {  // PARSY_PROFILE_KINDS entries each
+    for (int k = 0; k < 10; ++k) {  // PARSY_PROFILE_KINDS entries each
         if (kind_ms) kind_ms[k] = pl->kind_ms[k];
         if (kind_launches) kind_launches[k] = pl->kind_launches[k];
     }

@@ -790,10 +790,7 @@ __device__ __forceinline__ double* lds_colbuf(RowsLds&) { return nullptr; }
 __device__ __forceinline__ double* lds_dgbuf(TileLds& S) { return S.dgbuf; }
 __device__ __forceinline__ double* lds_dgbuf(RowsLds& S) { return &S.T[0][0]; }   // (the tile is in registers by then)
 
-// ATOMIC (THIN launches: the thin windows of wide descendants' updates, per-wave streams like the TILES launch): the
-// tile starts from zero, receives the products of this launch's list, and is ADDED to the panel with atomic adds (each
-// entry of L by one lane of one wave per launch; the launches of the BIG updates are ordered on their stream).
-template <bool CHAIN, bool ROWS = false, class LdsT = TileLds, bool ATOMIC = false>
+template <bool CHAIN, bool ROWS = false, class LdsT = TileLds>
 __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc* __restrict__ sn,
                                           const int32_t* __restrict__ relpos,
                                           const WaveEntry* __restrict__ wents,
@@ -857,7 +854,7 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
             const int e = q * 64 + lane;
             const int cc = e >> 5, rr = e & 31;
             const bool in = rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc);
-            tv[q] = (in && split_part == 0 && !ATOMIC) ? G[(int64_t)(subcol0 + cc) * ld + subrow0 + rr] : 0.0;
+            tv[q] = (in && split_part == 0) ? G[(int64_t)(subcol0 + cc) * ld + subrow0 + rr] : 0.0;
         }
         if (CHAIN && split_n > 1) {
             for (int part = 1; part < split_n; ++part) {
@@ -1086,15 +1083,7 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
         }
     };
     if (!CHAIN) {
-        if (ATOMIC) {
-            if (wave_on)
-                for (int e = lane; e < kSub * kSub; e += 64) {
-                    const int cc = e >> 5, rr = e & 31;
-                    const double v = Tw[cc * kLdSub + rr];
-                    if (rr < nrows && cc < ncols && (subrow0 + rr >= subcol0 + cc) && v != 0.0)
-                        unsafeAtomicAdd(&G[(int64_t)(subcol0 + cc) * ld + subrow0 + rr], v);
-                }
-        } else if (split_part == 0) {
+        if (split_part == 0) {
             write_tile(Tflat, td.row0, td.col0, 0);
         } else if (wave_on) {
             double* __restrict__ PT = tile_scratch + td.sp + (int64_t)(split_part - 1) * (kTile * kTile);
@@ -1794,13 +1783,8 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
             const int k = wave + kBigWaves * h;
             if (k < kend) {
                 const double* __restrict__ col = base + (int64_t)k * LE.ld;
-#ifdef PARSY_BIG_LANEMASK   // (experiment) lanes whose rows the window does not have take no part in the DMA
-                if (2 * lane < (LE.mn & 255)) glds16(col + LE.ia + 2 * lane, &S.R[b][k * kBLd]);
-                if (2 * lane < ((LE.mn >> 8) & 255)) glds16(col + LE.ja + 2 * lane, &S.C[b][k * kBLd]);
-#else
                 glds16(col + LE.ia + offR, &S.R[b][k * kBLd]);
                 glds16(col + LE.ja + offC, &S.C[b][k * kBLd]);
-#endif
             }
         }
         // ragged end of a source: the columns up to the next multiple of four are zero (k steps go by four)
@@ -2216,9 +2200,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         o.c01 = ok ? o.c01 : double2_t{0, 0};
         o.c23 = ok ? o.c23 : double2_t{0, 0};
     };
-    // the four products of column fragment fc.  (Skipping the fragments a ragged window does not have -- wave-uniform
-    // branches as in k_chol_big -- was built and measured: 5 % slower on full blocks, and ragged windows no faster than in
-    // k_chol_big: 334 ms for everything here against 245 + 67 ms split.)
+    // the four products of column fragment fc
     auto products4 = [&](const Ops& o, int fc) {
         const double rv[4] = {o.r01[0], o.r01[1], o.r23[0], o.r23[1]};
         const double cv[4] = {o.c01[0], o.c01[1], o.c23[0], o.c23[1]};
@@ -2429,22 +2411,6 @@ void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hi
     if (count <= 0) return;
     hipLaunchKernelGGL(k_chol_big, dim3(count), dim3(kBigThreads), 0, stream, P.csn, P.relpos, P.big_entries,
                        P.big_tasks + first, L);
-}
-
-__global__ __launch_bounds__(kThreads, 3) void k_chol_thin(const SnDesc* __restrict__ sn,
-                                                           const int32_t* __restrict__ relpos,
-                                                           const WaveEntry* __restrict__ wents,
-                                                           const int64_t* __restrict__ wptr,
-                                                           const TileDesc* __restrict__ tiles, double* __restrict__ L) {
-    __shared__ TileLds S;
-    tile_task<false, false, TileLds, true>(S, (int)blockIdx.x, sn, relpos, wents, wptr, nullptr, nullptr, tiles, L, nullptr,
-                                           nullptr, 0, 0);
-}
-
-void launch_chol_thin(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_thin, dim3(count), dim3(kThreads), 0, stream, P.csn, P.relpos, P.thin_entries, P.thin_ptr,
-                       P.thin_tasks + first, L);
 }
 
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {

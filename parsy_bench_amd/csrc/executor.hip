@@ -47,7 +47,6 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.bsolve_ranges, pl->dp.bsolve_ranges, true)) return -1;
     if (upload(pl, S.tiles, pl->dp.tiles, true)) return -1;
     if (upload(pl, S.big_tasks, pl->dp.big_tasks, true)) return -1;
-    if (upload(pl, S.thin_tasks, pl->dp.thin_tasks, true)) return -1;
     if (upload(pl, S.solve_small_list, pl->dp.solve_small_list, true)) return -1;
     if (upload(pl, S.solve_panels, pl->dp.solve_panels, true)) return -1;
     if (upload(pl, S.solve_mtasks, pl->dp.solve_mtasks, true)) return -1;
@@ -82,8 +81,6 @@ static int plan_upload(parsy_plan* pl) {
     if (upload(pl, S.sn, pl->dp.sn, false)) return -1;
     if (upload(pl, S.csn, pl->dp.csn, false)) return -1;
     if (upload(pl, S.big_entries, pl->dp.big_entries, false)) return -1;
-    if (upload(pl, S.thin_entries, pl->dp.thin_entries, false)) return -1;
-    if (upload(pl, S.thin_ptr, pl->dp.thin_ptr, false)) return -1;
     if (upload(pl, S.upd, pl->dp.upd, false)) return -1;
     if (upload(pl, S.relpos, pl->dp.relpos, false)) return -1;
     if (upload(pl, S.a_dst, pl->dp.a_dst, false)) return -1;
@@ -254,7 +251,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             // enqueued so far whose targets can be at level t: those with a level field <= t (a PUSH writes
             // into EVERY level from its field upwards).  The side stream runs in order, so the latest of them
             // covers the earlier ones; PUSH(t - 1) / TILES(t + 1) (field t + 1) stay free to overlap.
-            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig || l.kind == kLaunchDense || l.kind == kLaunchThin)) {
+            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig || l.kind == kLaunchDense)) {
                 int lw = std::min<int>(l.level, (int)early_seen.size() - 1);
                 while (lw >= 0 && !early_seen[lw]) --lw;
                 if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
@@ -266,14 +263,12 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchTiles:
             case kLaunchBig:
             case kLaunchDense:
-            case kLaunchThin:
                 if (on_side) {
                     record_levels_below(l.wait_level + 1);
                     (void)hipStreamWaitEvent(pl->side_stream,
                                              l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
                     if (l.kind == kLaunchBig) launch_chol_big(pl->dp, l.first, l.count, L, pl->side_stream);
                     else if (l.kind == kLaunchDense) launch_chol_dense(pl->dp, l.first, l.count, L, pl->side_stream);
-                    else if (l.kind == kLaunchThin) launch_chol_thin(pl->dp, l.first, l.count, L, pl->side_stream);
                     else launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
                     (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
                     early_seen[l.level] = 1;
@@ -281,8 +276,6 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                     launch_chol_big(pl->dp, l.first, l.count, L, stream);
                 } else if (l.kind == kLaunchDense) {
                     launch_chol_dense(pl->dp, l.first, l.count, L, stream);
-                } else if (l.kind == kLaunchThin) {
-                    launch_chol_thin(pl->dp, l.first, l.count, L, stream);
                 } else {
                     launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }
@@ -404,7 +397,7 @@ int plan_collect_profile(parsy_plan* pl) {
         const int k = pl->pev_kind[i];
         if (pl->pev_ms.size() <= i) pl->pev_ms.resize(i + 1, 0.f);
         pl->pev_ms[i] = ms;
-        if (k >= 0 && k < kProfileKinds) {
+        if (k >= 0 && k < 10) {
             pl->kind_ms[k] += ms;
             pl->kind_launches[k] += 1;
         }

@@ -29,9 +29,6 @@ struct DevicePattern {           // device copies of Schedule arrays
     const TileDesc* tiles = nullptr;
     const WaveEntry* big_entries = nullptr;   // BIG launches: (source, row window, column window) per task
     const TileDesc* big_tasks = nullptr;
-    const WaveEntry* thin_entries = nullptr;  // THIN launches: per-wave update streams of the thin windows of wide descendants
-    const int64_t* thin_ptr = nullptr;
-    const TileDesc* thin_tasks = nullptr;
     const int32_t* solve_small_list = nullptr;
     const PanelDesc* solve_panels = nullptr;
     const PanelDesc* solve_mtasks = nullptr;
@@ -61,7 +58,6 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
-void launch_chol_thin(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, bool rows, double* L,
                        hipStream_t stream);

@@ -318,10 +318,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     std::vector<int64_t> cursor;
     struct BigKeyed { int64_t launch_tile; WaveEntry e; int16_t sr, sc; };  // launch id << 40 | global tile index
     std::vector<BigKeyed> bigk;
-    struct ThinKeyed { int64_t key; int32_t piece; WaveEntry e; };   // (launch id << 40 | global 64 x 64 tile) * 4 + wave
-    std::vector<ThinKeyed> think;
-    const int thin_max = S.solve_only ? 0 : env_int("PARSY_THIN_FILL", (int)(kThinMaxFill * 100 + 0.5)) * kBigTile * kBigTile / 100;
-    std::vector<Group> tg_r, tg_c;
     std::vector<int64_t> big_tile0(nc + 1, 0);  // first 128x128 tile index of every tiled piece
     // Edge of a BIG task's super-tile in 128 x 128 tiles, rows x columns, per launch (source level, kind).  A launch
     // with many tasks whose 128 x 128 windows are mostly ragged (a 128-row window of the target holds about 64 rows of
@@ -493,37 +489,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                             const int mi = std::min(kBigTile, gr.len - rb), nj = std::min(kBigTile, njt - cb);
                             const int ia = gr.first + rb, ja = gc.first + cb;
                             if (ia + mi - 1 < ja) continue;   // block strictly above the diagonal
-                            if (U.rel >= 0 && mi * nj <= thin_max) {
-                                // THIN: the block along the 32-row windows of the target's 64 x 64 tiles, one entry per
-                                // (row window, column window) pair on or below the diagonal, for the wave of that sub-tile
-                                auto cut = [&](int k0, int len, std::vector<Group>& out) {
-                                    out.clear();
-                                    for (int k = k0; k < k0 + len;) {
-                                        const int win = rel_at(U, k) / kSub;
-                                        int k1 = k + 1;
-                                        while (k1 < k0 + len && rel_at(U, k1) / kSub == win) ++k1;
-                                        out.push_back(Group{win, k, k1 - k});
-                                        k = k1;
-                                    }
-                                };
-                                cut(ia, mi, tg_r);
-                                cut(ja, nj, tg_c);
-                                for (const Group& c32 : tg_c)
-                                    for (const Group& r32 : tg_r) {
-                                        if (r32.win < c32.win) continue;
-                                        const int I = r32.win / 2, J = c32.win / 2;
-                                        const int64_t gtile = (int64_t)T.tflag0 + (int64_t)I * nbc + J;
-                                        think.push_back(ThinKeyed{((launch << 40) | gtile) * 4 + (r32.win & 1) * 2 + (c32.win & 1), t,
-                                                                  WaveEntry{U.src, (int32_t)U.rel, U.ld, U.K, r32.first, c32.first,
-                                                                            r32.len | (c32.len << 8)}});
-                                    }
-                                {
-                                    double pairs = 0;
-                                    for (int jj = ja; jj < ja + nj; ++jj) pairs += std::max(0, ia + mi - std::max(ia, jj));
-                                    S.thin_flops += 2.0 * U.K * pairs;
-                                }
-                                continue;
-                            }
                             bigk.push_back(BigKeyed{(launch << 40) | tile,
                                                     WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, ia, ja,
                                                               mi | (nj << 8) | ((U.rel < 0) << 16)},
@@ -675,36 +640,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         }
     }
 
-    // ---- THIN tasks: one per (launch, 64 x 64 tile), four wave lists each, entries in update order
-    if (!think.empty()) {
-        std::stable_sort(think.begin(), think.end(), [](const ThinKeyed& a, const ThinKeyed& b) { return a.key < b.key; });
-        S.thin_entries.resize(think.size());
-        for (size_t i = 0; i < think.size();) {
-            const int64_t lt = think[i].key >> 2;
-            const int t = think[i].piece;
-            const SnDesc& T = S.csn[(size_t)t];
-            const int nbc = ceil_div(T.w, kTile);
-            const int64_t local = (lt & ((1LL << 40) - 1)) - T.tflag0;
-            const int64_t launch = lt >> 40;
-            Schedule::ThinTask task{t, (int32_t)(local / nbc) * kTile, (int32_t)(local % nbc) * kTile, 0,
-                                    (int64_t)S.thin_ptr.size(), (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0)};
-            size_t j = i;
-            for (int wv = 0; wv < 4; ++wv) {
-                S.thin_ptr.push_back((int64_t)j);
-                int64_t chunks = 0;
-                while (j < think.size() && (think[j].key >> 2) == lt && (int)(think[j].key & 3) == wv) {
-                    S.thin_entries[j] = think[j].e;
-                    chunks += ceil_div(think[j].e.K, 16) + 1;
-                    ++j;
-                }
-                task.weight = std::max<int32_t>(task.weight, (int32_t)std::min<int64_t>(chunks, INT32_MAX));
-            }
-            S.thin_ptr.push_back((int64_t)j);
-            S.thin_all.push_back(task);
-            i = j;
-        }
-    }
-
     build_launches(S, active);
 }
 
@@ -743,18 +678,6 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     // stream works through that level's chain; Launch::level = lev = s + 2 is the level whose main-stream
     // launches wait for them.
     S.big_tasks.clear();
-    S.thin_tasks.clear();
-    std::vector<std::vector<const Schedule::ThinTask*>> thin_next(S.cnlevels), thin_push(S.cnlevels);
-    for (const Schedule::ThinTask& b : S.thin_all)
-        if (S.active_piece[b.sn]) (b.next ? thin_next : thin_push)[b.src_level].push_back(&b);
-    auto emit_thin = [&](std::vector<const Schedule::ThinTask*>& v, Launch L) {
-        if (v.empty()) return L;
-        std::stable_sort(v.begin(), v.end(), [](const Schedule::ThinTask* a, const Schedule::ThinTask* b) { return a->weight > b->weight; });
-        L.first = (int32_t)S.thin_tasks.size();
-        for (const Schedule::ThinTask* b : v) S.thin_tasks.push_back(TileDesc{b->sn, b->row0, b->col0, 0, b->wp, 0});
-        L.count = (int32_t)v.size();
-        return L;
-    };
     std::vector<Launch> early_launches;
     std::vector<size_t> level_begin;  // index in S.chol where each level's launches start
     std::vector<int> bigs, sbigs;
@@ -935,16 +858,12 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             if (Ld.count > 0) early_launches.push_back(Ld);
             Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, false);
             if (Lp.count > 0) early_launches.push_back(Lp);
-            Launch Lt = emit_thin(thin_push[lev], Launch{kLaunchThin, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1});
-            if (Lt.count > 0) early_launches.push_back(Lt);
         }
         if (lev > 0) {
             Launch Ld = emit_big(big_next[lev - 1], Launch{kLaunchDense, 0, 0, lev, 0, 0, 0, 0, -1, 0}, true);
             if (Ld.count > 0) S.chol.push_back(Ld);
             Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0}, false);
             if (Ln.count > 0) S.chol.push_back(Ln);
-            Launch Lt = emit_thin(thin_next[lev - 1], Launch{kLaunchThin, 0, 0, lev, 0, 0, 0, 0, -1, 0});
-            if (Lt.count > 0) S.chol.push_back(Lt);
         }
         if (!bigs.empty()) {
             // ---- TILES: the early part of the external updates, longest streams first ------
@@ -1605,59 +1524,6 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
                     covered[(size_t)u] += entry_flops(E, E.ia == E.ja);
                 }
         }
-    }
-    // THIN tasks: 32-row windows of a 64 x 64 tile of the target, blocks of a wide descendant's rows
-    for (const Schedule::ThinTask& b : S.thin_all) {
-        const SnDesc& T = S.csn[(size_t)b.sn];
-        if (b.src_level >= S.level_of[(size_t)b.sn] || (b.next != 0) != (b.src_level == S.level_of[(size_t)b.sn] - 1))
-            fail("THIN task of piece " + std::to_string(b.sn) + " is filed under the wrong source level");
-        if (b.row0 % kTile || b.col0 % kTile || b.row0 < b.col0 || b.row0 >= T.r || b.col0 >= T.w || b.wp + 4 >= (int64_t)S.thin_ptr.size())
-            fail("THIN task of piece " + std::to_string(b.sn) + " has a bad tile origin");
-        for (int wv = 0; wv < 4; ++wv)
-            for (int64_t e = S.thin_ptr[(size_t)b.wp + wv]; e < S.thin_ptr[(size_t)b.wp + wv + 1]; ++e) {
-                const WaveEntry& E = S.thin_entries[(size_t)e];
-                int64_t u = -1;
-                for (int64_t q = T.upd0; q < T.upd0 + T.nupd; ++q)
-                    if (S.upd[q].src == E.src && S.upd[q].K == E.K) u = q;
-                const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-                if (u < 0 || S.upd[u].rel < 0 || mi < 1 || mi > kSub || nj < 1 || nj > kSub || E.ia + mi > S.upd[u].m ||
-                    E.ja + nj > S.upd[u].n1 || S.level_of[S.upd_src[u]] != b.src_level) {
-                    fail("THIN entry " + std::to_string(e) + " of piece " + std::to_string(b.sn) + " has a bad window or source");
-                    continue;
-                }
-                auto rel_at = [&](int k) { return S.relpos[(size_t)S.upd[u].rel + k] - T.rbias; };
-                const int r0 = b.row0 + kSub * (wv >> 1), c0 = b.col0 + kSub * (wv & 1);
-                if (rel_at(E.ia) / kSub != r0 / kSub || rel_at(E.ia + mi - 1) / kSub != r0 / kSub || rel_at(E.ja) / kSub != c0 / kSub ||
-                    rel_at(E.ja + nj - 1) / kSub != c0 / kSub)
-                    fail("THIN entry " + std::to_string(e) + " names rows outside its wave's sub-tile");
-                covered[(size_t)u] += block_flops(E);
-            }
-    }
-    {
-        // the THIN launches hold every task of an active target exactly once, under its (source level, kind), after
-        // the BIG / DENSE launches of the same (source level, kind)
-        std::vector<int64_t> seen;
-        for (const Launch& l : S.chol) {
-            if (l.kind != kLaunchThin) continue;
-            for (int q = l.first; q < l.first + l.count; ++q) {
-                const TileDesc& td = S.thin_tasks[(size_t)q];
-                auto it = std::lower_bound(S.thin_all.begin(), S.thin_all.end(), td.wp,
-                                           [](const Schedule::ThinTask& b, int64_t w) { return b.wp < w; });
-                if (it == S.thin_all.end() || it->wp != td.wp || it->sn != td.sn || it->row0 != td.row0 || it->col0 != td.col0) {
-                    fail("THIN launch task " + std::to_string(q) + " is not a task of the plan");
-                    continue;
-                }
-                const bool side = l.side != 0;
-                if (side == (it->next != 0) || (side ? l.wait_level : l.level - 1) != it->src_level)
-                    fail("THIN launch task " + std::to_string(q) + " runs in the launch of another source level");
-                seen.push_back(td.wp);
-            }
-        }
-        std::sort(seen.begin(), seen.end());
-        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) fail("a THIN task is launched twice");
-        int64_t want = 0;
-        for (const Schedule::ThinTask& b : S.thin_all) want += S.active_piece[(size_t)b.sn] != 0;
-        if ((int64_t)seen.size() != want) fail("THIN launches hold " + std::to_string(seen.size()) + " tasks, the active targets have " + std::to_string(want));
     }
     for (const Schedule::BigTask& b : S.big_all) {
         const SnDesc& T = S.csn[b.sn];

@@ -118,9 +118,8 @@ enum LaunchKind : int32_t {
                             // right before the level's chain launch
     kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
     kLaunchDense = 9,   // the dense entries of a BIG launch's tasks (k_chol_dense), right before that launch's ragged rest
-    kLaunchThin = 10,   // the thin windows of a BIG launch's updates as per-wave streams (k_chol_thin), right after it
 };
-inline bool is_chol_launch(int kind) { return (kind >= 0 && kind <= kLaunchBig) || kind == kLaunchDense || kind == kLaunchThin; }
+inline bool is_chol_launch(int kind) { return (kind >= 0 && kind <= kLaunchBig) || kind == kLaunchDense; }
 
 struct Launch {
     int32_t kind;
@@ -159,8 +158,6 @@ constexpr int kDenseChunk = 8;             // k extent of k_chol_dense's chunks 
 constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense when at least this share of its products is dense
                                            // (PARSY_BIG_DENSE=0: never, 2: wherever there is a dense entry)
 constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
-constexpr double kThinMaxFill = 0.0;       // a block of a wide descendant whose windows hold at most this share of 128 x 128 is streamed by
-                                           // single waves (THIN) instead of staged through LDS (PARSY_THIN_FILL, percent; 0: never)
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
@@ -230,17 +227,7 @@ struct Schedule {
     std::vector<BigTask> big_all;         // every task, grouped by (src_level, next)
     std::vector<TileDesc> big_tasks;      // tasks of the launches (active targets): k_chol_big: wp, sp = the ragged part [em, e1) of a
                                           // task; k_chol_dense: its dense part [e0, em), part = its 8-wide k chunks
-    // THIN: blocks of a wide descendant's rows whose windows hold only a few of them (at most kThinMaxFill of 128 x 128)
-    // do not enter the BIG lists: a chunk of k_chol_big costs the same whatever its window holds.  They are cut along the
-    // 32-row windows of the target's 64 x 64 tiles like the narrow descendants' updates and streamed by single waves
-    // (tile_task's update streams; the product added to the panel with atomic adds); one launch per BIG launch, after it.
-    std::vector<WaveEntry> thin_entries;  // per (launch, 64 x 64 tile, wave) in update order
-    std::vector<int64_t> thin_ptr;        // 5 per task: the four waves' ranges in thin_entries
-    struct ThinTask { int32_t sn, row0, col0, weight; int64_t wp; int32_t src_level, next; };
-    std::vector<ThinTask> thin_all;       // every task, grouped by (src_level, next)
-    std::vector<TileDesc> thin_tasks;     // tasks of the launches (active targets)
-    double thin_flops = 0;                // part of big_flops
-    double big_flops = 0;                 // flops of the BIG launches (dense + ragged entries) and of the THIN ones
+    double big_flops = 0;                 // flops of the BIG launches (dense + ragged entries)
     double dense_flops = 0;               // ... of which through k_chol_dense
     int64_t n_dense_entries = 0;
     std::vector<Launch> chol;

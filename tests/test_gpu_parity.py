@@ -733,50 +733,6 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
 
 
 # ---------------------------------------------------------------------------
-# THIN launches (k_chol_thin): blocks of a wide descendant whose windows hold few of its rows are streamed by single
-# waves along the 32-row windows of the target's 64 x 64 tiles (the TILES kernel's update streams) and ADDED to the
-# panel, instead of staged through LDS.  PARSY_THIN_FILL (percent of a 128 x 128 block): 0 never, 100 every block with a
-# row map (only the identity-map blocks between the pieces of a split supernode stay in the BIG lists).
-# ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name,piece,mink,sup,fill", [("mid3d", 128, 16, "0", 25), ("mid3d", 128, 16, "0", 100), ("lap30", 128, 32, "2", 25),
-                                                      ("lap30", 256, 64, "0", 100), ("ex15", 128, 16, "0", 100), ("nd24k", 0, 64, "0", 25),
-                                                      ("nd24k", 256, 64, "2", 100), ("small3d", 128, 16, "0", 50)])
-def test_factor_with_thin_launches(api, oracle, monkeypatch, name, piece, mink, sup, fill):
-    from parsy_bench_amd import inspector as I
-    A, perm, sym = problem(name)
-    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
-    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
-    if sup != "0":
-        monkeypatch.setenv("PARSY_BIG_SUPER", sup)
-    monkeypatch.setenv("PARSY_THIN_FILL", "0")
-    plan0 = api.Plan(sym, 0)
-    assert plan0.info["thin_entries"] == 0 and plan0.info["thin_tasks"] == 0
-    lv0, _ = plan0.factor(sym.A2x)
-    assert plan0.status() == 0
-    monkeypatch.setenv("PARSY_THIN_FILL", str(fill))
-    plan = api.Plan(sym, 0)
-    info = plan.info
-    assert info["thin_entries"] > 0 and info["thin_tasks"] > 0 and 0 < info["thin_flops"] <= info["big_flops"]
-    assert info["big_flops"] == plan0.info["big_flops"] and plan.check() == 0
-    lv, _ = plan.factor(sym.A2x)
-    assert plan.status() == 0
-    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
-    assert ok
-    scale = np.abs(lo).max()
-    assert np.abs(lv - lo).max() <= FACTOR_TOL * scale, f"{name}: thin launches vs oracle {np.abs(lv - lo).max() / scale:.3e}"
-    assert np.abs(lv - lv0).max() <= FACTOR_TOL * scale
-    for _ in range(2):
-        lv2, _ = plan.factor(sym.A2x)
-        assert np.array_equal(lv, lv2)   # one add per entry of L and launch, launches in stream order: bitwise reproducible
-    for sn in range(sym.nsuper):         # padding above the diagonal of every diagonal block stays exactly zero
-        c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
-        r = int(sym.i_ptr[c1] - sym.i_ptr[c0]) if c1 < sym.n else int(sym.ssize - sym.i_ptr[c0])
-        base = int(sym.p[c0])
-        for c in range(1, min(c1 - c0, 8)):
-            assert not lv[base + c * r: base + c * r + c].any()
-
-
-# ---------------------------------------------------------------------------
 # host buffers in and out (parsy_factor_host, what the drop-in operators call): large factors are downloaded band of
 # levels by band of levels BEHIND the kernels of the levels above (a worker thread; PARSY_HOST_PIPELINE=0: kernels, then
 # one download; 2: pipelined whatever the size).  Same kernels, same order: the factors must be bitwise equal, and
