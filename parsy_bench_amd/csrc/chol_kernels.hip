@@ -1715,9 +1715,12 @@ struct BigLds {
 };
 
 // one LDS-DMA instruction: 16 bytes per lane from the lane's own global address to lds + 16 * lane
+#ifndef PARSY_GLDS_AUX
+#define PARSY_GLDS_AUX 0     // (cache-policy bits of the staging loads: 2 = nt, 16 = sc1; measured: no gain, see DESIGN)
+#endif
 __device__ __forceinline__ void glds16(const double* g, double* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, PARSY_GLDS_AUX);
 }
 
 __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) void k_chol_big(const SnDesc* __restrict__ sn,
