@@ -149,9 +149,6 @@ typedef struct parsy_plan_info {
     int32_t dense_tasks;           /* workgroups of the DENSE launches (k_chol_dense) per factorization */
     double dense_flops;            /* part of big_flops in dense entries (full 128 x 128 blocks below the diagonal): k_chol_dense */
     int64_t dense_entries;
-    double thin_flops;             /* part of big_flops in thin windows, streamed by single waves: k_chol_thin */
-    int64_t thin_entries;
-    int32_t thin_tasks, pad_;
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).
@@ -295,11 +292,10 @@ double parsy_last_solve_ms(parsy_plan* plan);
  *   parsy_plan_profile(plan, 1) on, (plan, 0) off, (plan, 2) on + reset accumulators.
  *   parsy_plan_profile_collect(plan): after the stream is synchronised, add the
  *     elapsed time of every launch of the last factor/solve to its kernel kind.
- *   parsy_plan_profile_get: accumulated ms and launch counts per kind (PARSY_PROFILE_KINDS = 12 entries:
- *     0 SMALL, 1 TILES, 2 CHAIN, 3 BIG, 4 BACK_BELOW, 5 SOLVE_SMALL, 6 SOLVE_PANEL, 7 SOLVE_FIXUP,
- *     8 BACK_BLOCK, 9 DENSE, 10 THIN, 11 unused; the arrays passed must hold 12 entries) and the number of
- *     collected runs. */
-#define PARSY_PROFILE_KINDS 12
+ *   parsy_plan_profile_get: accumulated ms and launch counts per kind (PARSY_PROFILE_KINDS = 10 entries:
+ *     0 SMALL, 1 TILES, 2 CHAIN, 3 BIG, 4 unused, 5 SOLVE_SMALL, 6 SOLVE_PANEL, 7 SOLVE_FIXUP,
+ *     8 BACK_BLOCK, 9 unused; the arrays passed must hold 10 entries) and the number of collected runs. */
+#define PARSY_PROFILE_KINDS 10
 int parsy_plan_profile(parsy_plan* plan, int enable);
 int parsy_plan_profile_collect(parsy_plan* plan);
 int parsy_plan_profile_get(parsy_plan* plan, double* kind_ms, int* kind_launches, int* runs);

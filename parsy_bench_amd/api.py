@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _native as N
 
-KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "BACK_BELOW", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP", "BACK_BLOCK", "DENSE", "THIN", "---"]
+KIND_NAMES = ["SMALL", "TILES", "CHAIN", "BIG", "BACK_BELOW", "SOLVE_SMALL", "SOLVE_PANEL", "SOLVE_FIXUP", "BACK_BLOCK", "DENSE"]
 
 
 def device_count() -> int:
@@ -284,8 +284,8 @@ class Plan:
             raise RuntimeError("profile_collect: no profiled run to collect")
 
     def profile_get(self) -> dict:
-        ms = np.zeros(len(KIND_NAMES), dtype=np.float64)
-        cnt = np.zeros(len(KIND_NAMES), dtype=np.int32)
+        ms = np.zeros(10, dtype=np.float64)
+        cnt = np.zeros(10, dtype=np.int32)
         runs = C.c_int(0)
         N.lib().parsy_plan_profile_get(self._h, N.ptr(ms), N.ptr(cnt), C.byref(runs))
         return {"runs": runs.value, "ms": dict(zip(KIND_NAMES, ms.tolist())),

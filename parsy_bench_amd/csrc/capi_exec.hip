@@ -20,7 +20,6 @@
 
 using parsy::set_last_error;
 
-static_assert(PARSY_PROFILE_KINDS == kProfileKinds, "profile kinds");
 namespace {
 
 #define CAPI_HIP(call, ret)                                                          \
@@ -335,10 +334,6 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->backsolve_launches = (int32_t)S.bsolve.size();
     for (const parsy::Launch& l : S.chol)
         if (l.kind == parsy::kLaunchDense) o->dense_tasks += l.count;
-    for (const parsy::Launch& l : S.chol)
-        if (l.kind == parsy::kLaunchThin) o->thin_tasks += l.count;
-    o->thin_flops = S.thin_flops;
-    o->thin_entries = S.n_thin_entries;
     o->dense_flops = S.dense_flops;
     o->dense_entries = S.n_dense_entries;
     return 0;
@@ -428,17 +423,13 @@ int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap)
 }
 
 // Diagnostics: the tasks of the DENSE launches in launch order as rows of (launch index, 8-wide k chunks).
-// (and the THIN launches: rows of (launch, the task's weight = its k steps of four + 8 per piece))
-static int64_t debug_kind_tasks(const parsy_plan* pl, int kind, int32_t* out, int64_t cap);
-int64_t parsy_debug_thin_tasks(const parsy_plan* pl, int32_t* out, int64_t cap) { return debug_kind_tasks(pl, parsy::kLaunchThin, out, cap); }
-int64_t parsy_debug_dense_tasks(const parsy_plan* pl, int32_t* out, int64_t cap) { return debug_kind_tasks(pl, parsy::kLaunchDense, out, cap); }
-static int64_t debug_kind_tasks(const parsy_plan* pl, int kind, int32_t* out, int64_t cap) {
+int64_t parsy_debug_dense_tasks(const parsy_plan* pl, int32_t* out, int64_t cap) {
     if (!pl) return -1;
     const parsy::Schedule& S = pl->S;
     int64_t n = 0;
     int li = 0;
     for (const parsy::Launch& l : S.chol) {
-        if (l.kind != kind) continue;
+        if (l.kind != parsy::kLaunchDense) continue;
         for (int q = l.first; q < l.first + l.count; ++q, ++n)
             if (out && n < cap) {
                 out[2 * n] = li;
@@ -548,7 +539,7 @@ int parsy_plan_profile(parsy_plan* pl, int enable) {
     if (!pl) return -1;
     pl->profile = enable != 0;
     if (enable == 2) {  // reset the accumulators
-        for (int k = 0; k < PARSY_PROFILE_KINDS; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
+        for (int k = 0; k < 10; ++k) pl->kind_ms[k] = 0, pl->kind_launches[k] = 0;
         pl->profiled_runs = 0;
         pl->level_ms.clear();
     }
@@ -559,7 +550,7 @@ int parsy_plan_profile_collect(parsy_plan* pl) { return pl ? parsy::plan_collect
 
 int parsy_plan_profile_get(parsy_plan* pl, double* kind_ms, int* kind_launches, int* runs) {
     if (!pl) return -1;
-    for (int k = 0; k < PARSY_PROFILE_KINDS; ++k) {  // PARSY_PROFILE_KINDS entries each
+    for (int k = 0; k < 10; ++k) {  // PARSY_PROFILE_KINDS entries each
         if (kind_ms) kind_ms[k] = pl->kind_ms[k];
         if (kind_launches) kind_launches[k] = pl->kind_launches[k];
     }

@@ -2371,169 +2371,6 @@ void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, 
                        P.big_tasks + first, L);
 }
 
-// ---------------------------------------------------------------------------
-// THIN: the BIG entries whose windows hold a small share of 128 x 128 (63 % of k_chol_big's chunks on the Flan-class
-// input held at most a quarter; a chunk there costs the workgroup the same 2.7 us whatever its windows hold: two staged
-// columns of 128 rows per k, a barrier, eight waves).  The host cuts such a block into pieces of at most 8 fragments of
-// 16 x 16, at most two along one side (schedule.cpp: thin_piece_shape), and ONE WAVE forms a piece's product: its NA +
-// NB operand fragments per k step of four are loaded straight from the panel into the matrix instruction's registers
-// (lane = row l & 15 of a fragment at k + (l >> 4): four 128-byte runs per load), kThinDepth steps in flight, no LDS,
-// no barrier; a workgroup is four independent waves = four tasks.  A task = the thin entries of one (launch, target
-// tile), in update order, so the order of sums per entry of L stays what the plan says (one wave, program order;
-// launched after the launch's other parts).
-// The short side of a piece (<= 2 fragments) is the instruction's A operand -- its rows come out four to a lane, four
-// index registers per fragment -- and the long one (<= 8) its B operand (one index register each): a piece that is
-// long along the COLUMN window is multiplied transposed (swap), which changes nothing in what is summed.
-template <int NA, int NB>
-__device__ __forceinline__ void thin_piece(const WaveEntry& E, const bool swap, const SnDesc& D,
-                                           const int32_t* __restrict__ relpos, double* __restrict__ L, const int lane) {
-    constexpr int kDepth = NA + NB > 6 ? 3 : 4;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-    const bool ident = (E.mn >> 16) != 0;
-    // the A side's window (a0, am) and the B side's, in the source's rows
-    const int a0 = swap ? E.ia : E.ja, am = swap ? mi : nj, b0 = swap ? E.ja : E.ia, bm = swap ? nj : mi;
-    // where the product goes: asked for first, so that the indices land behind the products
-    int pa[NA][4], pb[NB];
-    if (ident) {
-#pragma unroll
-        for (int f = 0; f < NA; ++f)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pa[f][v] = a0 + 16 * f + kq + 4 * v;
-#pragma unroll
-        for (int f = 0; f < NB; ++f) pb[f] = b0 + 16 * f + l15;
-    } else {
-        const int32_t* __restrict__ rpa = relpos + (int64_t)E.rel + a0;
-        const int32_t* __restrict__ rpb = relpos + (int64_t)E.rel + b0;
-#pragma unroll
-        for (int f = 0; f < NA; ++f)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pa[f][v] = rpa[min(16 * f + kq + 4 * v, am - 1)];
-#pragma unroll
-        for (int f = 0; f < NB; ++f) pb[f] = rpb[min(16 * f + l15, bm - 1)];
-    }
-    int offA[NA], offB[NB];
-#pragma unroll
-    for (int f = 0; f < NA; ++f) offA[f] = a0 + min(16 * f + l15, am - 1);
-#pragma unroll
-    for (int f = 0; f < NB; ++f) offB[f] = b0 + min(16 * f + l15, bm - 1);
-    const double* __restrict__ base = L + E.src;
-    const int nsteps = (E.K + 3) >> 2;
-    double av[kDepth][NA], bv[kDepth][NB];
-    double4_t acc[NA * NB];
-#pragma unroll
-    for (int f = 0; f < NA * NB; ++f) acc[f] = double4_t{0, 0, 0, 0};
-    // step s of the entry into slot d, always NA + NB loads: a step past the end re-reads the last column (cache hits,
-    // multiplied as zeros).  The loads are inline assembly and the waits below counted by hand: written as plain loads,
-    // the compiler turned the loop round (load a round, wait for it, multiply it: nothing in flight across rounds), and
-    // with loads under a branch it waited for ALL of them before every product.
-    auto load = [&](int d, int s) {
-        const double* __restrict__ col = base + (int64_t)min(4 * s + kq, E.K - 1) * E.ld;
-#pragma unroll
-        for (int f = 0; f < NA; ++f) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(av[d][f]) : "v"(col + offA[f]) : "memory");
-#pragma unroll
-        for (int f = 0; f < NB; ++f) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bv[d][f]) : "v"(col + offB[f]) : "memory");
-    };
-    // step s from slot d: its loads are the oldest in flight, the kDepth - 1 steps after it may stay there.  k past the
-    // end of the source (the last step's ragged end, and the steps that round the entry up to whole rounds of the slots)
-    // multiplies zeros: the A side's lanes are cleared -- a loop without branches, or the compiler moves the
-    // accumulators between register files at every join
-    auto mult = [&](int d, int s) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kDepth - 1) * (NA + NB)) : "memory");
-#pragma unroll
-        for (int f = 0; f < NA; ++f) asm volatile("" : "+v"(av[d][f]));
-#pragma unroll
-        for (int f = 0; f < NB; ++f) asm volatile("" : "+v"(bv[d][f]));
-        const bool live = 4 * s + kq < E.K;
-#pragma unroll
-        for (int f = 0; f < NA; ++f) av[d][f] = live ? av[d][f] : 0.0;
-#pragma unroll
-        for (int fa = 0; fa < NA; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < NB; ++fb)
-                acc[fa * NB + fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[d][fa], bv[d][fb], acc[fa * NB + fb], 0, 0, 1);
-    };
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) load(d, d);
-    for (int s0 = 0; s0 < nsteps; s0 += kDepth) {
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d) {
-            mult(d, s0 + d);
-            load(d, s0 + d + kDepth);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (!ident) {
-#pragma unroll
-        for (int f = 0; f < NA; ++f)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pa[f][v] -= D.rbias;
-#pragma unroll
-        for (int f = 0; f < NB; ++f) pb[f] -= D.rbias;
-    }
-#pragma unroll
-    for (int f = 0; f < NA; ++f)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (16 * f + kq + 4 * v >= am) pa[f][v] = -1;
-#pragma unroll
-    for (int f = 0; f < NB; ++f)
-        if (16 * f + l15 >= bm) pb[f] = -1;
-    double* __restrict__ G = L + D.px;
-    // (the adds of the entry before this one are performed: they may have come from other lanes, under another row map)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int fa = 0; fa < NA; ++fa)
-#pragma unroll
-        for (int fb = 0; fb < NB; ++fb) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = swap ? pa[fa][v] : pb[fb], col = swap ? pb[fb] : pa[fa][v];
-                if (pa[fa][v] >= 0 && pb[fb] >= 0 && row >= col)
-                    unsafeAtomicAdd(&G[(int64_t)col * D.ld + row], acc[fa * NB + fb][v]);
-            }
-        }
-}
-
-#ifndef PARSY_THIN_WGS
-#define PARSY_THIN_WGS 2     // workgroups per compute unit the registers are budgeted for (3: spills)
-#endif
-__global__ __launch_bounds__(256, PARSY_THIN_WGS) void k_chol_thin(const SnDesc* __restrict__ sn, const int32_t* __restrict__ relpos,
-                                                      const WaveEntry* __restrict__ ents, const TileDesc* __restrict__ tasks,
-                                                      int ntasks, double* __restrict__ L) {
-    {
-        int agpr_hint = 0;
-        asm volatile("; accumulators in AGPRs %0" ::"a"(agpr_hint));
-    }
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (task >= ntasks) return;
-    const TileDesc td = tasks[task];
-    if (td.wp >= td.sp) return;
-    const SnDesc D = sn[td.sn];
-    for (int64_t e = td.wp; e < td.sp; ++e) {
-        const WaveEntry E = ents[e];
-        const int nfr = ((E.mn & 255) + 15) >> 4, nfc = (((E.mn >> 8) & 255) + 15) >> 4;
-        // the short side is the A operand; as in k_chol_big (A: the column window) where both would do
-        const bool swap = nfc > 2;
-        const int na = swap ? nfr : nfc, nb = swap ? nfc : nfr;
-#define PARSY_THIN_CASE(A, B) case (A) * 16 + (B): thin_piece<A, B>(E, swap, D, relpos, L, lane); break;
-        switch (na * 16 + nb) {
-            PARSY_THIN_CASE(1, 1) PARSY_THIN_CASE(1, 2) PARSY_THIN_CASE(1, 3) PARSY_THIN_CASE(1, 4)
-            PARSY_THIN_CASE(1, 5) PARSY_THIN_CASE(1, 6) PARSY_THIN_CASE(1, 7) PARSY_THIN_CASE(1, 8)
-            PARSY_THIN_CASE(2, 1) PARSY_THIN_CASE(2, 2) PARSY_THIN_CASE(2, 3) PARSY_THIN_CASE(2, 4)
-            default: break;   // (check_schedule: no such piece)
-        }
-#undef PARSY_THIN_CASE
-    }
-}
-
-void launch_chol_thin(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_chol_thin, dim3((count + 3) / 4), dim3(256), 0, stream, P.csn, P.relpos, P.big_entries,
-                       P.big_tasks + first, count, L);
-}
-
 #ifdef PARSY_DENSESTAMPS
 extern "C" void parsy_debug_densephase(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_densephase), sizeof(unsigned long long) * 16);

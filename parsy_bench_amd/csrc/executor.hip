@@ -251,7 +251,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             // enqueued so far whose targets can be at level t: those with a level field <= t (a PUSH writes
             // into EVERY level from its field upwards).  The side stream runs in order, so the latest of them
             // covers the earlier ones; PUSH(t - 1) / TILES(t + 1) (field t + 1) stay free to overlap.
-            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig || l.kind == kLaunchDense || l.kind == kLaunchThin)) {
+            if (overlap && (l.kind == kLaunchChain || l.kind == kLaunchBig || l.kind == kLaunchDense)) {
                 int lw = std::min<int>(l.level, (int)early_seen.size() - 1);
                 while (lw >= 0 && !early_seen[lw]) --lw;
                 if (lw >= 0) (void)hipStreamWaitEvent(stream, pl->ev_early_done[lw], 0);
@@ -263,14 +263,12 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchTiles:
             case kLaunchBig:
             case kLaunchDense:
-            case kLaunchThin:
                 if (on_side) {
                     record_levels_below(l.wait_level + 1);
                     (void)hipStreamWaitEvent(pl->side_stream,
                                              l.wait_level >= 0 ? pl->ev_level_done[l.wait_level] : pl->ev_init, 0);
                     if (l.kind == kLaunchBig) launch_chol_big(pl->dp, l.first, l.count, L, pl->side_stream);
                     else if (l.kind == kLaunchDense) launch_chol_dense(pl->dp, l.first, l.count, L, pl->side_stream);
-                    else if (l.kind == kLaunchThin) launch_chol_thin(pl->dp, l.first, l.count, L, pl->side_stream);
                     else launch_chol_tiles(pl->dp, l.first, l.count, L, pl->side_stream);
                     (void)hipEventRecord(pl->ev_early_done[l.level], pl->side_stream);
                     early_seen[l.level] = 1;
@@ -278,8 +276,6 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                     launch_chol_big(pl->dp, l.first, l.count, L, stream);
                 } else if (l.kind == kLaunchDense) {
                     launch_chol_dense(pl->dp, l.first, l.count, L, stream);
-                } else if (l.kind == kLaunchThin) {
-                    launch_chol_thin(pl->dp, l.first, l.count, L, stream);
                 } else {
                     launch_chol_tiles(pl->dp, l.first, l.count, L, stream);
                 }
@@ -401,7 +397,7 @@ int plan_collect_profile(parsy_plan* pl) {
         const int k = pl->pev_kind[i];
         if (pl->pev_ms.size() <= i) pl->pev_ms.resize(i + 1, 0.f);
         pl->pev_ms[i] = ms;
-        if (k >= 0 && k < kProfileKinds) {
+        if (k >= 0 && k < 10) {
             pl->kind_ms[k] += ms;
             pl->kind_launches[k] += 1;
         }

@@ -10,8 +10,6 @@
 #include "kernels.hpp"
 #include "schedule.hpp"
 
-constexpr int kProfileKinds = 12;   // = PARSY_PROFILE_KINDS (include/parsy_amd.h)
-
 struct parsy_plan {
     parsy::Schedule S;
     int device = -1;          // < 0: host schedule only
@@ -74,8 +72,8 @@ struct parsy_plan {
     std::vector<int> pev_count;     // per mark: work items of the launch
     std::vector<float> pev_ms;      // per mark: elapsed time in the last collected run (diagnostics)
     std::vector<double> level_ms;   // accumulated ms per (level << 1 | side)
-    double kind_ms[kProfileKinds] = {};
-    int kind_launches[kProfileKinds] = {};
+    double kind_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int kind_launches[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int profiled_runs = 0;
 };
 

@@ -58,7 +58,6 @@ void launch_chol_small(const DevicePattern& P, int first, int count, int lds_byt
 void launch_chol_big(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 void launch_chol_tiles(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
-void launch_chol_thin(const DevicePattern& P, int first, int count, double* L, hipStream_t stream);
 int chain_workgroups_per_cu();
 void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket, int epoch, bool rows, double* L,
                        hipStream_t stream);

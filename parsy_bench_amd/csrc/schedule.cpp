@@ -22,27 +22,6 @@ static int env_int(const char* name, int dflt) {
     return std::atoi(v);
 }
 
-// A thin block of mi x nj of a source's rows -> pieces of pr x pc fragments (16 rows each) that k_chol_thin's wave can
-// hold: at most kThinFrags accumulators, one side at most kThinShort fragments.  The shape that loads the fewest operand
-// fragments per k step over the block's pieces; ties: fewer pieces.
-static void thin_piece_shape(int mi, int nj, int& pr, int& pc) {
-    const int nfr = ceil_div(mi, 16), nfc = ceil_div(nj, 16);
-    int best = INT_MAX, best_pieces = INT_MAX;
-    pr = pc = 1;
-    for (int a = 1; a <= std::min(nfr, kThinFrags); ++a)
-        for (int b = 1; b <= std::min(nfc, kThinFrags); ++b) {
-            if (a * b > kThinFrags || std::min(a, b) > kThinShort) continue;
-            const int gr = ceil_div(nfr, a), gc = ceil_div(nfc, b);
-            const int loads = nfr * gc + nfc * gr;   // every row fragment once per piece column, and the other way round
-            if (loads < best || (loads == best && gr * gc < best_pieces)) {
-                best = loads;
-                best_pieces = gr * gc;
-                pr = a;
-                pc = b;
-            }
-        }
-}
-
 // Subtrees of the etree that consist of eligible supernodes only and cost at most `cap`, as large as
 // possible: subtree[s] = its subtree (numbered from the last root down) or -1.  `parent` must be a
 // postordered forest (parent[s] > s); otherwise no subtree is formed.
@@ -337,10 +316,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     struct Group { int32_t win, first, len; };
     std::vector<Group> groups, cgroups;
     std::vector<int64_t> cursor;
-    struct BigKeyed { int64_t launch_tile; WaveEntry e; int16_t sr, sc; int16_t thin; };  // launch id << 40 | global tile index
-    const int thin_stats = env_int("PARSY_THIN_STATS", 0);
-    double tstat[6][3] = {};
-    const int thin_max = S.solve_only ? 0 : env_int("PARSY_THIN_FILL", (int)(kThinMaxFill * 100 + 0.5)) * kBigTile * kBigTile / 100;
+    struct BigKeyed { int64_t launch_tile; WaveEntry e; int16_t sr, sc; };  // launch id << 40 | global tile index
     std::vector<BigKeyed> bigk;
     std::vector<int64_t> big_tile0(nc + 1, 0);  // first 128x128 tile index of every tiled piece
     // Edge of a BIG task's super-tile in 128 x 128 tiles, rows x columns, per launch (source level, kind).  A launch
@@ -501,56 +477,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             make_groups(kBigTile * sr, groups);
             if (sc == sr) cgroups = groups;
             else make_groups(kBigTile * sc, cgroups);
-            if (thin_stats) {   // TEMP: what merged thin regions would load
-                const double ks = ceil_div(U.K, 4);
-                const int lim = thin_stats;
-                for (const Group& gr : groups) {
-                    // per-tile blocks of this row group
-                    for (const Group& gc : cgroups) {
-                        if (gc.first >= U.n1) break;
-                        const int njt = std::min(gc.len, U.n1 - gc.first);
-                        if ((int64_t)(gr.win + 1) * sr * kBigTile - 1 < (int64_t)gc.win * sc * kBigTile) continue;
-                        for (int cb = 0; cb < njt; cb += kBigTile)
-                            for (int rb = 0; rb < gr.len; rb += kBigTile) {
-                                const int mi = std::min(kBigTile, gr.len - rb), nj = std::min(kBigTile, njt - cb);
-                                if (gr.first + rb + mi - 1 < gc.first + cb) continue;
-                                const bool rowthin = gr.len <= lim, colthin = !rowthin && njt <= lim;
-                                int pr, pc;
-                                thin_piece_shape(mi, nj, pr, pc);
-                                const int nfr = ceil_div(mi, 16), nfc = ceil_div(nj, 16);
-                                const double loads = ((double)nfr * ceil_div(nfc, pc) + (double)nfc * ceil_div(nfr, pr)) * ks;
-                                const double mf = (double)nfr * nfc * ks;
-                                const int cls = rowthin ? 0 : colthin ? 1 : (mi * nj <= thin_max ? 2 : 3);
-                                tstat[cls][0] += loads; tstat[cls][1] += mf; tstat[cls][2] += 1;
-                            }
-                    }
-                    if (gr.len <= lim) {
-                        const int cols = std::min(U.n1, gr.first + gr.len);
-                        if (cols > 0) {
-                            const int nfr = ceil_div(gr.len, 16), ncf = ceil_div(cols, 16);
-                            const int per = kThinFrags / nfr;
-                            tstat[4][0] += ((double)nfr * ceil_div(ncf, per) + ncf) * ks;
-                            tstat[4][1] += (double)nfr * ncf * ks;
-                            tstat[4][2] += ceil_div(ncf, per);
-                        }
-                    }
-                }
-                for (const Group& gc : cgroups) {
-                    if (gc.first >= U.n1) break;
-                    const int njt = std::min(gc.len, U.n1 - gc.first);
-                    if (njt > lim) continue;
-                    int rows = 0;
-                    for (const Group& gr : groups)
-                        if (gr.len > lim && !((int64_t)(gr.win + 1) * sr * kBigTile - 1 < (int64_t)gc.win * sc * kBigTile))
-                            rows += gr.first + gr.len > gc.first ? std::min(gr.len, gr.first + gr.len - gc.first) : 0;
-                    if (rows <= 0) continue;
-                    const int nfc = ceil_div(njt, 16), nrf = ceil_div(rows, 16);
-                    const int per = kThinFrags / nfc;
-                    tstat[5][0] += ((double)nfc * ceil_div(nrf, per) + nrf) * ks;
-                    tstat[5][1] += (double)nfc * nrf * ks;
-                    tstat[5][2] += ceil_div(nrf, per);
-                }
-            }
             for (const Group& gc : cgroups) {
                 if (gc.first >= U.n1) break;
                 const int njt = std::min(gc.len, U.n1 - gc.first);
@@ -563,25 +489,10 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                             const int mi = std::min(kBigTile, gr.len - rb), nj = std::min(kBigTile, njt - cb);
                             const int ia = gr.first + rb, ja = gc.first + cb;
                             if (ia + mi - 1 < ja) continue;   // block strictly above the diagonal
-                            if (mi * nj <= thin_max) {
-                                // THIN: the block in pieces of pr x pc 16-row fragments of the source's rows, one wave each
-                                int pr, pc;
-                                thin_piece_shape(mi, nj, pr, pc);
-                                for (int c0 = 0; c0 < nj; c0 += 16 * pc)
-                                    for (int r0 = 0; r0 < mi; r0 += 16 * pr) {
-                                        const int pm = std::min(16 * pr, mi - r0), pn = std::min(16 * pc, nj - c0);
-                                        if (ia + r0 + pm - 1 < ja + c0) continue;
-                                        bigk.push_back(BigKeyed{(launch << 40) | tile,
-                                                                WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, ia + r0, ja + c0,
-                                                                          pm | (pn << 8) | ((U.rel < 0) << 16)},
-                                                                (int16_t)sr, (int16_t)sc, 1});
-                                    }
-                                continue;
-                            }
                             bigk.push_back(BigKeyed{(launch << 40) | tile,
                                                     WaveEntry{U.src, (int32_t)std::max<int64_t>(U.rel, 0), U.ld, U.K, ia, ja,
                                                               mi | (nj << 8) | ((U.rel < 0) << 16)},
-                                                    (int16_t)sr, (int16_t)sc, 0});
+                                                    (int16_t)sr, (int16_t)sc});
                         }
                 }
             }
@@ -626,13 +537,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             }
         }
     }
-    if (thin_stats) {
-        const char* nm[6] = {"blocks of thin row groups (per tile)", "blocks of thin col groups (per tile)", "other thin blocks", "other blocks",
-                             "row groups merged", "col groups merged"};
-        for (int q = 0; q < 6; ++q)
-            std::fprintf(stderr, "thin_stats %-40s loads %.3e (%.1f GB) mfma %.3e pieces/blocks %.3e\n", nm[q], tstat[q][0], tstat[q][0] * 512 / 1e9,
-                         tstat[q][1], tstat[q][2]);
-    }
     // ---- BIG tasks: one per (launch, tile), entries in update order (stable sort)
     if (!bigk.empty()) {
         std::stable_sort(bigk.begin(), bigk.end(),
@@ -654,7 +558,6 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             return (double)ceil_div(E.K, 4) * ceil_div(mi, 16) * ceil_div(nj, 16);
         };
         for (const BigKeyed& b : bigk) {
-            if (b.thin) continue;   // (k_chol_thin's: not part of the dense / ragged decision)
             const size_t l = (size_t)(b.launch_tile >> 40);
             lprod[l] += products_of(b.e);
             if (is_full(b.e)) ldense[l] += products_of(b.e);
@@ -701,7 +604,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const int lmode = launch_dense[(size_t)launch];
             if (lmode)
                 for (size_t q = i; q < j; ++q)
-                    if (!bigk[q].thin && is_dense(bigk[q].e, lmode)) {
+                    if (is_dense(bigk[q].e, lmode)) {
                         S.big_entries[at++] = bigk[q].e;
                         dchunks += ceil_div(bigk[q].e.K, kDenseChunk);
                         dweight += ceil_div(bigk[q].e.K, 16) + 2;
@@ -715,23 +618,10 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                     }
             const size_t mid = at;
             for (size_t q = i; q < j; ++q)
-                if (!bigk[q].thin && !is_dense(bigk[q].e, lmode)) {
+                if (!is_dense(bigk[q].e, lmode)) {
                     S.big_entries[at++] = bigk[q].e;
                     weight += ceil_div(bigk[q].e.K, 16) + 4;
                 }
-            const size_t thin0 = at;
-            int64_t tweight = 0;
-            for (size_t q = i; q < j; ++q)
-                if (bigk[q].thin) {
-                    const WaveEntry& E = bigk[q].e;
-                    S.big_entries[at++] = E;
-                    tweight += ceil_div(E.K, 4) + 8;
-                    const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-                    double pairs = 0;
-                    for (int jj = E.ja; jj < E.ja + nj; ++jj) pairs += std::max(0, E.ia + mi - std::max(E.ia, jj));
-                    S.thin_flops += 2.0 * E.K * pairs;
-                }
-            S.n_thin_entries += (int64_t)(j - thin0);
             S.n_dense_entries += (int64_t)(mid - i);
             while (t + 1 < nc && big_tile0[t + 1] <= tile) ++t;   // tiles ascend within a launch ...
             if (tile < big_tile0[t]) {                             // ... and start over with the next one
@@ -745,8 +635,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                                                   (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
                                                   (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), bigk[i].sr, bigk[i].sc,
                                                   (int64_t)mid, (int32_t)std::min<int64_t>(dweight, INT32_MAX),
-                                                  (int32_t)std::min<int64_t>(dchunks, INT32_MAX), (int64_t)thin0,
-                                                  (int32_t)std::min<int64_t>(tweight, INT32_MAX)});
+                                                  (int32_t)std::min<int64_t>(dchunks, INT32_MAX)});
             i = j;
         }
     }
@@ -805,20 +694,16 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     // which return at once).  Small launches keep the plain heaviest-first order.  PARSY_BIG_GROUP=g
     // (0: never group).
     const int big_group = env_int("PARSY_BIG_GROUP", kBigGroup);
-    // (part 1: the tasks' dense parts for k_chol_dense -- TileDesc::part = its 8-wide k chunks --, 0: their ragged ones,
-    // 2: their thin ones for k_chol_thin -- a task per WAVE there, in plain heaviest-first order)
-    auto emit_big = [&](const std::vector<const Schedule::BigTask*>& all, Launch L, int part) {
-        const bool dense = part == 1;
+    // (dense: the tasks' dense parts for k_chol_dense -- TileDesc::part = its 8-wide k chunks --, else their ragged rests)
+    auto emit_big = [&](const std::vector<const Schedule::BigTask*>& all, Launch L, bool dense) {
         std::vector<const Schedule::BigTask*> v;
         for (const Schedule::BigTask* b : all)
-            if (part == 1 ? b->em > b->e0 : part == 2 ? b->e1 > b->et : b->et > b->em) v.push_back(b);
+            if (dense ? b->em > b->e0 : b->e1 > b->em) v.push_back(b);
         if (v.empty()) return L;
         L.first = (int32_t)S.big_tasks.size();
-        auto wt = [part](const Schedule::BigTask* b) { return part == 1 ? b->dweight : part == 2 ? b->tweight : b->weight; };
-        auto desc = [part](const Schedule::BigTask* b) {
-            return part == 1   ? TileDesc{b->sn, b->row0, b->col0, b->dchunks, b->e0, b->em}
-                   : part == 2 ? TileDesc{b->sn, b->row0, b->col0, b->tweight, b->et, b->e1}
-                               : TileDesc{b->sn, b->row0, b->col0, 0, b->em, b->et};
+        auto wt = [dense](const Schedule::BigTask* b) { return dense ? b->dweight : b->weight; };
+        auto desc = [dense](const Schedule::BigTask* b) {
+            return dense ? TileDesc{b->sn, b->row0, b->col0, b->dchunks, b->e0, b->em} : TileDesc{b->sn, b->row0, b->col0, 0, b->em, b->e1};
         };
         auto by_weight = [&](const Schedule::BigTask* a, const Schedule::BigTask* b) { return wt(a) > wt(b); };
         // group edge: as large as leaves every XCD at least kBigGroupsPerXcd groups to balance with
@@ -827,7 +712,6 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         const int per_task = v[0]->sr * v[0]->sc;
         while (g > 1 && (int64_t)v.size() * per_task < (int64_t)8 * kBigGroupsPerXcd * g * g) g /= 2;
         if (g < std::max(v[0]->sr, v[0]->sc)) g = 1;
-        if (part == 2 && env_int("PARSY_THIN_GROUP", 1) == 0) g = 1;
         if (g <= 1) {
             std::stable_sort(v.begin(), v.end(), by_weight);
             for (const Schedule::BigTask* b : v) S.big_tasks.push_back(desc(b));
@@ -888,20 +772,17 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
                 load[x] += G.weight;
             }
         }
-        // (a THIN workgroup holds four tasks, one per wave: the sequences are dealt four tasks at a time)
-        const size_t per_wg = part == 2 ? 4 : 1;
         size_t len = 0;
-        for (int x = 0; x < 8; ++x) len = std::max(len, (seq[x].size() + per_wg - 1) / per_wg);
+        for (int x = 0; x < 8; ++x) len = std::max(len, seq[x].size());
         for (size_t s = 0; s < len; ++s)
-            for (int x = 0; x < 8; ++x)
-                for (size_t q = s * per_wg; q < (s + 1) * per_wg; ++q) {
-                    if (q < seq[x].size()) {
-                        S.big_tasks.push_back(desc(seq[x][q]));
-                    } else {
-                        S.big_tasks.push_back(TileDesc{0, 0, 0, 0, 0, 0});  // padding: no entries
-                    }
+            for (int x = 0; x < 8; ++x) {
+                if (s < seq[x].size()) {
+                    S.big_tasks.push_back(desc(seq[x][s]));
+                } else {
+                    S.big_tasks.push_back(TileDesc{0, 0, 0, 0, 0, 0});  // padding: no entries
                 }
-        L.count = (int32_t)(8 * len * per_wg);
+            }
+        L.count = (int32_t)(8 * len);
         return L;
     };
     // The active supernodes of every subtree in index order (descendants first), subtrees by falling cost:
@@ -973,20 +854,16 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         // ---- PUSH(lev): this level's wide supernodes update everything at least two levels up (side
         // stream, once the level is complete); NEXT(lev - 1): the level below updates this level's tiles
         if (lev + 2 < S.cnlevels) {
-            Launch Ld = emit_big(big_push[lev], Launch{kLaunchDense, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, 1);
+            Launch Ld = emit_big(big_push[lev], Launch{kLaunchDense, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, true);
             if (Ld.count > 0) early_launches.push_back(Ld);
-            Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, 0);
+            Launch Lp = emit_big(big_push[lev], Launch{kLaunchBig, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, false);
             if (Lp.count > 0) early_launches.push_back(Lp);
-            Launch Lt = emit_big(big_push[lev], Launch{kLaunchThin, 0, 0, lev + 2, 0, 0, 0, 1, lev, 1}, 2);
-            if (Lt.count > 0) early_launches.push_back(Lt);
         }
         if (lev > 0) {
-            Launch Ld = emit_big(big_next[lev - 1], Launch{kLaunchDense, 0, 0, lev, 0, 0, 0, 0, -1, 0}, 1);
+            Launch Ld = emit_big(big_next[lev - 1], Launch{kLaunchDense, 0, 0, lev, 0, 0, 0, 0, -1, 0}, true);
             if (Ld.count > 0) S.chol.push_back(Ld);
-            Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0}, 0);
+            Launch Ln = emit_big(big_next[lev - 1], Launch{kLaunchBig, 0, 0, lev, 0, 0, 0, 0, -1, 0}, false);
             if (Ln.count > 0) S.chol.push_back(Ln);
-            Launch Lt = emit_big(big_next[lev - 1], Launch{kLaunchThin, 0, 0, lev, 0, 0, 0, 0, -1, 0}, 2);
-            if (Lt.count > 0) S.chol.push_back(Lt);
         }
         if (!bigs.empty()) {
             // ---- TILES: the early part of the external updates, longest streams first ------
@@ -1680,12 +1557,12 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
         // active target exactly once, under its (source level, kind), the dense part in a launch enqueued BEFORE the
         // one that holds the ragged part; padding tasks (XCD sequences of unequal length) have no entries
         std::vector<int64_t> starts;
-        std::vector<int64_t> dense_pos(S.big_all.size(), -1), ragged_pos(S.big_all.size(), -1), thin_pos(S.big_all.size(), -1);
+        std::vector<int64_t> dense_pos(S.big_all.size(), -1), ragged_pos(S.big_all.size(), -1);
         int64_t li = 0;
         for (const Launch& l : S.chol) {
             ++li;
-            if (l.kind != kLaunchBig && l.kind != kLaunchDense && l.kind != kLaunchThin) continue;
-            const bool dense = l.kind == kLaunchDense, thin = l.kind == kLaunchThin;
+            if (l.kind != kLaunchBig && l.kind != kLaunchDense) continue;
+            const bool dense = l.kind == kLaunchDense;
             const bool side = l.side != 0;
             auto find_task = [&](int64_t e) -> const Schedule::BigTask* {   // the task whose entry range holds big_entries[e]
                 auto it = std::upper_bound(S.big_all.begin(), S.big_all.end(), e,
@@ -1704,15 +1581,14 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
                     continue;
                 }
                 const Schedule::BigTask* it = find_task(td.wp);
-                const bool ok = it && (dense  ? (it->e0 == td.wp && it->em == td.sp && td.part == it->dchunks)
-                                       : thin ? (it->et == td.wp && it->e1 == td.sp)
-                                              : (it->em == td.wp && it->et == td.sp));
+                const bool ok = it && (dense ? (it->e0 == td.wp && it->em == td.sp && td.part == it->dchunks)
+                                             : (it->em == td.wp && it->e1 == td.sp));
                 if (!ok || it->sn != td.sn || it->row0 != td.row0 || it->col0 != td.col0) {
                     fail("BIG launch task " + std::to_string(q) + " is not a task of the plan");
                     continue;
                 }
                 if (!right_launch(*it)) fail("BIG launch task " + std::to_string(q) + " runs in the launch of another source level");
-                (dense ? dense_pos : thin ? thin_pos : ragged_pos)[(size_t)(it - S.big_all.data())] = li;
+                (dense ? dense_pos : ragged_pos)[(size_t)(it - S.big_all.data())] = li;
                 starts.push_back(td.wp);
             }
         }
@@ -1721,13 +1597,7 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
         int64_t want = 0;
         for (size_t k = 0; k < S.big_all.size(); ++k) {
             const Schedule::BigTask& b = S.big_all[k];
-            if (b.em < b.e0 || b.et < b.em || b.et > b.e1) fail("BIG task " + std::to_string(k) + " has a bad dense / ragged / thin split");
-            for (int64_t e = b.et; e < b.e1; ++e) {
-                const WaveEntry& E = S.big_entries[(size_t)e];
-                const int tfr = ceil_div(E.mn & 255, 16), tfc = ceil_div((E.mn >> 8) & 255, 16);
-                if (tfr * tfc > kThinFrags || std::min(tfr, tfc) > kThinShort)
-                    fail("BIG entry " + std::to_string(e) + " is filed as thin but is larger than a wave's piece");
-            }
+            if (b.em < b.e0 || b.em > b.e1) fail("BIG task " + std::to_string(k) + " has a bad dense / ragged split");
             int64_t dch = 0;
             for (int64_t e = b.e0; e < b.em; ++e) {
                 const WaveEntry& E = S.big_entries[(size_t)e];
@@ -1736,11 +1606,9 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             }
             if (dch != b.dchunks) fail("BIG task " + std::to_string(k) + " has a wrong dense chunk count");
             if (!S.active_piece[b.sn]) continue;
-            want += (b.em > b.e0) + (b.et > b.em) + (b.e1 > b.et);
-            if (b.em > b.e0 && b.et > b.em && !(dense_pos[k] > 0 && ragged_pos[k] > dense_pos[k]))
+            want += (b.em > b.e0) + (b.e1 > b.em);
+            if (b.em > b.e0 && b.e1 > b.em && !(dense_pos[k] > 0 && ragged_pos[k] > dense_pos[k]))
                 fail("BIG task " + std::to_string(k) + ": the ragged part is not launched after the dense part");
-            if (b.e1 > b.et && !(thin_pos[k] > std::max(dense_pos[k], ragged_pos[k])))
-                fail("BIG task " + std::to_string(k) + ": the thin part is not launched after the other parts");
         }
         if ((int64_t)starts.size() != want)
             fail("BIG launches hold " + std::to_string(starts.size()) + " task parts, the active targets have " + std::to_string(want));

@@ -118,9 +118,8 @@ enum LaunchKind : int32_t {
                             // right before the level's chain launch
     kLaunchSolveSmall = 5, kLaunchSolvePanel = 6, kLaunchSolveFixup = 7, kLaunchBackBlock = 8,
     kLaunchDense = 9,   // the dense entries of a BIG launch's tasks (k_chol_dense), right before that launch's ragged rest
-    kLaunchThin = 10,   // the thin entries of a BIG launch's tasks (k_chol_thin: one wave per task), right after it
 };
-inline bool is_chol_launch(int kind) { return (kind >= 0 && kind <= kLaunchBig) || kind == kLaunchDense || kind == kLaunchThin; }
+inline bool is_chol_launch(int kind) { return (kind >= 0 && kind <= kLaunchBig) || kind == kLaunchDense; }
 
 struct Launch {
     int32_t kind;
@@ -159,9 +158,6 @@ constexpr int kDenseChunk = 8;             // k extent of k_chol_dense's chunks 
 constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense when at least this share of its products is dense
                                            // (PARSY_BIG_DENSE=0: never, 2: wherever there is a dense entry)
 constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
-constexpr double kThinMaxFill = 0.25;      // a block whose windows hold at most this share of 128 x 128 goes to k_chol_thin (PARSY_THIN_FILL,
-                                           // percent; 0: never)
-constexpr int kThinFrags = 8, kThinShort = 2;   // ... in pieces of at most 8 fragments of 16 x 16, at most 2 along one side
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
@@ -222,23 +218,18 @@ struct Schedule {
     // and launch; launches go by the level of the SOURCE: NEXT(s) = targets one level up (main stream,
     // before their chain), PUSH(s) = targets further up (side stream, as soon as level s is complete).
     std::vector<WaveEntry> big_entries;   // per task: (source, row window, column window), sources in update order
-    // A task's entries [e0, e1): first its DENSE ones [e0, em) -- full 128 x 128 blocks of a source's rows, for
-    // k_chol_dense (em = e0 where the launch does not use that kernel) --, then the ragged ones [em, et) for k_chol_big,
-    // then the THIN ones [et, e1) for k_chol_thin: blocks whose windows hold at most kThinMaxFill of 128 x 128, cut into
-    // pieces of at most kThinFrags fragments that ONE wave multiplies straight from the panel (a chunk of k_chol_big costs
-    // the same whatever its window holds); each part in update order.  dchunks: 8-wide k chunks of the dense part.
+    // A task's entries [e0, e1): first its DENSE ones [e0, em) -- full 128 x 128 blocks of a source's rows entirely on
+    // or below the target's diagonal, for k_chol_dense (em = e0 where the launch does not use that kernel) -- then the
+    // ragged rest [em, e1) for k_chol_big; each part in update order.  dchunks: 8-wide k chunks of the dense part.
     struct BigTask { int32_t sn, row0, col0, weight; int64_t e0, e1; int32_t src_level, next;
                      int32_t sr, sc;      // sr x sc: the super-tile's edge in 128 x 128 tiles
-                     int64_t em; int32_t dweight, dchunks;
-                     int64_t et; int32_t tweight; };
+                     int64_t em; int32_t dweight, dchunks; };
     std::vector<BigTask> big_all;         // every task, grouped by (src_level, next)
     std::vector<TileDesc> big_tasks;      // tasks of the launches (active targets): k_chol_big: wp, sp = the ragged part [em, e1) of a
                                           // task; k_chol_dense: its dense part [e0, em), part = its 8-wide k chunks
     double big_flops = 0;                 // flops of the BIG launches (dense + ragged entries)
     double dense_flops = 0;               // ... of which through k_chol_dense
     int64_t n_dense_entries = 0;
-    double thin_flops = 0;                // ... and through k_chol_thin
-    int64_t n_thin_entries = 0;
     std::vector<Launch> chol;
 
     // solve launch data

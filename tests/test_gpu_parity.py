@@ -719,7 +719,6 @@ def test_factor_with_super_tiles(api, oracle, monkeypatch, name, piece, mink, su
     monkeypatch.setenv("PARSY_BIG_SUPER", "1")
     # (which entries are dense blocks depends on the windows: the dense / ragged order of sums is tested below)
     monkeypatch.setenv("PARSY_BIG_DENSE", "0")
-    monkeypatch.setenv("PARSY_THIN_FILL", "0")   # (... and so does which are thin)
     plan1 = api.Plan(sym, 0)
     lv1, _ = plan1.factor(sym.A2x)
     assert plan1.status() == 0
@@ -779,7 +778,6 @@ def test_factor_with_dense_launches(api, oracle, monkeypatch, name, piece, mink,
     if sup != "0":
         monkeypatch.setenv("PARSY_BIG_SUPER", sup)
     monkeypatch.setenv("PARSY_BIG_DENSE", "0")
-    monkeypatch.setenv("PARSY_THIN_FILL", "0")   # (the thin blocks have a test of their own below)
     plan0 = api.Plan(sym, 0)
     assert plan0.info["dense_entries"] == 0 and plan0.info["dense_tasks"] == 0
     lv0, _ = plan0.factor(sym.A2x)
@@ -798,56 +796,6 @@ def test_factor_with_dense_launches(api, oracle, monkeypatch, name, piece, mink,
     assert ok
     scale = np.abs(lo).max()
     assert np.abs(lv - lo).max() <= FACTOR_TOL * scale, f"{name}: dense launches vs oracle {np.abs(lv - lo).max() / scale:.3e}"
-    assert np.abs(lv - lv0).max() <= FACTOR_TOL * scale
-    for _ in range(2):
-        lv2, _ = plan.factor(sym.A2x)
-        assert np.array_equal(lv, lv2)   # fixed summation order: bitwise reproducible
-    # padding above the diagonal of every diagonal block stays exactly zero
-    for sn in range(sym.nsuper):
-        c0, c1 = int(sym.super[sn]), int(sym.super[sn + 1])
-        r = int(sym.i_ptr[c1] - sym.i_ptr[c0]) if c1 < sym.n else int(sym.ssize - sym.i_ptr[c0])
-        base = int(sym.p[c0])
-        for c in range(1, min(c1 - c0, 8)):
-            assert not lv[base + c * r: base + c * r + c].any()
-
-
-# ---------------------------------------------------------------------------
-# THIN launches: the BIG entries whose windows hold a small share of 128 x 128, cut into pieces that one wave of
-# k_chol_thin multiplies straight from the panel (PARSY_THIN_FILL = the share in percent; 100 with PARSY_BIG_DENSE=0:
-# EVERY BIG entry goes that way -- all piece shapes, both orientations, ragged windows, K tails, identity maps).
-# ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name,piece,mink,sup,fill,dense", [("mid3d", 128, 16, "0", 25, 1), ("lap30", 128, 32, "0", 25, 1),
-                                                            ("lap30", 256, 64, "2", 50, 1), ("nd24k", 0, 64, "0", 25, 1),
-                                                            ("small3d", 128, 16, "0", 100, 0), ("mid3d", 128, 16, "0", 100, 0),
-                                                            ("mid3d", 0, 32, "2", 100, 0), ("lap30", 128, 32, "0", 100, 0),
-                                                            ("ex15", 128, 16, "0", 100, 0), ("nd24k", 200, 24, "2", 100, 0),
-                                                            ("nd24k", 200, 24, "0", 100, 1)])
-def test_factor_with_thin_launches(api, oracle, monkeypatch, name, piece, mink, sup, fill, dense):
-    from parsy_bench_amd import inspector as I
-    A, perm, sym = problem(name)
-    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
-    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
-    if sup != "0":
-        monkeypatch.setenv("PARSY_BIG_SUPER", sup)
-    monkeypatch.setenv("PARSY_BIG_DENSE", str(dense))
-    monkeypatch.setenv("PARSY_THIN_FILL", "0")
-    plan0 = api.Plan(sym, 0)
-    assert plan0.info["thin_entries"] == 0 and plan0.info["thin_tasks"] == 0 and plan0.info["thin_flops"] == 0
-    lv0, _ = plan0.factor(sym.A2x)
-    assert plan0.status() == 0
-    monkeypatch.setenv("PARSY_THIN_FILL", str(fill))
-    plan = api.Plan(sym, 0)
-    info = plan.info
-    assert info["thin_entries"] > 0 and info["thin_tasks"] > 0 and 0 < info["thin_flops"] <= info["big_flops"]
-    if fill == 100 and dense == 0:
-        assert info["thin_flops"] == info["big_flops"]
-    assert info["big_flops"] == plan0.info["big_flops"] and plan.check() == 0
-    lv, _ = plan.factor(sym.A2x)
-    assert plan.status() == 0
-    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
-    assert ok
-    scale = np.abs(lo).max()
-    assert np.abs(lv - lo).max() <= FACTOR_TOL * scale, f"{name}: thin launches vs oracle {np.abs(lv - lo).max() / scale:.3e}"
     assert np.abs(lv - lv0).max() <= FACTOR_TOL * scale
     for _ in range(2):
         lv2, _ = plan.factor(sym.A2x)
