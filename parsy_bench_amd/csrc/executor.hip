@@ -59,6 +59,13 @@ int plan_upload_launches(parsy_plan* pl) {
         pl->dp.bpart = nullptr;
     }
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
+    if (upload(pl, S.one_sn, pl->dp.one_sn, true)) return -1;
+    if (upload(pl, S.one_slot0, pl->dp.one_slot0, true)) return -1;
+    if (upload(pl, S.one_pull_ptr, pl->dp.one_pull_ptr, true)) return -1;
+    if (upload(pl, S.one_pull_slot, pl->dp.one_pull_slot, true)) return -1;
+    if (upload(pl, S.one_pull_pos, pl->dp.one_pull_pos, true)) return -1;
+    if (upload(pl, S.one_bblocks, pl->dp.one_bblocks, true)) return -1;
+    if (upload(pl, S.one_branges, pl->dp.one_branges, true)) return -1;
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
@@ -180,6 +187,8 @@ void plan_free(parsy_plan* pl) {
         for (void* d : pl->owned) (void)hipFree(d);
         for (void* d : pl->launch_owned) (void)hipFree(d);
         if (pl->xscratch) (void)hipFree(pl->xscratch);
+        if (pl->one_y) (void)hipFree(pl->one_y);
+        if (pl->one_state) (void)hipFree(pl->one_state);
         if (pl->xt) (void)hipFree(pl->xt);
         if (pl->dinv) (void)hipFree(pl->dinv);
         if (pl->dp.bpart) (void)hipFree(pl->dp.bpart);
@@ -327,7 +336,41 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
 // Start of a forward / backward solve: a fresh epoch range for its passes (flags of earlier solves go
 // stale; on wrap-around the flags are cleared first, so that no old value can pass for a new one), its own
 // status word and ticket counters zeroed.
+// (one: a ONE-launch solve -- its counters follow the status word; no flags, epochs or chain tickets)
+static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs) {
+    return pl->S.solve_one && nrhs <= kOneMaxRhs;
+}
+
+// The buffers of the ONE-launch solves, made by the first of them: per direction two hand-off buffers (forward: one
+// slot per entry of the row-id array, backward: one per unknown; kOneMaxRhs right-hand sides), all armed, and two
+// {status, ticket} pairs, zero.  Every such solve then works through buffer / pair (its direction's count & 1) and
+// leaves the other one armed and zeroed for the next solve of its kind (k_solve_one, k_bsolve_block<.., ONE>) -- one
+// enqueue per solve, no memset.
+static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*& y, double*& y_next, int*& st, int*& st_next) {
+    const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * kOneMaxRhs, lb = (size_t)pl->S.n * kOneMaxRhs;
+    if (!pl->one_y) {
+        PARSY_HIP(hipMalloc((void**)&pl->one_y, 2 * (lf + lb) * sizeof(double)));
+        PARSY_HIP(hipMalloc((void**)&pl->one_state, 8 * sizeof(int)));
+        pl->device_bytes += (int64_t)(2 * (lf + lb) * sizeof(double) + 8 * sizeof(int));
+        PARSY_HIP(solve_arm_handoff(pl->one_y, (int64_t)(2 * (lf + lb)), stream));
+        PARSY_HIP(hipMemsetAsync(pl->one_state, 0, 8 * sizeof(int), stream));
+        pl->one_calls[0] = pl->one_calls[1] = 0;
+    }
+    const unsigned k = pl->one_calls[backward]++ & 1u;
+    double* base = backward ? pl->one_y + 2 * lf : pl->one_y;
+    const size_t len = backward ? lb : lf;
+    y = base + k * len;
+    y_next = base + (k ^ 1u) * len;
+    st = pl->one_state + (backward ? 4 : 0) + 2 * k;
+    st_next = pl->one_state + (backward ? 4 : 0) + 2 * (k ^ 1u);
+    pl->solve_status_word = st;
+    const char* stall = std::getenv("PARSY_DEBUG_SOLVE_STALL");
+    pl->solve_wait_bias = (stall && stall[0] == '1') ? (1 << 20) : 0;
+    return 0;
+}
+
 static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream) {
+    pl->solve_status_word = nullptr;
     if (pl->epoch > INT_MAX - 2 * passes - 2) {
         PARSY_HIP(hipMemsetAsync(pl->dp.flags, 0, (size_t)pl->n_flags * sizeof(int), stream));
         PARSY_HIP(hipMemsetAsync(pl->dp.tflags, 0, 2 * (size_t)std::max(pl->dp.n_tflags, 1) * sizeof(int), stream));
@@ -354,6 +397,21 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         return -1;
     }
     const int64_t need = (int64_t)ldx * nrhs;
+    if (solve_takes_one_launch(pl, nrhs)) {
+        // a small plan: the whole solve is one launch (k_bsolve_block<.., ONE>)
+        double *y = nullptr, *y_next = nullptr;
+        int *st = nullptr, *st_next = nullptr;
+        if (one_begin(pl, true, stream, y, y_next, st, st_next) != 0) return -1;
+        PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+        run_begin(pl);
+        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->S.nsuper);
+        launch_bsolve_one(pl->dp, pl->S.nsuper, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
+        run_end(pl, stream);
+        PARSY_HIP(hipGetLastError());
+        PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+        pl->have_s = true;
+        return 0;
+    }
     // one epoch per pass of right-hand sides (what the chain launches publish / wait for)
     const int passes = (nrhs + 3) / 4;
     if (solve_begin(pl, passes, stream) != 0) return -1;
@@ -518,6 +576,21 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     if (nrhs < 1 || ldx < pl->S.n) {
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
+    }
+    if (solve_takes_one_launch(pl, nrhs)) {
+        // a small plan: the whole solve is one launch (k_solve_one)
+        double *y = nullptr, *y_next = nullptr;
+        int *st = nullptr, *st_next = nullptr;
+        if (one_begin(pl, false, stream, y, y_next, st, st_next) != 0) return -1;
+        PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+        run_begin(pl);
+        profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
+        launch_solve_one(pl->dp, (int)pl->S.one_sn.size(), std::max<int64_t>(pl->S.one_nslots, 1), d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
+        run_end(pl, stream);
+        PARSY_HIP(hipGetLastError());
+        PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+        pl->have_s = true;
+        return 0;
     }
     // one epoch per pass of right-hand sides (what the chain kernel publishes / waits for)
     const int passes = (nrhs + 7) / 8;

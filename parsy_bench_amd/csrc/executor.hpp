@@ -30,6 +30,12 @@ struct parsy_plan {
     double* dinv = nullptr;       // inverse 64x64 diagonal blocks of the wide supernodes (solve)
     double* xscratch = nullptr;
     int64_t xscratch_len = 0;
+    // ONE-launch solves (Schedule::solve_one): per direction two hand-off buffers (a solve works through the one its
+    // predecessor armed and arms the other: no memset between solves) and two {status, ticket} pairs, used in turn
+    double* one_y = nullptr;
+    int* one_state = nullptr;
+    unsigned one_calls[2] = {0, 0};   // forward, backward
+    const int* solve_status_word = nullptr;   // where the last solve left its status (null: dp.sinfo)
 
     // buffers of the host-convenience calls
     double* h_values_dev = nullptr;

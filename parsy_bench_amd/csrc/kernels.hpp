@@ -48,6 +48,14 @@ struct DevicePattern {           // device copies of Schedule arrays
     int* sinfo = nullptr;        // status of the last solve: 0 ok, < 0 a hand-off wait timed out (own word: a solve
                                  // never touches the factorization's status)
     int* stickets = nullptr;     // one counter per chain launch of the forward / backward solve
+    // ONE-launch solves of small plans (Schedule::solve_one)
+    const SnDesc* one_sn = nullptr;         // forward: the block columns (<= 64 columns each) in ticket order
+    const int64_t* one_slot0 = nullptr;     // ... and the first hand-off slot of each
+    const int32_t* one_pull_ptr = nullptr;  // forward: per supernode its gather list [ptr[t], ptr[t + 1]) of
+    const int32_t* one_pull_slot = nullptr; // ... (slot of the hand-off buffer,
+    const int32_t* one_pull_pos = nullptr;  //      column of the supernode)
+    const PanelDesc* one_bblocks = nullptr; // backward: every supernode's block columns, last one first, from the root down
+    const int32_t* one_branges = nullptr;   // ... (begin, end) per supernode in that order
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -64,6 +72,12 @@ void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket,
 
 void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
                         double* x, int nrhs, int ldx, int ldq, hipStream_t stream);
+// (y: the hand-off buffer armed for this solve -- forward: nslots x kOneMaxRhs, backward: n x kOneMaxRhs values --,
+// y_next: the one this solve arms for the next of its kind; state / state_next: {status, ticket} likewise)
+void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
+                      double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
+void launch_bsolve_one(const DevicePattern& P, int nsuper, int n, const double* L, double* x, int nrhs, int ldx,
+                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,

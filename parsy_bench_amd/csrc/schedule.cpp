@@ -643,6 +643,8 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     build_launches(S, active);
 }
 
+static void build_solve_one(Schedule& S, bool sharded);
+
 void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pieces) {
     const int ns = S.nsuper;
     // PARSY_FORCE_UNFUSED=1 schedules the solve's fallback form everywhere (per-block-column
@@ -1193,6 +1195,86 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     }
     if (!S.solve_fix_list.empty())
         S.solve.push_back(Launch{kLaunchSolveFixup, 0, (int32_t)S.solve_fix_list.size(), S.nlevels, 0, 0, 0, 0, -1, 0});
+    build_solve_one(S, active != nullptr || active_pieces != nullptr);
+}
+
+// ONE-launch solves of small plans (schedule.hpp: Schedule::solve_one).  Forward: the supernodes are taken block column
+// by block column (<= 64 columns: one_sn, a window of the supernode's panel like a piece of the Cholesky view); what
+// block p subtracts from the x of a row below its columns -- a later column of its supernode or a row of an ancestor --
+// goes into slot one_slot0[p] + (row - w) of a hand-off buffer (written once, so the data can be its own flag); the
+// block that owns that row gathers its slots -- listed here per owner: (slot, column of the owner).  Backward: every
+// supernode's block columns, last one first.  PARSY_SOLVE_ONE=0: never, 2: whatever the size (tests).
+static void build_solve_one(Schedule& S, bool sharded) {
+    const int ns = S.nsuper;
+    S.solve_one = false;
+    S.one_sn.clear();
+    S.one_slot0.clear();
+    S.one_nslots = 0;
+    S.one_pull_ptr.clear();
+    S.one_pull_slot.clear();
+    S.one_pull_pos.clear();
+    S.one_bblocks.clear();
+    S.one_branges.clear();
+    const int mode = env_int("PARSY_SOLVE_ONE", 1);
+    if (mode == 0 || sharded || ns == 0 || (int)S.levelSet.size() != ns) return;   // (a rank's share of the supernodes: level launches)
+    if (mode == 1 && (ns > kOneMaxSupernodes || S.xsize > kOneMaxEntries || S.max_width > kOneMaxWidth)) return;
+    // the blocks in ticket order: level by level, a supernode's block columns from left to right
+    std::vector<int32_t> blk_of_col((size_t)S.n, -1), blk_sn;
+    for (int q = 0; q < ns; ++q) {
+        const int t = S.levelSet[(size_t)q];
+        const SnDesc& T = S.sn[t];
+        for (int cb = 0; cb < T.w; cb += kTile) {
+            SnDesc B = T;
+            B.c0 = T.c0 + cb;
+            B.w = std::min(kTile, T.w - cb);
+            B.r = T.r - cb;
+            B.px = T.px + (int64_t)cb * T.r + cb;
+            B.pi = T.pi + cb;
+            B.ld = T.r;
+            for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = (int32_t)S.one_sn.size();
+            S.one_slot0.push_back(S.one_nslots);
+            S.one_nslots += B.r - B.w;
+            S.one_sn.push_back(B);
+            blk_sn.push_back(t);
+        }
+    }
+    const int nb = (int)S.one_sn.size();
+    if (S.one_nslots > INT32_MAX / 2) {
+        S.one_sn.clear();
+        return;
+    }
+    // column of the row k (counted inside block p's window of the panel): a later column of the supernode, or lR
+    auto col_of = [&](int p, int k) {
+        const SnDesc& T = S.sn[blk_sn[(size_t)p]];
+        const int kk = (S.one_sn[(size_t)p].c0 - T.c0) + k;   // row of the supernode's panel
+        return kk < T.w ? T.c0 + kk : S.rows[(size_t)T.pi + kk];
+    };
+    S.one_pull_ptr.assign((size_t)nb + 1, 0);
+    for (int p = 0; p < nb; ++p)
+        for (int k = S.one_sn[(size_t)p].w; k < S.one_sn[(size_t)p].r; ++k) {
+            const int owner = blk_of_col[(size_t)col_of(p, k)];
+            if (owner <= p) throw std::runtime_error("schedule: a row below a block's columns is not owned by a later block");
+            S.one_pull_ptr[(size_t)owner + 1]++;
+        }
+    for (int p = 0; p < nb; ++p) S.one_pull_ptr[(size_t)p + 1] += S.one_pull_ptr[(size_t)p];
+    S.one_pull_slot.resize((size_t)S.one_pull_ptr[(size_t)nb]);
+    S.one_pull_pos.resize(S.one_pull_slot.size());
+    std::vector<int32_t> at(S.one_pull_ptr.begin(), S.one_pull_ptr.end() - 1);
+    for (int p = 0; p < nb; ++p)
+        for (int k = S.one_sn[(size_t)p].w; k < S.one_sn[(size_t)p].r; ++k) {
+            const int col = col_of(p, k), owner = blk_of_col[(size_t)col];
+            const int32_t e = at[(size_t)owner]++;
+            S.one_pull_slot[(size_t)e] = (int32_t)(S.one_slot0[(size_t)p] + (k - S.one_sn[(size_t)p].w));
+            S.one_pull_pos[(size_t)e] = col - S.one_sn[(size_t)owner].c0;
+        }
+    // backward: from the root down = the level order reversed; a supernode's block columns from the last one up
+    for (int q = ns; q-- > 0;) {
+        const int t = S.levelSet[(size_t)q];
+        S.one_branges.push_back((int32_t)S.one_bblocks.size());
+        for (int jb = ceil_div(S.sn[t].w, kTile); jb-- > 0;) S.one_bblocks.push_back(PanelDesc{t, jb, 0, 0});
+        S.one_branges.push_back((int32_t)S.one_bblocks.size());
+    }
+    S.solve_one = true;
 }
 
 int64_t simulate_chain(const Schedule& S, int slots) {
@@ -1465,12 +1547,89 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
     }
 }
 
+// The ONE-launch solves: the blocks tile the supernodes in ticket order; every row below a block's columns has a slot
+// of its own and is gathered exactly once, by the block that owns its column, at the right column, from a block with an
+// earlier ticket; the backward runs hold every block column once, last one first, supernodes from the root down.
+template <class Fail>
+static void check_solve_one(const Schedule& S, Fail&& fail) {
+    if (!S.solve_one) return;
+    const int ns = S.nsuper, nb = (int)S.one_sn.size();
+    if ((int)S.one_branges.size() != 2 * ns || (int)S.levelSet.size() != ns || (int)S.one_pull_ptr.size() != nb + 1 ||
+        (int)S.one_slot0.size() != nb || S.one_pull_slot.size() != S.one_pull_pos.size() ||
+        (int64_t)S.one_pull_slot.size() != S.one_nslots || S.one_pull_ptr[(size_t)nb] != (int32_t)S.one_pull_slot.size()) {
+        fail("one-launch solve: lists of the wrong length");
+        return;
+    }
+    // the blocks: windows of the supernodes' panels, left to right, supernodes in level order
+    std::vector<int32_t> blk_of_col((size_t)S.n, -1);
+    {
+        int p = 0;
+        int64_t slots = 0;
+        for (int q = 0; q < ns; ++q) {
+            const SnDesc& T = S.sn[S.levelSet[(size_t)q]];
+            for (int cb = 0; cb < T.w; cb += kTile, ++p) {
+                if (p >= nb) break;
+                const SnDesc& B = S.one_sn[(size_t)p];
+                if (B.c0 != T.c0 + cb || B.w != std::min(kTile, T.w - cb) || B.r != T.r - cb || B.ld != T.r ||
+                    B.px != T.px + (int64_t)cb * T.r + cb || B.pi != T.pi + cb || S.one_slot0[(size_t)p] != slots)
+                    fail("one-launch solve: block " + std::to_string(p) + " is not a block column of its supernode");
+                slots += B.r - B.w;
+                for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = p;
+            }
+        }
+        if (p != nb || slots != S.one_nslots) {
+            fail("one-launch solve: the blocks do not tile the supernodes");
+            return;
+        }
+    }
+    std::vector<int32_t> slot_blk((size_t)S.one_nslots, -1), slot_col((size_t)S.one_nslots, -1);
+    for (int p = 0; p < nb; ++p) {
+        const SnDesc& B = S.one_sn[(size_t)p];
+        for (int k = B.w; k < B.r; ++k) {
+            const int64_t slot = S.one_slot0[(size_t)p] + (k - B.w);
+            slot_blk[(size_t)slot] = p;
+        }
+    }
+    // columns of the slots through the supernodes (independent of one_sn's construction)
+    {
+        int p = 0;
+        for (int q = 0; q < ns; ++q) {
+            const SnDesc& T = S.sn[S.levelSet[(size_t)q]];
+            for (int cb = 0; cb < T.w; cb += kTile, ++p) {
+                const int wbk = std::min(kTile, T.w - cb);
+                for (int kk = cb + wbk; kk < T.r; ++kk)
+                    slot_col[(size_t)(S.one_slot0[(size_t)p] + (kk - cb - wbk))] = kk < T.w ? T.c0 + kk : S.rows[(size_t)T.pi + kk];
+            }
+        }
+    }
+    std::vector<uint8_t> seen((size_t)S.one_nslots, 0);
+    for (int p = 0; p < nb; ++p)
+        for (int32_t e = S.one_pull_ptr[(size_t)p]; e < S.one_pull_ptr[(size_t)p + 1]; ++e) {
+            const int32_t slot = S.one_pull_slot[(size_t)e], pos = S.one_pull_pos[(size_t)e];
+            const bool in = slot >= 0 && slot < S.one_nslots;
+            if (!in || seen[(size_t)slot] || pos < 0 || pos >= S.one_sn[(size_t)p].w ||
+                slot_col[(size_t)slot] != S.one_sn[(size_t)p].c0 + pos || slot_blk[(size_t)slot] >= p) {
+                fail("one-launch solve: bad entry " + std::to_string(e) + " in the gather list of block " + std::to_string(p));
+                continue;
+            }
+            seen[(size_t)slot] = 1;
+        }
+    for (int q = 0; q < ns; ++q) {
+        const int t = S.levelSet[(size_t)(ns - 1 - q)];
+        const int b0 = S.one_branges[2 * (size_t)q], b1 = S.one_branges[2 * (size_t)q + 1], nbk = ceil_div(S.sn[t].w, kTile);
+        bool ok = b1 - b0 == nbk && b0 >= 0 && b1 <= (int)S.one_bblocks.size();
+        for (int j = 0; ok && j < nbk; ++j) ok = S.one_bblocks[(size_t)b0 + j].sn == t && S.one_bblocks[(size_t)b0 + j].jb == nbk - 1 - j;
+        if (!ok) fail("one-launch solve: wrong block-column run of supernode " + std::to_string(t));
+    }
+}
+
 int64_t check_schedule(const Schedule& S, std::string& what) {
     int64_t bad = 0;
     auto fail = [&](const std::string& msg) {
         if (bad++ == 0) what = msg;
     };
     check_solve_launches(S, fail);
+    check_solve_one(S, fail);
     if (S.solve_only) return bad;
     const int nc = (int)S.csn.size();
     // ---- pieces tile their supernode; levels respect the chain-extended etree

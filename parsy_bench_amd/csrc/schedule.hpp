@@ -160,6 +160,12 @@ constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense whe
 constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
+constexpr int kOneMaxSupernodes = 4096;   // plans of at most this many supernodes and ...
+constexpr int64_t kOneMaxEntries = 1 << 21;   // ... this many stored entries of L ...
+constexpr int kOneMaxWidth = 192;         // ... whose widest supernode has at most this many columns (a wide one is a chain of
+                                          // block columns inside the launch: mid3d-class, 580 wide: 0.23 / 0.30 ms against
+                                          // 0.18 / 0.22 ms of the level launches) -- solve in ONE launch per direction when
+constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
 constexpr int kSubtreeMinPerSlot = 2;     // ... and only where there are this many eligible supernodes per subtree
@@ -253,6 +259,21 @@ struct Schedule {
                                            // first slot + 1 in pad (0: the chain streams those rows itself)
     int64_t n_bpart_slots = 0;             // 64 doubles each
     std::vector<Launch> bsolve;
+
+    // ONE-launch solves (k_solve_one, k_bsolve_block<.., ONE>): a small plan's level launches are a job of launch
+    // latencies; one workgroup per block column, taken by ticket in level order, and every value handed over as the data
+    // itself (a buffer armed with a NaN pattern: the data is the flag) instead of level barriers.  Forward: block p
+    // (one_sn[p]: <= 64 columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below
+    // its columns to slot one_slot0[p] + k - w (one slot per such row, written once), and the block that owns the row
+    // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward: x itself is
+    // handed over (n values per right-hand side).
+    bool solve_one = false;
+    std::vector<SnDesc> one_sn;          // the block columns in ticket order (level by level, left to right)
+    std::vector<int64_t> one_slot0;
+    int64_t one_nslots = 0;
+    std::vector<int32_t> one_pull_ptr, one_pull_slot, one_pull_pos;
+    std::vector<PanelDesc> one_bblocks; // backward: block columns per supernode (last first), supernodes from the root down
+    std::vector<int32_t> one_branges;   // ... (begin, end) into one_bblocks per supernode in that order
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)
     std::vector<uint8_t> active_piece; // per piece of the Cholesky view, 1 = factored by the launches

@@ -33,8 +33,14 @@ static constexpr int kRhs = 8;  // right-hand sides carried per pass over a pane
 __device__ __forceinline__ void block_solve_apply16(const double* Dg, const double* invd,
                                                     double (*xs)[kRhs], int w, int nq, int tid);
 
+__device__ __forceinline__ void block_invert16(double* Dg, double* invd, int w, int tid);
 __device__ __forceinline__ void block_solve_inv16(double* Dg, double* invd, double (*xs)[kRhs], int w,
                                                   int nq, int tid) {
+    block_invert16(Dg, invd, w, tid);
+    block_solve_apply16(Dg, invd, xs, w, nq, tid);
+}
+// (the inversions alone: they do not depend on x -- k_solve_one does them before it waits for its x; ends synchronised)
+__device__ __forceinline__ void block_invert16(double* Dg, double* invd, int w, int tid) {
     if (tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
     __syncthreads();
     if (tid < kTile && (tid & ~15) < w) {
@@ -55,7 +61,6 @@ __device__ __forceinline__ void block_solve_inv16(double* Dg, double* invd, doub
             if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
     }
     __syncthreads();
-    block_solve_apply16(Dg, invd, xs, w, nq, tid);
 }
 
 // The substitution itself, given the inverted sub-blocks (re-used for every pass of
@@ -1607,6 +1612,289 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 }
 
 // ---------------------------------------------------------------------------
+// ONE-launch solves of small plans (Schedule::solve_one): a job of a few thousand supernodes is ten to twenty level
+// launches of a few microseconds of work each -- the ex15-class forward solve took 0.126 ms, slower than one CPU
+// thread (0.0745 ms), all of it launch latency and hand-offs through memory.  Here a solve is ONE enqueue: one
+// workgroup per supernode, taken by ticket in level order (a workgroup only ever waits for supernodes with smaller
+// tickets, which are held by workgroups that run or have finished: no deadlock at any residency), and instead of
+// level barriers every value is handed over as the data itself: the hand-off buffer holds the armed pattern when the
+// solve starts and a value is valid once it differs (8-byte agent-scope atomics both sides, as the chain launches'
+// xscratch) -- ONE memory round trip per step of the critical path.
+// Forward: the tasks are BLOCK COLUMNS (<= 64 columns of a supernode: Schedule::one_sn).  What block p subtracts from
+// the x of row k below its columns -- a later column of its supernode or a row of an ancestor --, c = L[k, cols] y_p,
+// is not added to x but written to a slot of its own (written once); the block that owns row k gathers its slots
+// (one_pull_*: all of them polled at once, one per thread), solves its diagonal block, publishes x and then its own
+// c's -- from its panel, which it staged in LDS BEFORE it waited (L does not depend on anybody).
+// The same sums as the level launches, in gather order (the reference's `omp atomic` order is schedule-dependent
+// as well: triangularSolve/Triangular_BCSC.h:139-157).  Two earlier forms, both measured on the ex15-class input:
+// atomics on x + a dependency counter per supernode (three round trips per step) 0.098 ms; a pull through the
+// factorization's update lists (the top separators then stream every row inside their columns themselves, after
+// their last descendant) 0.175 ms; whole supernodes as tasks (the 124-column root then spends 24 us on its two block
+// columns, its second diagonal block and the rows between them fetched on the critical path) 0.093 ms.
+// No memset either: a solve arms the OTHER buffer of its kind (its supernode's slots / columns) and zeroes the other
+// {status, ticket} pair for the solve after it; the executor alternates.  Every wait is bounded like the chain
+// launches' (2 s, status -1, nobody hangs).
+__device__ __forceinline__ double one_poll(const double* p, int* info, int wait_bias, bool& ok) {
+    const long long* src = reinterpret_cast<const long long*>(p);
+    const unsigned long long t0 = wall_clock64();
+    int spins = 0;
+    for (;;) {
+        const long long b = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != kXArmed && wait_bias == 0) return __longlong_as_double(b);
+        if ((++spins & 15) == 0 && (wall_clock64() - t0 > kSolveSpinTicks ||
+                                    __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+            atomicMin(info, -1);   // (the result is wrong and reported)
+            ok = false;
+            return 0.0;
+        }
+        if (spins < 8) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(8);   // (the late ones poll at leisure)
+    }
+}
+// what every workgroup of a ONE-launch solve does first: its part (entries [e0, e0 + len) per right-hand side, stride
+// ldy) of the NEXT solve's buffer is armed, and the first ticket zeroes the next solve's {status, ticket}
+__device__ __forceinline__ void one_arm_next(double* __restrict__ y_next, int* __restrict__ state_next, int64_t ldy, int64_t e0,
+                                             int len, int task, int tid) {
+    for (int e = tid; e < len * kOneMaxRhs; e += kThreads) {
+        const int q = e / len, c = e - q * len;
+        reinterpret_cast<long long*>(y_next)[(int64_t)q * ldy + e0 + c] = kXArmed;
+    }
+    if (task == 0 && tid < 2) state_next[tid] = 0;
+}
+
+#ifdef PARSY_ONESTAMPS
+// diagnostic build: per supernode the 100 MHz wall clock at five points of k_solve_one (tools/one_stamps.py)
+__device__ unsigned long long g_onestamp[4096 * 8];
+#define ONESTAMP(i) do { if (tid == 0 && t < 4096) g_onestamp[t * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ONESTAMP(i) do { } while (0)
+#endif
+static constexpr int kOneStage = 4096;   // doubles of a block's rows below its columns staged in LDS (larger: streamed)
+// NQ: right-hand sides carried (1, 4 or 8).  On the critical path -- between the last slot's arrival and the block's
+// own slots going out -- there are two LDS matrix-vector products and nothing else: the INVERSE of the diagonal block
+// is formed while the block waits (it had 6 - 35 us of slack on the ex15-class chain; the blocked substitution of
+// k_solve_small took 1.1 - 4.8 us per step of the chain instead).
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict__ blocks, const int64_t* __restrict__ slot0,
+                                                        const int32_t* __restrict__ pull_ptr,
+                                                        const int32_t* __restrict__ pull_slot,
+                                                        const int32_t* __restrict__ pull_pos, const double* __restrict__ L,
+                                                        double* __restrict__ x, int nrhs, int ldx, int64_t nslots,
+                                                        double* __restrict__ y, double* __restrict__ y_next,
+                                                        int* __restrict__ state, int* __restrict__ state_next,
+                                                        int wait_bias) {
+    __shared__ double Dg[kTile * kLdDiag];  // the diagonal block (column-major), then its inverse in place (see below);
+                                            // at the end: the parts of the products below
+    __shared__ double invd[kTile];
+    __shared__ double s_t[16 * 17];         // a 16 x 16 block of the inverse under way
+    __shared__ double s_m[kTile / 16][16 * 17];   // the inverses of the 16 x 16 diagonal sub-blocks, dense (zero above the diagonal)
+    __shared__ double s_b[kTile][NQ];       // the block's right-hand side minus what the gathered slots say
+    __shared__ double s_x[kTile][NQ];       // its solution
+    __shared__ double s_pan[kOneStage];     // the rows below the block's columns, [c][k - w] (row stride nb | 1)
+    __shared__ int s_task;
+    static_assert(4 * kTile * 8 <= kTile * kLdDiag, "the products' parts reuse Dg");
+    const int tid = threadIdx.x;
+    if (tid == 0) s_task = atomicAdd(&state[1], 1);
+    __syncthreads();
+    const int t = s_task;                   // (the blocks are listed in ticket order)
+    const SnDesc D = blocks[t];
+    const int w = D.w, nb = D.r - w, ldp = nb | 1, ld = D.ld;
+    const double* __restrict__ G = L + D.px;
+    const int64_t s0 = slot0[t];
+    ONESTAMP(0);
+    one_arm_next(y_next, state_next, nslots, s0, nb, t, tid);
+    // ---- what does not depend on the other blocks: the right-hand side, the panel below the columns (small: LDS), the
+    // diagonal block and its inverse
+    for (int e = tid; e < kTile * NQ; e += kThreads) {
+        const int q = e / kTile, c = e - q * kTile;
+        s_b[c][q] = (c < w && q < nrhs) ? x[(int64_t)q * ldx + D.c0 + c] : 0.0;
+    }
+    const bool staged = w * ldp <= kOneStage;
+    if (staged)
+        for (int e = tid; e < w * nb; e += kThreads) {
+            const int c = e / nb, k = e - c * nb;
+            s_pan[c * ldp + k] = G[(int64_t)c * ld + w + k];
+        }
+    const int wpad = (w + 15) & ~15;
+    for (int e = tid; e < wpad * wpad; e += kThreads) {
+        const int c = e / wpad, i = e - c * wpad;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (i >= c && i < w && c < w) v = G[(int64_t)c * ld + i];
+        Dg[c * kLdDiag + i] = v;
+    }
+    __syncthreads();
+    // The inverse M of the block, in place.  First the 16 x 16 diagonal sub-blocks (block_invert16: inv(L_bb)[r][c], r > c,
+    // at Dg[(b + r) * ld + b + c] -- transposed into the strict upper triangle -- and 1 / l[r][r] in invd); then, block row
+    // by block row from the bottom up and inside a row from right to left,
+    //     M_ij = -(sum_{k = j + 1}^{i} M_ik L_kj) M_jj
+    // which overwrites L_ij (no later block reads it: rows above use only rows <= their own of L).  One thread per entry.
+    block_invert16(Dg, invd, w, tid);   // (ends synchronised)
+    for (int e = tid; e < (wpad / 16) * 256; e += kThreads) {
+        const int b = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+        s_m[b][rr * 17 + cc] = rr > cc ? Dg[(16 * b + rr) * kLdDiag + 16 * b + cc] : (rr == cc ? invd[16 * b + rr] : 0.0);
+    }
+    __syncthreads();
+    {
+        const int rr = tid >> 4, cc = tid & 15;
+        for (int bi = wpad - 16; bi >= 16; bi -= 16)
+            for (int bj = bi - 16; bj >= 0; bj -= 16) {
+                // T = sum_k M_ik L_kj, k from j + 1 to i (M_ii from the dense copy, the others already in place)
+                double tv = 0.0;
+                for (int bk = bj + 16; bk < bi; bk += 16) {
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        tv = fma(Dg[(bk + m) * kLdDiag + bi + rr], Dg[(bj + cc) * kLdDiag + bk + m], tv);
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m) tv = fma(s_m[bi >> 4][rr * 17 + m], Dg[(bj + cc) * kLdDiag + bi + m], tv);
+                s_t[rr * 17 + cc] = tv;
+                __syncthreads();   // (T complete, and every read of L_ij is done: it is overwritten next)
+                double mv = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) mv = fma(s_t[rr * 17 + m], s_m[bj >> 4][m * 17 + cc], mv);
+                Dg[(bj + cc) * kLdDiag + bi + rr] = -mv;
+                __syncthreads();
+            }
+    }
+    auto m_at = [&](int c, int k) {   // M[c][k], k <= c
+        const int b = c & ~15;
+        return k >= b ? s_m[b >> 4][(c - b) * 17 + (k - b)] : Dg[k * kLdDiag + c];
+    };
+    ONESTAMP(1);
+    // ---- gather: one slot per thread and right-hand side, all polls in flight together
+    {
+        bool ok = true;
+        for (int e = pull_ptr[t] + tid; e < pull_ptr[t + 1]; e += kThreads) {
+            const int64_t slot = pull_slot[e];
+            const int pos = pull_pos[e];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nrhs) unsafeAtomicAdd(&s_b[pos][q], -one_poll(&y[(int64_t)q * nslots + slot], state, wait_bias, ok));
+        }
+    }
+    __syncthreads();
+    ONESTAMP(2);
+    // ---- x = inv(L_bb) b: four lanes per row share the sum
+    {
+        const int c = tid >> 2, part = tid & 3;
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+        if (c < w) {
+            for (int k = part; k <= c; k += 4) {
+                const double iv = m_at(c, k);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = fma(iv, s_b[k][q], acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc[q] += __shfl_xor(acc[q], 1);
+            acc[q] += __shfl_xor(acc[q], 2);
+        }
+        if (part == 0 && c < kTile) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                s_x[c][q] = c < w ? acc[q] : 0.0;
+                if (c < w && q < nrhs) x[(int64_t)q * ldx + D.c0 + c] = acc[q];
+            }
+        }
+    }
+    __syncthreads();
+    ONESTAMP(3);
+    // ---- what this block subtracts from the rows below its columns: published, one slot per row.  Up to 256 staged
+    // rows: the columns are dealt over P = 4 / 2 / 1 groups of threads, the parts added up through LDS
+    const int nbp = (nb + 63) & ~63;
+    if (staged && nbp <= kThreads && nb > 0) {
+        const int P = kThreads / nbp;                 // 4, 2 or 1 (nbp = 64, 128, 192 / 256)
+        const int part = tid / nbp, k = tid - part * nbp;
+        double* __restrict__ red = Dg;                // [part][q][k]: the inverse is not needed any more
+        if (part < P) {
+            double acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+            if (k < nb) {
+                const int c_lo = part * w / P, c_hi = (part + 1) * w / P;
+                for (int c = c_lo; c < c_hi; ++c) {
+                    const double lv = s_pan[c * ldp + k];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_x[c][q], acc[q]);
+                }
+            }
+            if (P > 1) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) red[(part * NQ + q) * nbp + k] = acc[q];
+            } else if (k < nb) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (q < nrhs)
+                        __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(acc[q]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (P > 1) {
+            __syncthreads();
+            for (int e = tid; e < nb * NQ; e += kThreads) {
+                const int q = e / nb, kk = e - q * nb;
+                double v = 0.0;
+                for (int pp = 0; pp < P; ++pp) v += red[(pp * NQ + q) * nbp + kk];
+                if (q < nrhs)
+                    __hip_atomic_store(&y[(int64_t)q * nslots + s0 + kk], unarmed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
+        for (int k = tid; k < nb; k += kThreads) {
+            double acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+            if (staged) {
+                for (int c = 0; c < w; ++c) {
+                    const double lv = s_pan[c * ldp + k];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_x[c][q], acc[q]);
+                }
+            } else {
+                for (int c0 = 0; c0 < w; c0 += 8) {   // (eight loads in flight per thread)
+                    double lv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lv[i] = G[(int64_t)min(c0 + i, w - 1) * ld + w + k];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c0 + i < w) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[q] = fma(lv[i], s_x[c0 + i][q], acc[q]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nrhs)
+                    __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(acc[q]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    ONESTAMP(4);
+}
+
+void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
+                      double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+    if (nblocks <= 0) return;
+#define PARSY_ONE_LAUNCH(NQ)                                                                                               \
+    hipLaunchKernelGGL(k_solve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.one_slot0, P.one_pull_ptr,    \
+                       P.one_pull_slot, P.one_pull_pos, L, x, nrhs, ldx, nslots, y, y_next, state, state_next, wait_bias)
+    if (nrhs == 1) PARSY_ONE_LAUNCH(1);
+    else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
+    else PARSY_ONE_LAUNCH(8);
+#undef PARSY_ONE_LAUNCH
+}
+
+#ifdef PARSY_ONESTAMPS
+extern "C" void parsy_debug_onestamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_onestamp), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
+
+// ---------------------------------------------------------------------------
 // Backward solve L' x = y (the reference only has the forward solve;
 // with this the library solves A x = b end to end).  Pull form, no atomics: a block of <= 64
 // columns [cb, cb+wbk) of a supernode is finished by one workgroup once every row below it
@@ -1615,7 +1903,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 // The product runs one wave per column with lanes along the (contiguous) rows.
 // ---------------------------------------------------------------------------
 static constexpr int kLdRedB = 65;   // row stride of a wave's reduction buffer (doubles): conflict-free both ways
-template <int NQ>
+template <int NQ, bool ONE = false>
 __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restrict__ sn,
                                                            const PanelDesc* __restrict__ pds,
                                                            const int32_t* __restrict__ rows,
@@ -1624,7 +1912,13 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            int nrhs, int ldx, int chain, int* __restrict__ info,
                                                            int* __restrict__ ticket, int wait_bias, int nblocks,
                                                            const int32_t* __restrict__ ranges,
-                                                           const double* __restrict__ dinv) {
+                                                           const double* __restrict__ dinv,
+                                                           double* __restrict__ y_next = nullptr,
+                                                           int* __restrict__ state_next = nullptr, int one_n = 0) {
+    // ONE (one-launch backward solve of a small plan, see k_solve_one; chain == 0, ranges != null): task b, taken by
+    // ticket from the root down, is the run of ONE supernode's block columns, last one first; the x of the rows below a
+    // block -- other supernodes', and the supernode's own later block columns -- is taken from the armed buffer as it
+    // is published (xscratch = y: one_n x kOneMaxRhs, the data is the flag), and the block's own x is published there.
     // chain != 0: every block column of the wide supernodes of a level is in this launch; block jb takes the x
     // of blocks jb+1.. of its supernode as they are published: as the data itself, through the armed buffer
     // (xscratch: 8-byte agent-scope atomics both sides, a value is valid once it differs from kXArmed -- see
@@ -1639,7 +1933,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     __shared__ int s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
-    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
+    if (tid == 0) s_task = (chain || ONE) ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
     __syncthreads();
     // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on
     const int plane = s_task / nblocks;
@@ -1696,7 +1990,8 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     }
 
     const int nbc = (w + kTile - 1) / kTile;
-    for (int pass = plane; pass * NQ < nrhs; pass += kPassLanes) {
+    if (ONE && qsn == q_begin) one_arm_next(y_next, state_next, one_n, D.c0, w, task, tid);   // (its columns of the next buffer)
+    for (int pass = plane; pass * NQ < nrhs; pass += ONE ? 1 : kPassLanes) {   // (ONE: the workgroup takes every pass itself)
         const int q0 = pass * NQ;
         const int nq = min(NQ, nrhs - q0);
         __syncthreads();
@@ -1734,8 +2029,15 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 for (int u = 0; u < kBackUnroll; ++u) {
                     double xk[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        xk[q] = (q < nq && k0 + 64 * u < r) ? x[(int64_t)(q0 + q) * ldx + xr[u]] : 0.0;
+                    for (int q = 0; q < NQ; ++q) {
+                        const bool have = q < nq && k0 + 64 * u < r;
+                        if (ONE) {
+                            bool okp = true;   // (a timeout is reported in the status word; nobody may hang)
+                            xk[q] = have ? one_poll(&xscratch[(int64_t)(q0 + q) * one_n + xr[u]], info, wait_bias, okp) : 0.0;
+                        } else {
+                            xk[q] = have ? x[(int64_t)(q0 + q) * ldx + xr[u]] : 0.0;
+                        }
+                    }
 #pragma unroll
                     for (int ci = 0; ci < kTile / 4; ++ci) {
                         const double lvv = (wave + 4 * ci < wbk) ? lv[u][ci] : 0.0;
@@ -1872,6 +2174,9 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
         for (int e = tid; e < wbk * nq; e += kThreads) {
             const int q = e / wbk, c = e - q * wbk;
             x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = ts[c][q];
+            if (ONE)
+                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * one_n + D.c0 + cb + c], unarmed(ts[c][q]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             if (chain)
                 __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], unarmed(ts[c][q]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -1879,6 +2184,19 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
         // (chain launch: nothing else to do -- the values stored in the armed buffer are the publication)
     }
   }
+}
+
+void launch_bsolve_one(const DevicePattern& P, int nsuper, int n, const double* L, double* x, int nrhs, int ldx,
+                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+    if (nsuper <= 0) return;
+    if (nrhs == 1)
+        hipLaunchKernelGGL((k_bsolve_block<1, true>), dim3(nsuper), dim3(kThreads), 0, stream, P.sn, P.one_bblocks, P.rows, L,
+                           x, y, nrhs, ldx, 0, state, state + 1, wait_bias, nsuper, P.one_branges, nullptr, y_next,
+                           state_next, n);
+    else
+        hipLaunchKernelGGL((k_bsolve_block<4, true>), dim3(nsuper), dim3(kThreads), 0, stream, P.sn, P.one_bblocks, P.rows, L,
+                           x, y, nrhs, ldx, 0, state, state + 1, wait_bias, nsuper, P.one_branges, nullptr, y_next,
+                           state_next, n);
 }
 
 // ---------------------------------------------------------------------------

@@ -871,6 +871,74 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
     api.dropin_reset()
 
 
+# ---------------------------------------------------------------------------
+# ONE-launch solves of small plans (k_solve_one, k_bsolve_block<.., ONE>): one workgroup per supernode taken by ticket
+# in level order, every value handed over as the data itself (an armed buffer) instead of level launches.  By itself
+# for plans of <= 4096 supernodes and blocks of <= 8 right-hand sides: the small inputs of the tests above take it.
+# Here also forced onto inputs whose top separators are up to 28 block columns wide; repeated solves (two hand-off
+# buffers used in turn, no memset), both directions alternating, against the oracle / the checker and against the level
+# launches (PARSY_SOLVE_ONE=0).
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "13x13x13:27", "24x24x2:27", "mid3d", "lap30", "nd24k"])
+@pytest.mark.parametrize("nrhs", [1, 3, 8])
+def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
+    plan0 = api.Plan(sym, 0)
+    assert plan0.info["solve_one"] == 0
+    lv, _ = plan0.factor(sym.A2x)
+    assert plan0.status() == 0
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "2")
+    plan = api.Plan(sym, 0)
+    assert plan.info["solve_one"] == 1 and plan.check() == 0
+    rng = np.random.default_rng(5)
+    b1 = oracle.rhs_init_blocked(sym, lv)
+    for rep in range(3):
+        B = np.stack([b1] + [rng.standard_normal(sym.n) for _ in range(nrhs - 1)], axis=1)
+        X, _ = plan.solve(lv, B)
+        assert plan.solve_status() == 0
+        X0, _ = plan0.solve(lv, B)
+        for q in range(nrhs):
+            xo = oracle.blocked_lsolve(sym, lv, B[:, q], "serial")
+            assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+            assert np.abs(X[:, q] - X0[:, q]).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+        assert np.abs(X[:, 0] - 1.0).max() <= 1e-9
+        Y = rng.standard_normal((sym.n, nrhs))
+        for _ in range(1 + rep):   # (an odd and an even number of solves between two forward ones)
+            Z, _ = plan.solve2(lv, Y, forward=False)
+            assert plan.solve_status() == 0
+        for q in range(nrhs):
+            zo = oracle.blocked_ltsolve(sym, lv, Y[:, q])
+            assert np.abs(Z[:, q] - zo).max() <= SOLVE_TOL * max(1.0, np.abs(zo).max())
+    # more right-hand sides than one pass holds: the level launches, then ONE launch again
+    B9 = np.stack([b1] * 9, axis=1)
+    X9, _ = plan.solve(lv, B9)
+    assert np.abs(X9 - 1.0).max() <= 1e-9
+    x1, _ = plan.solve(lv, b1)
+    assert plan.solve_status() == 0 and np.abs(x1 - 1.0).max() <= 1e-9
+
+
+def test_one_launch_solve_timeout_is_reported(api, oracle, monkeypatch):
+    A, perm, sym = problem("ex15")
+    plan = api.Plan(sym, 0)
+    assert plan.info["solve_one"] == 1    # (small enough: taken by itself)
+    lv, _ = plan.factor(sym.A2x)
+    b = oracle.rhs_init_blocked(sym, lv)
+    x, _ = plan.solve(lv, b)
+    assert plan.solve_status() == 0 and np.abs(x - 1.0).max() < 1e-9
+    monkeypatch.setenv("PARSY_DEBUG_SOLVE_STALL", "1")   # every dependency wait runs into its bound
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve(lv, b)
+    assert plan.solve_status() == -1 and plan.status() == 0
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve2(lv, b, forward=False)
+    monkeypatch.delenv("PARSY_DEBUG_SOLVE_STALL")
+    x2, _ = plan.solve(lv, b)                             # the next solve starts clean
+    assert plan.solve_status() == 0 and np.abs(x2 - 1.0).max() < 1e-9
+    z, _ = plan.solve2(lv, b, forward=False)
+    assert plan.solve_status() == 0
+
+
 @pytest.mark.parametrize("nrhs", [1, 5, 64])
 def test_right_hand_side_with_the_armed_nan_pattern_does_not_stall(api, oracle, nrhs):
     """The chain launches of the solves hand x over as the data itself (a hand-off buffer armed with a signalling-NaN

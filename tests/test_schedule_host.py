@@ -263,3 +263,32 @@ def test_solve_launches_are_consistent(name, monkeypatch):
                 assert N.lib().parsy_plan_check(h) == 0, (env, N.last_error())
         finally:
             N.lib().parsy_plan_destroy(h)
+
+
+@pytest.mark.parametrize("name,auto,forced", [("tiny2d", 1, 1), ("ex15", 1, 1), ("small3d", 1, 1), ("13x13x13:27", 1, 1),
+                                              ("mid3d", 0, 1), ("nd24k", 0, 1)])
+def test_one_launch_solve_lists(name, auto, forced, monkeypatch):
+    """Small plans (<= 4096 supernodes, <= 2 M stored entries) solve in ONE launch per direction: that the block columns
+    tile the supernodes in ticket order, that every row below a block's columns has its own hand-off slot and is
+    gathered exactly once by the block that owns it, and the block-column runs of the backward solve are checked by
+    parsy_plan_check; a rank's share of the supernodes keeps the level launches; PARSY_SOLVE_ONE=0 / 2 switch it (2:
+    whatever the size)."""
+    A, perm, sym = problem(name)
+    monkeypatch.delenv("PARSY_SOLVE_ONE", raising=False)
+    h, info = host_plan(sym)
+    try:
+        assert info["solve_one"] == auto and N.lib().parsy_plan_check(h) == 0, N.last_error()
+        m = np.ascontiguousarray(shard_masks(sym, 2)[0], dtype=np.uint8)
+        assert N.lib().parsy_plan_set_active(h, N.ptr(m)) == 0, N.last_error()
+        pi = N.PlanInfo()
+        N.lib().parsy_plan_get_info(h, C.byref(pi))
+        assert pi.solve_one == 0 and N.lib().parsy_plan_check(h) == 0
+    finally:
+        N.lib().parsy_plan_destroy(h)
+    for mode, want in (("0", 0), ("2", forced)):
+        monkeypatch.setenv("PARSY_SOLVE_ONE", mode)
+        h, info = host_plan(sym)
+        try:
+            assert info["solve_one"] == want and N.lib().parsy_plan_check(h) == 0, N.last_error()
+        finally:
+            N.lib().parsy_plan_destroy(h)
