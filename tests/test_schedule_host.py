@@ -265,7 +265,7 @@ def test_solve_launches_are_consistent(name, monkeypatch):
             N.lib().parsy_plan_destroy(h)
 
 
-@pytest.mark.parametrize("name,auto,forced", [("tiny2d", 1, 1), ("ex15", 1, 1), ("small3d", 1, 1), ("13x13x13:27", 1, 1),
+@pytest.mark.parametrize("name,auto,forced", [("tiny2d", 1, 1), ("ex15", 1, 1), ("small3d", 1, 1), ("13x13x13:27", 0, 1), ("12x12x12:27", 0, 1), ("24x24x2:27", 1, 1),
                                               ("mid3d", 0, 1), ("nd24k", 0, 1)])
 def test_one_launch_solve_lists(name, auto, forced, monkeypatch):
     """Small plans (<= 4096 supernodes, <= 2 M stored entries) solve in ONE launch per direction: that the block columns
