@@ -61,11 +61,10 @@ int plan_upload_launches(parsy_plan* pl) {
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
     if (upload(pl, S.one_sn, pl->dp.one_sn, true)) return -1;
     if (upload(pl, S.one_slot0, pl->dp.one_slot0, true)) return -1;
+    if (upload(pl, S.one_wleft, pl->dp.one_wleft, true)) return -1;
     if (upload(pl, S.one_pull_ptr, pl->dp.one_pull_ptr, true)) return -1;
     if (upload(pl, S.one_pull_slot, pl->dp.one_pull_slot, true)) return -1;
     if (upload(pl, S.one_pull_pos, pl->dp.one_pull_pos, true)) return -1;
-    if (upload(pl, S.one_bblocks, pl->dp.one_bblocks, true)) return -1;
-    if (upload(pl, S.one_branges, pl->dp.one_branges, true)) return -1;
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
@@ -404,8 +403,8 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         if (one_begin(pl, true, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
-        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->S.nsuper);
-        launch_bsolve_one(pl->dp, pl->S.nsuper, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
+        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
+        launch_bsolve_one(pl->dp, (int)pl->S.one_sn.size(), pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -51,11 +51,10 @@ struct DevicePattern {           // device copies of Schedule arrays
     // ONE-launch solves of small plans (Schedule::solve_one)
     const SnDesc* one_sn = nullptr;         // forward: the block columns (<= 64 columns each) in ticket order
     const int64_t* one_slot0 = nullptr;     // ... and the first hand-off slot of each
+    const int32_t* one_wleft = nullptr;     // ... and the columns of its supernode from its first column on
     const int32_t* one_pull_ptr = nullptr;  // forward: per supernode its gather list [ptr[t], ptr[t + 1]) of
     const int32_t* one_pull_slot = nullptr; // ... (slot of the hand-off buffer,
     const int32_t* one_pull_pos = nullptr;  //      column of the supernode)
-    const PanelDesc* one_bblocks = nullptr; // backward: every supernode's block columns, last one first, from the root down
-    const int32_t* one_branges = nullptr;   // ... (begin, end) per supernode in that order
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -76,7 +75,7 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
 // y_next: the one this solve arms for the next of its kind; state / state_next: {status, ticket} likewise)
 void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
-void launch_bsolve_one(const DevicePattern& P, int nsuper, int n, const double* L, double* x, int nrhs, int ldx,
+void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
                        double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);

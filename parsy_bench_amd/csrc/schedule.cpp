@@ -1202,8 +1202,8 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
 // by block column (<= 64 columns: one_sn, a window of the supernode's panel like a piece of the Cholesky view); what
 // block p subtracts from the x of a row below its columns -- a later column of its supernode or a row of an ancestor --
 // goes into slot one_slot0[p] + (row - w) of a hand-off buffer (written once, so the data can be its own flag); the
-// block that owns that row gathers its slots -- listed here per owner: (slot, column of the owner).  Backward: every
-// supernode's block columns, last one first.  PARSY_SOLVE_ONE=0: never, 2: whatever the size (tests).
+// block that owns that row gathers its slots -- listed here per owner: (slot, column of the owner).  Backward: the same
+// blocks from the last one to the first.  PARSY_SOLVE_ONE=0: never, 2: whatever the size (tests).
 static void build_solve_one(Schedule& S, bool sharded) {
     const int ns = S.nsuper;
     S.solve_one = false;
@@ -1213,8 +1213,7 @@ static void build_solve_one(Schedule& S, bool sharded) {
     S.one_pull_ptr.clear();
     S.one_pull_slot.clear();
     S.one_pull_pos.clear();
-    S.one_bblocks.clear();
-    S.one_branges.clear();
+    S.one_wleft.clear();
     const int mode = env_int("PARSY_SOLVE_ONE", 1);
     if (mode == 0 || sharded || ns == 0 || (int)S.levelSet.size() != ns) return;   // (a rank's share of the supernodes: level launches)
     if (mode == 1 && (ns > kOneMaxSupernodes || S.xsize > kOneMaxEntries || S.max_width > kOneMaxWidth)) return;
@@ -1233,6 +1232,7 @@ static void build_solve_one(Schedule& S, bool sharded) {
             B.ld = T.r;
             for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = (int32_t)S.one_sn.size();
             S.one_slot0.push_back(S.one_nslots);
+            S.one_wleft.push_back(T.w - cb);
             S.one_nslots += B.r - B.w;
             S.one_sn.push_back(B);
             blk_sn.push_back(t);
@@ -1267,13 +1267,6 @@ static void build_solve_one(Schedule& S, bool sharded) {
             S.one_pull_slot[(size_t)e] = (int32_t)(S.one_slot0[(size_t)p] + (k - S.one_sn[(size_t)p].w));
             S.one_pull_pos[(size_t)e] = col - S.one_sn[(size_t)owner].c0;
         }
-    // backward: from the root down = the level order reversed; a supernode's block columns from the last one up
-    for (int q = ns; q-- > 0;) {
-        const int t = S.levelSet[(size_t)q];
-        S.one_branges.push_back((int32_t)S.one_bblocks.size());
-        for (int jb = ceil_div(S.sn[t].w, kTile); jb-- > 0;) S.one_bblocks.push_back(PanelDesc{t, jb, 0, 0});
-        S.one_branges.push_back((int32_t)S.one_bblocks.size());
-    }
     S.solve_one = true;
 }
 
@@ -1549,13 +1542,13 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
 
 // The ONE-launch solves: the blocks tile the supernodes in ticket order; every row below a block's columns has a slot
 // of its own and is gathered exactly once, by the block that owns its column, at the right column, from a block with an
-// earlier ticket; the backward runs hold every block column once, last one first, supernodes from the root down.
+// earlier ticket (the backward solve takes the same blocks in reverse order).
 template <class Fail>
 static void check_solve_one(const Schedule& S, Fail&& fail) {
     if (!S.solve_one) return;
     const int ns = S.nsuper, nb = (int)S.one_sn.size();
-    if ((int)S.one_branges.size() != 2 * ns || (int)S.levelSet.size() != ns || (int)S.one_pull_ptr.size() != nb + 1 ||
-        (int)S.one_slot0.size() != nb || S.one_pull_slot.size() != S.one_pull_pos.size() ||
+    if ((int)S.levelSet.size() != ns || (int)S.one_pull_ptr.size() != nb + 1 || (int)S.one_slot0.size() != nb ||
+        (int)S.one_wleft.size() != nb || S.one_pull_slot.size() != S.one_pull_pos.size() ||
         (int64_t)S.one_pull_slot.size() != S.one_nslots || S.one_pull_ptr[(size_t)nb] != (int32_t)S.one_pull_slot.size()) {
         fail("one-launch solve: lists of the wrong length");
         return;
@@ -1571,7 +1564,8 @@ static void check_solve_one(const Schedule& S, Fail&& fail) {
                 if (p >= nb) break;
                 const SnDesc& B = S.one_sn[(size_t)p];
                 if (B.c0 != T.c0 + cb || B.w != std::min(kTile, T.w - cb) || B.r != T.r - cb || B.ld != T.r ||
-                    B.px != T.px + (int64_t)cb * T.r + cb || B.pi != T.pi + cb || S.one_slot0[(size_t)p] != slots)
+                    B.px != T.px + (int64_t)cb * T.r + cb || B.pi != T.pi + cb || S.one_slot0[(size_t)p] != slots ||
+                    S.one_wleft[(size_t)p] != T.w - cb)
                     fail("one-launch solve: block " + std::to_string(p) + " is not a block column of its supernode");
                 slots += B.r - B.w;
                 for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = p;
@@ -1614,13 +1608,6 @@ static void check_solve_one(const Schedule& S, Fail&& fail) {
             }
             seen[(size_t)slot] = 1;
         }
-    for (int q = 0; q < ns; ++q) {
-        const int t = S.levelSet[(size_t)(ns - 1 - q)];
-        const int b0 = S.one_branges[2 * (size_t)q], b1 = S.one_branges[2 * (size_t)q + 1], nbk = ceil_div(S.sn[t].w, kTile);
-        bool ok = b1 - b0 == nbk && b0 >= 0 && b1 <= (int)S.one_bblocks.size();
-        for (int j = 0; ok && j < nbk; ++j) ok = S.one_bblocks[(size_t)b0 + j].sn == t && S.one_bblocks[(size_t)b0 + j].jb == nbk - 1 - j;
-        if (!ok) fail("one-launch solve: wrong block-column run of supernode " + std::to_string(t));
-    }
 }
 
 int64_t check_schedule(const Schedule& S, std::string& what) {

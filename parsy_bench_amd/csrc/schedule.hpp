@@ -265,15 +265,15 @@ struct Schedule {
     // itself (a buffer armed with a NaN pattern: the data is the flag) instead of level barriers.  Forward: block p
     // (one_sn[p]: <= 64 columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below
     // its columns to slot one_slot0[p] + k - w (one slot per such row, written once), and the block that owns the row
-    // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward: x itself is
-    // handed over (n values per right-hand side).
+    // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward (k_bsolve_one):
+    // the same blocks in reverse order; x itself is handed over (n values per right-hand side).
     bool solve_one = false;
     std::vector<SnDesc> one_sn;          // the block columns in ticket order (level by level, left to right)
     std::vector<int64_t> one_slot0;
+    std::vector<int32_t> one_wleft;      // per block: columns of its supernode from the block's first column on (backward:
+                                         // the first one_wleft - w rows below the block are the supernode's later columns)
     int64_t one_nslots = 0;
     std::vector<int32_t> one_pull_ptr, one_pull_slot, one_pull_pos;
-    std::vector<PanelDesc> one_bblocks; // backward: block columns per supernode (last first), supernodes from the root down
-    std::vector<int32_t> one_branges;   // ... (begin, end) into one_bblocks per supernode in that order
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)
     std::vector<uint8_t> active_piece; // per piece of the Cholesky view, 1 = factored by the launches

@@ -1669,7 +1669,46 @@ __device__ unsigned long long g_onestamp[4096 * 8];
 #else
 #define ONESTAMP(i) do { } while (0)
 #endif
+static constexpr int kOneRows = 256;     // rows below a block whose x the backward solve keeps in LDS
 static constexpr int kOneStage = 4096;   // doubles of a block's rows below its columns staged in LDS (larger: streamed)
+// The inverse M of a diagonal block (<= 64 x 64, column-major in Dg, identity padded to wpad), in place.  First the 16 x 16
+// diagonal sub-blocks (block_invert16), copied dense into s_m; then, block row by block row from the bottom up and inside
+// a row from right to left,
+//     M_ij = -(sum_{k = j + 1}^{i} M_ik L_kj) M_jj
+// which overwrites L_ij (no later block reads it: rows above use only rows <= their own of L).  One thread per entry;
+// ends synchronised.  Afterwards M[c][k], k <= c, is s_m[..] inside c's 16-block and Dg[k * kLdDiag + c] left of it.
+__device__ __forceinline__ void one_invert_block(double* Dg, double* invd, double* s_t, double (*s_m)[16 * 17], int w, int wpad,
+                                                 int tid) {
+    block_invert16(Dg, invd, w, tid);   // (ends synchronised)
+    for (int e = tid; e < (wpad / 16) * 256; e += kThreads) {
+        const int b = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+        s_m[b][rr * 17 + cc] = rr > cc ? Dg[(16 * b + rr) * kLdDiag + 16 * b + cc] : (rr == cc ? invd[16 * b + rr] : 0.0);
+    }
+    __syncthreads();
+    {
+        const int rr = tid >> 4, cc = tid & 15;
+        for (int bi = wpad - 16; bi >= 16; bi -= 16)
+            for (int bj = bi - 16; bj >= 0; bj -= 16) {
+                // T = sum_k M_ik L_kj, k from j + 1 to i (M_ii from the dense copy, the others already in place)
+                double tv = 0.0;
+                for (int bk = bj + 16; bk < bi; bk += 16) {
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        tv = fma(Dg[(bk + m) * kLdDiag + bi + rr], Dg[(bj + cc) * kLdDiag + bk + m], tv);
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m) tv = fma(s_m[bi >> 4][rr * 17 + m], Dg[(bj + cc) * kLdDiag + bi + m], tv);
+                s_t[rr * 17 + cc] = tv;
+                __syncthreads();   // (T complete, and every read of L_ij is done: it is overwritten next)
+                double mv = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) mv = fma(s_t[rr * 17 + m], s_m[bj >> 4][m * 17 + cc], mv);
+                Dg[(bj + cc) * kLdDiag + bi + rr] = -mv;
+                __syncthreads();
+            }
+    }
+}
+
 // NQ: right-hand sides carried (1, 4 or 8).  On the critical path -- between the last slot's arrival and the block's
 // own slots going out -- there are two LDS matrix-vector products and nothing else: the INVERSE of the diagonal block
 // is formed while the block waits (it had 6 - 35 us of slack on the ex15-class chain; the blocked substitution of
@@ -1723,39 +1762,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
         Dg[c * kLdDiag + i] = v;
     }
     __syncthreads();
-    // The inverse M of the block, in place.  First the 16 x 16 diagonal sub-blocks (block_invert16: inv(L_bb)[r][c], r > c,
-    // at Dg[(b + r) * ld + b + c] -- transposed into the strict upper triangle -- and 1 / l[r][r] in invd); then, block row
-    // by block row from the bottom up and inside a row from right to left,
-    //     M_ij = -(sum_{k = j + 1}^{i} M_ik L_kj) M_jj
-    // which overwrites L_ij (no later block reads it: rows above use only rows <= their own of L).  One thread per entry.
-    block_invert16(Dg, invd, w, tid);   // (ends synchronised)
-    for (int e = tid; e < (wpad / 16) * 256; e += kThreads) {
-        const int b = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-        s_m[b][rr * 17 + cc] = rr > cc ? Dg[(16 * b + rr) * kLdDiag + 16 * b + cc] : (rr == cc ? invd[16 * b + rr] : 0.0);
-    }
-    __syncthreads();
-    {
-        const int rr = tid >> 4, cc = tid & 15;
-        for (int bi = wpad - 16; bi >= 16; bi -= 16)
-            for (int bj = bi - 16; bj >= 0; bj -= 16) {
-                // T = sum_k M_ik L_kj, k from j + 1 to i (M_ii from the dense copy, the others already in place)
-                double tv = 0.0;
-                for (int bk = bj + 16; bk < bi; bk += 16) {
-#pragma unroll
-                    for (int m = 0; m < 16; ++m)
-                        tv = fma(Dg[(bk + m) * kLdDiag + bi + rr], Dg[(bj + cc) * kLdDiag + bk + m], tv);
-                }
-#pragma unroll
-                for (int m = 0; m < 16; ++m) tv = fma(s_m[bi >> 4][rr * 17 + m], Dg[(bj + cc) * kLdDiag + bi + m], tv);
-                s_t[rr * 17 + cc] = tv;
-                __syncthreads();   // (T complete, and every read of L_ij is done: it is overwritten next)
-                double mv = 0.0;
-#pragma unroll
-                for (int m = 0; m < 16; ++m) mv = fma(s_t[rr * 17 + m], s_m[bj >> 4][m * 17 + cc], mv);
-                Dg[(bj + cc) * kLdDiag + bi + rr] = -mv;
-                __syncthreads();
-            }
-    }
+    one_invert_block(Dg, invd, s_t, s_m, w, wpad, tid);   // (ends synchronised)
     auto m_at = [&](int c, int k) {   // M[c][k], k <= c
         const int b = c & ~15;
         return k >= b ? s_m[b >> 4][(c - b) * 17 + (k - b)] : Dg[k * kLdDiag + c];
@@ -1876,6 +1883,154 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
     ONESTAMP(4);
 }
 
+// The backward counterpart: block column p, taken by ticket from the root down (the forward order reversed), needs the x
+// of every row below its columns -- the later columns of its supernode and rows of ancestors: all of them owned by
+// blocks with earlier tickets --, written once each: x itself is the hand-off (y: n values per right-hand side, armed).
+//     t = y_blk - L(below, blk)' x(below),   x_blk = inv(L_bb)' t
+// Before it polls, the block has its panel below in LDS and the inverse of its diagonal block (as k_solve_one); after the
+// last x arrives there are two LDS matrix-vector products.  The first version ran k_bsolve_block's loops (blocked
+// substitution, rows below streamed from memory after the wait): ex15-class 0.086 ms.
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restrict__ blocks, const int32_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ blk_w0, const double* __restrict__ L,
+                                                         double* __restrict__ x, int nrhs, int ldx, int n, int nblocks,
+                                                         double* __restrict__ y, double* __restrict__ y_next,
+                                                         int* __restrict__ state, int* __restrict__ state_next,
+                                                         int wait_bias) {
+    __shared__ double Dg[kTile * kLdDiag];  // the diagonal block (column-major), then its inverse in place; at the end: parts
+    __shared__ double invd[kTile];
+    __shared__ double s_t[16 * 17];
+    __shared__ double s_m[kTile / 16][16 * 17];
+    __shared__ double s_b[kTile][NQ];       // y_blk, then t
+    __shared__ double s_xb[kOneRows][NQ];   // x of the rows below
+    __shared__ double s_pan[kOneStage];     // the rows below the block's columns, [c][k - w] (row stride nb | 1)
+    __shared__ int s_task;
+    static_assert(4 * kTile * 8 <= kTile * kLdDiag, "the products' parts reuse Dg");
+    const int tid = threadIdx.x;
+    if (tid == 0) s_task = atomicAdd(&state[1], 1);
+    __syncthreads();
+    const int t = nblocks - 1 - s_task;     // (the forward order reversed)
+    const SnDesc D = blocks[t];
+    const int w = D.w, nb = D.r - w, ldp = nb | 1, ld = D.ld;
+    const double* __restrict__ G = L + D.px;
+    // row k >= w of the block's window: a later column of its supernode (the first w0 - w rows below) or lR
+    const int w_left = blk_w0[t];           // columns of the supernode from this block's first one on
+    const int32_t* __restrict__ ri = rows + D.pi;
+    one_arm_next(y_next, state_next, n, D.c0, w, s_task, tid);
+    for (int e = tid; e < kTile * NQ; e += kThreads) {
+        const int q = e / kTile, c = e - q * kTile;
+        s_b[c][q] = (c < w && q < nrhs) ? x[(int64_t)q * ldx + D.c0 + c] : 0.0;
+    }
+    const bool xb_staged = nb <= kOneRows;                  // the x of the rows below fits in LDS
+    const bool staged = xb_staged && w * ldp <= kOneStage;  // ... and so does the panel below
+    if (staged)
+        for (int e = tid; e < w * nb; e += kThreads) {
+            const int c = e / nb, k = e - c * nb;
+            s_pan[c * ldp + k] = G[(int64_t)c * ld + w + k];
+        }
+    const int wpad = (w + 15) & ~15;
+    for (int e = tid; e < wpad * wpad; e += kThreads) {
+        const int c = e / wpad, i = e - c * wpad;
+        double v = (i == c) ? 1.0 : 0.0;
+        if (i >= c && i < w && c < w) v = G[(int64_t)c * ld + i];
+        Dg[c * kLdDiag + i] = v;
+    }
+    __syncthreads();
+    one_invert_block(Dg, invd, s_t, s_m, w, wpad, tid);   // (ends synchronised)
+    auto m_at = [&](int c, int k) {   // M[c][k], k <= c
+        const int b = c & ~15;
+        return k >= b ? s_m[b >> 4][(c - b) * 17 + (k - b)] : Dg[k * kLdDiag + c];
+    };
+    bool ok = true;
+    if (xb_staged) {
+        // ---- the x of the rows below: one row per thread and right-hand side, all polls in flight together
+        for (int k = tid; k < nb; k += kThreads) {
+            const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_xb[k][q] = q < nrhs ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok) : 0.0;
+        }
+        __syncthreads();
+    }
+    if (staged) {
+        // ---- t = y_blk - panel' x(below): four lanes per column share the sum
+        const int c = tid >> 2, part = tid & 3;
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+        if (c < w)
+            for (int k = part; k < nb; k += 4) {
+                const double lv = s_pan[c * ldp + k];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_xb[k][q], acc[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc[q] += __shfl_xor(acc[q], 1);
+            acc[q] += __shfl_xor(acc[q], 2);
+        }
+        if (part == 0 && c < w) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];
+        }
+    } else {
+        // a tall or wide panel: streamed, one wave per column at a time, lanes along the rows (as k_bsolve_block)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int c = wave; c < w; c += kThreads / 64) {
+            double acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+            for (int k = lane; k < nb; k += 64) {
+                const double lv = G[(int64_t)c * ld + w + k];
+                if (xb_staged) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_xb[k][q], acc[q]);
+                } else {
+                    const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (q < nrhs) acc[q] = fma(lv, one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok), acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- x = inv(L_bb)' t: x[c] = sum_{k >= c} M[k][c] t[k]; four lanes per column
+    {
+        const int c = tid >> 2, part = tid & 3;
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+        if (c < w)
+            for (int k = c + part; k < w; k += 4) {
+                const double iv = m_at(k, c);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = fma(iv, s_b[k][q], acc[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc[q] += __shfl_xor(acc[q], 1);
+            acc[q] += __shfl_xor(acc[q], 2);
+        }
+        if (part == 0 && c < w) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nrhs) {
+                    __hip_atomic_store(&y[(int64_t)q * n + D.c0 + c], unarmed(acc[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x[(int64_t)q * ldx + D.c0 + c] = acc[q];
+                }
+        }
+    }
+}
+
 void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
     if (nblocks <= 0) return;
@@ -1903,7 +2058,7 @@ extern "C" void parsy_debug_onestamps(unsigned long long* out) {
 // The product runs one wave per column with lanes along the (contiguous) rows.
 // ---------------------------------------------------------------------------
 static constexpr int kLdRedB = 65;   // row stride of a wave's reduction buffer (doubles): conflict-free both ways
-template <int NQ, bool ONE = false>
+template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restrict__ sn,
                                                            const PanelDesc* __restrict__ pds,
                                                            const int32_t* __restrict__ rows,
@@ -1912,13 +2067,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                                                            int nrhs, int ldx, int chain, int* __restrict__ info,
                                                            int* __restrict__ ticket, int wait_bias, int nblocks,
                                                            const int32_t* __restrict__ ranges,
-                                                           const double* __restrict__ dinv,
-                                                           double* __restrict__ y_next = nullptr,
-                                                           int* __restrict__ state_next = nullptr, int one_n = 0) {
-    // ONE (one-launch backward solve of a small plan, see k_solve_one; chain == 0, ranges != null): task b, taken by
-    // ticket from the root down, is the run of ONE supernode's block columns, last one first; the x of the rows below a
-    // block -- other supernodes', and the supernode's own later block columns -- is taken from the armed buffer as it
-    // is published (xscratch = y: one_n x kOneMaxRhs, the data is the flag), and the block's own x is published there.
+                                                           const double* __restrict__ dinv) {
     // chain != 0: every block column of the wide supernodes of a level is in this launch; block jb takes the x
     // of blocks jb+1.. of its supernode as they are published: as the data itself, through the armed buffer
     // (xscratch: 8-byte agent-scope atomics both sides, a value is valid once it differs from kXArmed -- see
@@ -1933,7 +2082,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     __shared__ int s_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // chain launch: blocks are listed last block column first (producers first) and taken by ticket
-    if (tid == 0) s_task = (chain || ONE) ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
+    if (tid == 0) s_task = chain ? atomicAdd(ticket, 1) : (int)(blockIdx.x + blockIdx.y * nblocks);
     __syncthreads();
     // every block once per pass lane: tasks 0..nblocks-1 are lane 0, and so on
     const int plane = s_task / nblocks;
@@ -1990,8 +2139,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
     }
 
     const int nbc = (w + kTile - 1) / kTile;
-    if (ONE && qsn == q_begin) one_arm_next(y_next, state_next, one_n, D.c0, w, task, tid);   // (its columns of the next buffer)
-    for (int pass = plane; pass * NQ < nrhs; pass += ONE ? 1 : kPassLanes) {   // (ONE: the workgroup takes every pass itself)
+    for (int pass = plane; pass * NQ < nrhs; pass += kPassLanes) {
         const int q0 = pass * NQ;
         const int nq = min(NQ, nrhs - q0);
         __syncthreads();
@@ -2029,15 +2177,8 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
                 for (int u = 0; u < kBackUnroll; ++u) {
                     double xk[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const bool have = q < nq && k0 + 64 * u < r;
-                        if (ONE) {
-                            bool okp = true;   // (a timeout is reported in the status word; nobody may hang)
-                            xk[q] = have ? one_poll(&xscratch[(int64_t)(q0 + q) * one_n + xr[u]], info, wait_bias, okp) : 0.0;
-                        } else {
-                            xk[q] = have ? x[(int64_t)(q0 + q) * ldx + xr[u]] : 0.0;
-                        }
-                    }
+                    for (int q = 0; q < NQ; ++q)
+                        xk[q] = (q < nq && k0 + 64 * u < r) ? x[(int64_t)(q0 + q) * ldx + xr[u]] : 0.0;
 #pragma unroll
                     for (int ci = 0; ci < kTile / 4; ++ci) {
                         const double lvv = (wave + 4 * ci < wbk) ? lv[u][ci] : 0.0;
@@ -2174,9 +2315,6 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
         for (int e = tid; e < wbk * nq; e += kThreads) {
             const int q = e / wbk, c = e - q * wbk;
             x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] = ts[c][q];
-            if (ONE)
-                __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * one_n + D.c0 + cb + c], unarmed(ts[c][q]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
             if (chain)
                 __hip_atomic_store(&xscratch[(int64_t)(q0 + q) * ldx + D.c0 + cb + c], unarmed(ts[c][q]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -2186,17 +2324,16 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
   }
 }
 
-void launch_bsolve_one(const DevicePattern& P, int nsuper, int n, const double* L, double* x, int nrhs, int ldx,
+void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
                        double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
-    if (nsuper <= 0) return;
-    if (nrhs == 1)
-        hipLaunchKernelGGL((k_bsolve_block<1, true>), dim3(nsuper), dim3(kThreads), 0, stream, P.sn, P.one_bblocks, P.rows, L,
-                           x, y, nrhs, ldx, 0, state, state + 1, wait_bias, nsuper, P.one_branges, nullptr, y_next,
-                           state_next, n);
-    else
-        hipLaunchKernelGGL((k_bsolve_block<4, true>), dim3(nsuper), dim3(kThreads), 0, stream, P.sn, P.one_bblocks, P.rows, L,
-                           x, y, nrhs, ldx, 0, state, state + 1, wait_bias, nsuper, P.one_branges, nullptr, y_next,
-                           state_next, n);
+    if (nblocks <= 0) return;
+#define PARSY_ONE_LAUNCH(NQ)                                                                                              \
+    hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.rows, P.one_wleft, L, x,    \
+                       nrhs, ldx, n, nblocks, y, y_next, state, state_next, wait_bias)
+    if (nrhs == 1) PARSY_ONE_LAUNCH(1);
+    else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
+    else PARSY_ONE_LAUNCH(8);
+#undef PARSY_ONE_LAUNCH
 }
 
 // ---------------------------------------------------------------------------
