@@ -748,7 +748,9 @@ def main():
                               "ms_per_factorization": d0 / 50 * 1e3, "solves_per_sec": 50 / ds0,
                               "solve_ms": ds0 / 50 * 1e3, "backward_solve_ms": db0 / 50 * 1e3,
                               "solve_max_abs_err_vs_ones": e0, "forward_backward_max_abs_err_vs_ones": eb0,
-                              "note": "a job of a few launch latencies: 20 launches per factorization"}
+                              "solve_launches_per_direction": 1 if pl0.info["solve_one"] == 3 else pl0.info["solve_launches"],
+                              "note": "a job of a few launch latencies: 20 launches per factorization; the solves are ONE launch "
+                                      "each (k_solve_one / k_bsolve_one: values handed over as the data itself)"}
             del pl0
             # configs[3] parabolic_fem-class: BCSC lower-triangular solve only, many right-hand sides
             A3, p3 = M.workload("parabolic_fem")

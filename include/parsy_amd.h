@@ -149,8 +149,8 @@ typedef struct parsy_plan_info {
     int32_t dense_tasks;           /* workgroups of the DENSE launches (k_chol_dense) per factorization */
     double dense_flops;            /* part of big_flops in dense entries (full 128 x 128 blocks below the diagonal): k_chol_dense */
     int64_t dense_entries;
-    int32_t solve_one;             /* 1: a small plan -- blocks of at most 8 right-hand sides are solved in ONE launch per
-                                    * direction (dependency counts instead of level launches: k_solve_one) */
+    int32_t solve_one;             /* a small plan -- blocks of at most 8 right-hand sides are solved in ONE launch instead of
+                                    * one per level (k_solve_one / k_bsolve_one): bit 0 the forward, bit 1 the backward solve */
     int32_t pad_;
 } parsy_plan_info;
 

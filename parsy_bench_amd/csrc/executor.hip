@@ -336,8 +336,8 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
 // stale; on wrap-around the flags are cleared first, so that no old value can pass for a new one), its own
 // status word and ticket counters zeroed.
 // (one: a ONE-launch solve -- its counters follow the status word; no flags, epochs or chain tickets)
-static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs) {
-    return pl->S.solve_one && nrhs <= kOneMaxRhs;
+static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward) {
+    return (backward ? pl->S.solve_one_back : pl->S.solve_one) && nrhs <= kOneMaxRhs;
 }
 
 // The buffers of the ONE-launch solves, made by the first of them: per direction two hand-off buffers (forward: one
@@ -396,7 +396,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         return -1;
     }
     const int64_t need = (int64_t)ldx * nrhs;
-    if (solve_takes_one_launch(pl, nrhs)) {
+    if (solve_takes_one_launch(pl, nrhs, true)) {
         // a small plan: the whole solve is one launch (k_bsolve_block<.., ONE>)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
@@ -576,7 +576,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
-    if (solve_takes_one_launch(pl, nrhs)) {
+    if (solve_takes_one_launch(pl, nrhs, false)) {
         // a small plan: the whole solve is one launch (k_solve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;

@@ -1206,7 +1206,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
 // blocks from the last one to the first.  PARSY_SOLVE_ONE=0: never, 2: whatever the size (tests).
 static void build_solve_one(Schedule& S, bool sharded) {
     const int ns = S.nsuper;
-    S.solve_one = false;
+    S.solve_one = S.solve_one_back = false;
     S.one_sn.clear();
     S.one_slot0.clear();
     S.one_nslots = 0;
@@ -1268,6 +1268,7 @@ static void build_solve_one(Schedule& S, bool sharded) {
             S.one_pull_pos[(size_t)e] = col - S.one_sn[(size_t)owner].c0;
         }
     S.solve_one = true;
+    S.solve_one_back = mode == 2 || S.max_width <= kOneMaxWidthBack;
 }
 
 int64_t simulate_chain(const Schedule& S, int slots) {

@@ -162,9 +162,11 @@ constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged 
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
 constexpr int kOneMaxSupernodes = 4096;   // plans of at most this many supernodes and ...
 constexpr int64_t kOneMaxEntries = 1 << 21;   // ... this many stored entries of L ...
-constexpr int kOneMaxWidth = 192;         // ... whose widest supernode has at most this many columns (a wide one is a chain of
-                                          // block columns inside the launch: mid3d-class, 580 wide: 0.23 / 0.30 ms against
-                                          // 0.18 / 0.22 ms of the level launches) -- solve in ONE launch per direction when
+constexpr int kOneMaxWidth = 640;         // ... whose widest supernode has at most this many columns -- a wide one is a chain of
+                                          // block columns inside the launch; mid3d-class, 580 wide: forward 0.136 ms against 0.183 ms
+                                          // of the level launches -- solve in ONE launch when
+constexpr int kOneMaxWidthBack = 192;     // (the backward solve: its kernel streams tall panels badly -- mid3d-class 0.58 against
+                                          // 0.22 ms -- and is taken up to this width only)
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
@@ -267,7 +269,7 @@ struct Schedule {
     // its columns to slot one_slot0[p] + k - w (one slot per such row, written once), and the block that owns the row
     // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward (k_bsolve_one):
     // the same blocks in reverse order; x itself is handed over (n values per right-hand side).
-    bool solve_one = false;
+    bool solve_one = false, solve_one_back = false;   // forward / backward solve (the lists are built when the first is set)
     std::vector<SnDesc> one_sn;          // the block columns in ticket order (level by level, left to right)
     std::vector<int64_t> one_slot0;
     std::vector<int32_t> one_wleft;      // per block: columns of its supernode from the block's first column on (backward:

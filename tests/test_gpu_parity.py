@@ -872,7 +872,7 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
 
 
 # ---------------------------------------------------------------------------
-# ONE-launch solves of small plans (k_solve_one, k_bsolve_block<.., ONE>): one workgroup per supernode taken by ticket
+# ONE-launch solves of small plans (k_solve_one, k_bsolve_one): one workgroup per block column taken by ticket
 # in level order, every value handed over as the data itself (an armed buffer) instead of level launches.  By itself
 # for plans of <= 4096 supernodes and blocks of <= 8 right-hand sides: the small inputs of the tests above take it.
 # Here also forced onto inputs whose top separators are up to 28 block columns wide; repeated solves (two hand-off
@@ -890,7 +890,7 @@ def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
     assert plan0.status() == 0
     monkeypatch.setenv("PARSY_SOLVE_ONE", "2")
     plan = api.Plan(sym, 0)
-    assert plan.info["solve_one"] == 1 and plan.check() == 0
+    assert plan.info["solve_one"] == 3 and plan.check() == 0
     rng = np.random.default_rng(5)
     b1 = oracle.rhs_init_blocked(sym, lv)
     for rep in range(3):
@@ -921,7 +921,7 @@ def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
 def test_one_launch_solve_timeout_is_reported(api, oracle, monkeypatch):
     A, perm, sym = problem("ex15")
     plan = api.Plan(sym, 0)
-    assert plan.info["solve_one"] == 1    # (small enough: taken by itself)
+    assert plan.info["solve_one"] == 3    # (small enough: taken by itself, both directions)
     lv, _ = plan.factor(sym.A2x)
     b = oracle.rhs_init_blocked(sym, lv)
     x, _ = plan.solve(lv, b)

@@ -29,7 +29,7 @@ for name in sys.argv[1:] or ["ex15"]:
     dev = torch.device("cuda", 0)
     values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
     L = torch.empty(int(sym.xsize), dtype=torch.float64, device=dev)
-    for mode in ("0", "1"):
+    for mode in os.environ.get("SMALL_JOBS_MODES", "0,1").split(","):
         os.environ["PARSY_SOLVE_ONE"] = mode
         plan = api.Plan(sym, 0)
         f = timed(lambda: plan.factor_device(values.data_ptr(), L.data_ptr(), 0), 5, 50)
