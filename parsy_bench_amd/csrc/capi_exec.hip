@@ -336,8 +336,8 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
         if (l.kind == parsy::kLaunchDense) o->dense_tasks += l.count;
     o->dense_flops = S.dense_flops;
     o->dense_entries = S.n_dense_entries;
-    o->solve_one = (S.solve_one ? 1 : 0) | (S.solve_one_back ? 2 : 0) | (S.solve_one && S.one_cut >= 0 ? 4 : 0);
-    o->solve_one_blocks = S.solve_one ? (int32_t)S.one_f.sn.size() : 0;   // (diagnostics: block columns of the forward ONE launch)
+    o->solve_one = (S.solve_one ? 1 : 0) | (S.solve_one_back ? 2 : 0);
+    o->pad_ = 0;
     return 0;
 }
 
@@ -507,12 +507,8 @@ int parsy_factor_status(parsy_plan* pl) {
 int parsy_solve_status(parsy_plan* pl) {
     if (!pl || pl->device < 0) return -1;
     int v = 0;
-    if (pl->solve_status_plan && hipMemcpy(&v, pl->dp.sinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (pl->solve_status_word) {
-        int v1 = 0;
-        if (hipMemcpy(&v1, pl->solve_status_word, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        v = std::min(v, v1);
-    }
+    const int* word = pl->solve_status_word ? pl->solve_status_word : pl->dp.sinfo;
+    if (hipMemcpy(&v, word, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (v < 0) set_last_error("solve: a hand-off wait inside a chain launch timed out; x is not the solution");
     return v < 0 ? -1 : 0;
 }

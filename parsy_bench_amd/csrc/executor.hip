@@ -59,26 +59,12 @@ int plan_upload_launches(parsy_plan* pl) {
         pl->dp.bpart = nullptr;
     }
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
-    {
-        auto up = [&](const Schedule::OneLists& O, DevicePattern::OneDev& D) {
-            D = DevicePattern::OneDev();
-            if (upload(pl, O.sn, D.sn, true) || upload(pl, O.slot0, D.slot0, true) || upload(pl, O.wleft, D.wleft, true) ||
-                upload(pl, O.slot_row, D.slot_row, true) || upload(pl, O.pull_ptr, D.pull_ptr, true) ||
-                upload(pl, O.pull_slot, D.pull_slot, true) || upload(pl, O.pull_pos, D.pull_pos, true))
-                return -1;
-            D.nblocks = (int)O.sn.size();
-            D.nslots = std::max<int64_t>(O.nslots, 1);
-            return 0;
-        };
-        if (up(S.one_f, pl->dp.one_f)) return -1;
-        if (S.one_b.sn.empty()) pl->dp.one_b = pl->dp.one_f;
-        else if (up(S.one_b, pl->dp.one_b)) return -1;
-        // (the hand-off buffers are sized by the lists: made again by the next ONE-launch solve)
-        if (pl->one_y) (void)hipFree(pl->one_y);
-        if (pl->one_state) (void)hipFree(pl->one_state);
-        pl->one_y = nullptr;
-        pl->one_state = nullptr;
-    }
+    if (upload(pl, S.one_sn, pl->dp.one_sn, true)) return -1;
+    if (upload(pl, S.one_slot0, pl->dp.one_slot0, true)) return -1;
+    if (upload(pl, S.one_wleft, pl->dp.one_wleft, true)) return -1;
+    if (upload(pl, S.one_pull_ptr, pl->dp.one_pull_ptr, true)) return -1;
+    if (upload(pl, S.one_pull_slot, pl->dp.one_pull_slot, true)) return -1;
+    if (upload(pl, S.one_pull_pos, pl->dp.one_pull_pos, true)) return -1;
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
@@ -360,7 +346,7 @@ static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward
 // leaves the other one armed and zeroed for the next solve of its kind (k_solve_one, k_bsolve_block<.., ONE>) -- one
 // enqueue per solve, no memset.
 static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*& y, double*& y_next, int*& st, int*& st_next) {
-    const size_t lf = (size_t)pl->dp.one_f.nslots * kOneMaxRhs, lb = (size_t)pl->S.n * kOneMaxRhs;
+    const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * kOneMaxRhs, lb = (size_t)pl->S.n * kOneMaxRhs;
     if (!pl->one_y) {
         PARSY_HIP(hipMalloc((void**)&pl->one_y, 2 * (lf + lb) * sizeof(double)));
         PARSY_HIP(hipMalloc((void**)&pl->one_state, 8 * sizeof(int)));
@@ -377,7 +363,6 @@ static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*&
     st = pl->one_state + (backward ? 4 : 0) + 2 * k;
     st_next = pl->one_state + (backward ? 4 : 0) + 2 * (k ^ 1u);
     pl->solve_status_word = st;
-    pl->solve_status_plan = pl->S.one_cut >= 0;   // (a larger plan: level launches above the cut as well)
     const char* stall = std::getenv("PARSY_DEBUG_SOLVE_STALL");
     pl->solve_wait_bias = (stall && stall[0] == '1') ? (1 << 20) : 0;
     return 0;
@@ -385,7 +370,6 @@ static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*&
 
 static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream) {
     pl->solve_status_word = nullptr;
-    pl->solve_status_plan = true;
     if (pl->epoch > INT_MAX - 2 * passes - 2) {
         PARSY_HIP(hipMemsetAsync(pl->dp.flags, 0, (size_t)pl->n_flags * sizeof(int), stream));
         PARSY_HIP(hipMemsetAsync(pl->dp.tflags, 0, 2 * (size_t)std::max(pl->dp.n_tflags, 1) * sizeof(int), stream));
@@ -412,20 +396,15 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         return -1;
     }
     const int64_t need = (int64_t)ldx * nrhs;
-    const bool one = solve_takes_one_launch(pl, nrhs, true);
-    auto one_launch = [&]() -> int {
+    if (solve_takes_one_launch(pl, nrhs, true)) {
+        // a small plan: the whole solve is one launch (k_bsolve_block<.., ONE>)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
         if (one_begin(pl, true, stream, y, y_next, st, st_next) != 0) return -1;
-        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->dp.one_b.nblocks);
-        launch_bsolve_one(pl->dp, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
-        return 0;
-    };
-    if (one && pl->S.one_cut < 0) {
-        // a small plan: the whole solve is one launch (k_bsolve_one)
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
-        if (one_launch() != 0) return -1;
+        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
+        launch_bsolve_one(pl->dp, (int)pl->S.one_sn.size(), pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
@@ -458,17 +437,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
         launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     }
-    if (one) {
-        // the levels above the cut, the ONE launch for the bottom levels, the subtree launch (status: the ONE launch's
-        // word -- the chain launches above report into the plan's own, read first by parsy_solve_status)
-        run_begin(pl);
-        run_range(pl, pl->S.bsolve, 0, (size_t)pl->S.one_b_skip0, nullptr, d_L, d_x, nrhs, ldx, stream);
-        if (one_launch() != 0) return -1;
-        run_range(pl, pl->S.bsolve, (size_t)pl->S.one_b_skip1, pl->S.bsolve.size(), nullptr, d_L, d_x, nrhs, ldx, stream);
-        run_end(pl, stream);
-    } else {
-        run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
-    }
+    run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
     pl->epoch += passes;
@@ -607,20 +576,15 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
-    const bool one = solve_takes_one_launch(pl, nrhs, false);
-    auto one_launch = [&]() -> int {
+    if (solve_takes_one_launch(pl, nrhs, false)) {
+        // a small plan: the whole solve is one launch (k_solve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
         if (one_begin(pl, false, stream, y, y_next, st, st_next) != 0) return -1;
-        profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, pl->dp.one_f.nblocks);
-        launch_solve_one(pl->dp, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
-        return 0;
-    };
-    if (one && pl->S.one_cut < 0) {
-        // a small plan: the whole solve is one launch (k_solve_one)
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
-        if (one_launch() != 0) return -1;
+        profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
+        launch_solve_one(pl->dp, (int)pl->S.one_sn.size(), std::max<int64_t>(pl->S.one_nslots, 1), d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
@@ -675,17 +639,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     pl->solve_ldq = ldq;
     if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, true, stream);
-    if (one && !use_xt) {
-        // the subtree launch, the ONE launch for the bottom levels, the levels above the cut (X in the caller's layout:
-        // the transposed one is only taken from 16 right-hand sides on, or when forced)
-        run_begin(pl);
-        run_range(pl, pl->S.solve, 0, (size_t)pl->S.one_f_skip0, nullptr, d_L, d_x, nrhs, ldx, stream);
-        if (one_launch() != 0) return -1;
-        run_range(pl, pl->S.solve, (size_t)pl->S.one_f_skip1, pl->S.solve.size(), nullptr, d_L, d_x, nrhs, ldx, stream);
-        run_end(pl, stream);
-    } else {
-        run_launches(pl, pl->S.solve, nullptr, d_L, use_xt ? pl->xt : d_x, nrhs, ldx, stream);
-    }
+    run_launches(pl, pl->S.solve, nullptr, d_L, use_xt ? pl->xt : d_x, nrhs, ldx, stream);
     if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, false, stream);
     pl->solve_ldq = 0;
     PARSY_HIP(hipGetLastError());

@@ -35,8 +35,7 @@ struct parsy_plan {
     double* one_y = nullptr;
     int* one_state = nullptr;
     unsigned one_calls[2] = {0, 0};   // forward, backward
-    const int* solve_status_word = nullptr;   // where the last solve's ONE launch left its status (null: none)
-    bool solve_status_plan = true;            // ... and whether its level launches reported into dp.sinfo
+    const int* solve_status_word = nullptr;   // where the last solve left its status (null: dp.sinfo)
 
     // buffers of the host-convenience calls
     double* h_values_dev = nullptr;

@@ -167,10 +167,7 @@ constexpr int kOneMaxWidth = 640;         // ... whose widest supernode has at m
                                           // of the level launches -- solve in ONE launch when
 constexpr int kOneMaxWidthBack = 192;     // (the backward solve: its kernel streams tall panels badly -- mid3d-class 0.58 against
                                           // 0.22 ms -- and is taken up to this width only)
-constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: the whole
-                                          // plan whatever its size, 3: the bottom levels whatever their size)
-constexpr int kOneMinBottom = 64;         // larger plans: the bottom levels go into a ONE launch when they hold at least this many
-                                          // supernodes outside the subtree launches, in at least two levels
+constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
 constexpr int kSubtreeMinPerSlot = 2;     // ... and only where there are this many eligible supernodes per subtree
@@ -265,35 +262,20 @@ struct Schedule {
     int64_t n_bpart_slots = 0;             // 64 doubles each
     std::vector<Launch> bsolve;
 
-    // ONE-launch solves (k_solve_one, k_bsolve_one): level launches of a few microseconds of work each are a job of
-    // launch latencies; instead one workgroup per block column, taken by ticket in level order, and every value handed
-    // over as the data itself (a buffer armed with a NaN pattern: the data is the flag).  Forward: block p (sn[p]: <= 64
-    // columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below its columns to
-    // slot slot0[p] + k - w (one slot per such row, written once), and the block that owns the row gathers its slots:
-    // [pull_ptr[p], pull_ptr[p + 1]) of (slot, column of the block).  Backward: the same blocks in reverse order; x itself
-    // is handed over (n values per right-hand side).
-    // Which supernodes: ALL of a small plan (one_cut = -1), or -- larger plans -- the levels <= one_cut, where every
-    // supernode outside the subtree launches has a single block column (the bottom of the tree: 9 of the nd24k-class
-    // forward solve's 17 launches): forward = the subtree launch, the ONE launch, the level launches above the cut;
-    // backward the other way round.  A row owned by a supernode above the cut is not a slot: slot_row names it (forward:
-    // subtracted from x with an atomic as in the level launches; backward: x read directly, final by then).
-    struct OneLists {
-        std::vector<SnDesc> sn;           // the block columns in ticket order (level by level, left to right)
-        std::vector<int64_t> slot0;
-        std::vector<int32_t> wleft;       // per block: columns of its supernode from the block's first column on (the first
-                                          // wleft - w rows below the block are the supernode's later columns)
-        std::vector<int32_t> slot_row;    // per slot: -1 = owned by a block of the launch, else the row (owner above the cut)
-        int64_t nslots = 0;
-        std::vector<int32_t> pull_ptr, pull_slot, pull_pos;
-        std::vector<uint8_t> member;      // per supernode
-        void clear() { *this = OneLists(); }
-    };
-    bool solve_one = false, solve_one_back = false;   // forward / backward solve
-    int one_cut = -1;                    // -1: the whole plan in the ONE launch; else the last level inside it
-    OneLists one_f, one_b;               // (one_b.sn empty: the backward solve uses one_f -- the same supernodes)
-    // hybrid: the launches [first, last) of `solve` / `bsolve` that the ONE launch replaces
-    int one_f_skip0 = 0, one_f_skip1 = 0, one_b_skip0 = 0, one_b_skip1 = 0;
-    const OneLists& one_back() const { return one_b.sn.empty() ? one_f : one_b; }
+    // ONE-launch solves (k_solve_one, k_bsolve_block<.., ONE>): a small plan's level launches are a job of launch
+    // latencies; one workgroup per block column, taken by ticket in level order, and every value handed over as the data
+    // itself (a buffer armed with a NaN pattern: the data is the flag) instead of level barriers.  Forward: block p
+    // (one_sn[p]: <= 64 columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below
+    // its columns to slot one_slot0[p] + k - w (one slot per such row, written once), and the block that owns the row
+    // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward (k_bsolve_one):
+    // the same blocks in reverse order; x itself is handed over (n values per right-hand side).
+    bool solve_one = false, solve_one_back = false;   // forward / backward solve (the lists are built when the first is set)
+    std::vector<SnDesc> one_sn;          // the block columns in ticket order (level by level, left to right)
+    std::vector<int64_t> one_slot0;
+    std::vector<int32_t> one_wleft;      // per block: columns of its supernode from the block's first column on (backward:
+                                         // the first one_wleft - w rows below the block are the supernode's later columns)
+    int64_t one_nslots = 0;
+    std::vector<int32_t> one_pull_ptr, one_pull_slot, one_pull_pos;
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)
     std::vector<uint8_t> active_piece; // per piece of the Cholesky view, 1 = factored by the launches

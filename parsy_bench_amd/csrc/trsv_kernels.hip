@@ -1715,7 +1715,6 @@ __device__ __forceinline__ void one_invert_block(double* Dg, double* invd, doubl
 // k_solve_small took 1.1 - 4.8 us per step of the chain instead).
 template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict__ blocks, const int64_t* __restrict__ slot0,
-                                                        const int32_t* __restrict__ slot_row,
                                                         const int32_t* __restrict__ pull_ptr,
                                                         const int32_t* __restrict__ pull_slot,
                                                         const int32_t* __restrict__ pull_pos, const double* __restrict__ L,
@@ -1810,15 +1809,6 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
     }
     __syncthreads();
     ONESTAMP(3);
-    // (a row whose owner is not in the launch -- a supernode above the cut of a larger plan -- is subtracted from x itself,
-    // with an atomic as in the level launches: those run afterwards)
-    auto publish = [&](int k, int q, double v) {
-        const int row = slot_row[s0 + k];
-        if (row < 0)
-            __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            atomicAdd(&x[(int64_t)q * ldx + row], -v);
-    };
     // ---- what this block subtracts from the rows below its columns: published, one slot per row.  Up to 256 staged
     // rows: the columns are dealt over P = 4 / 2 / 1 groups of threads, the parts added up through LDS
     const int nbp = (nb + 63) & ~63;
@@ -1844,7 +1834,9 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
             } else if (k < nb) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    if (q < nrhs) publish(k, q, acc[q]);
+                    if (q < nrhs)
+                        __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(acc[q]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (P > 1) {
@@ -1853,7 +1845,8 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
                 const int q = e / nb, kk = e - q * nb;
                 double v = 0.0;
                 for (int pp = 0; pp < P; ++pp) v += red[(pp * NQ + q) * nbp + kk];
-                if (q < nrhs) publish(kk, q, v);
+                if (q < nrhs)
+                    __hip_atomic_store(&y[(int64_t)q * nslots + s0 + kk], unarmed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     } else {
@@ -1882,7 +1875,9 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (q < nrhs) publish(k, q, acc[q]);
+                if (q < nrhs)
+                    __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(acc[q]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     ONESTAMP(4);
@@ -1897,8 +1892,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
 // substitution, rows below streamed from memory after the wait): ex15-class 0.086 ms.
 template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restrict__ blocks, const int32_t* __restrict__ rows,
-                                                         const int32_t* __restrict__ blk_w0, const int64_t* __restrict__ slot0,
-                                                         const int32_t* __restrict__ slot_row, const double* __restrict__ L,
+                                                         const int32_t* __restrict__ blk_w0, const double* __restrict__ L,
                                                          double* __restrict__ x, int nrhs, int ldx, int n, int nblocks,
                                                          double* __restrict__ y, double* __restrict__ y_next,
                                                          int* __restrict__ state, int* __restrict__ state_next,
@@ -1922,8 +1916,6 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     // row k >= w of the block's window: a later column of its supernode (the first w0 - w rows below) or lR
     const int w_left = blk_w0[t];           // columns of the supernode from this block's first one on
     const int32_t* __restrict__ ri = rows + D.pi;
-    const int32_t* __restrict__ srow = slot_row + slot0[t];   // per row below: -1 = owned by a block of this launch (its x
-                                                              // arrives through y), else final before the launch: x itself
     one_arm_next(y_next, state_next, n, D.c0, w, s_task, tid);
     for (int e = tid; e < kTile * NQ; e += kThreads) {
         const int q = e / kTile, c = e - q * kTile;
@@ -1955,9 +1947,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
         for (int k = tid; k < nb; k += kThreads) {
             const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                s_xb[k][q] = q >= nrhs ? 0.0 : srow[k] < 0 ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok)
-                                                           : x[(int64_t)q * ldx + row];
+            for (int q = 0; q < NQ; ++q) s_xb[k][q] = q < nrhs ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok) : 0.0;
         }
         __syncthreads();
     }
@@ -1998,9 +1988,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
                     const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
-                        if (q < nrhs)
-                            acc[q] = fma(lv, srow[k] < 0 ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok)
-                                                         : x[(int64_t)q * ldx + row], acc[q]);
+                        if (q < nrhs) acc[q] = fma(lv, one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok), acc[q]);
                 }
             }
 #pragma unroll
@@ -2043,13 +2031,12 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     }
 }
 
-void launch_solve_one(const DevicePattern& P, const double* L, double* x, int nrhs, int ldx, double* y, double* y_next,
-                      int* state, int* state_next, int wait_bias, hipStream_t stream) {
-    const DevicePattern::OneDev& O = P.one_f;
-    if (O.nblocks <= 0) return;
+void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
+                      double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+    if (nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                               \
-    hipLaunchKernelGGL(k_solve_one<NQ>, dim3(O.nblocks), dim3(kThreads), 0, stream, O.sn, O.slot0, O.slot_row, O.pull_ptr,  \
-                       O.pull_slot, O.pull_pos, L, x, nrhs, ldx, O.nslots, y, y_next, state, state_next, wait_bias)
+    hipLaunchKernelGGL(k_solve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.one_slot0, P.one_pull_ptr,    \
+                       P.one_pull_slot, P.one_pull_pos, L, x, nrhs, ldx, nslots, y, y_next, state, state_next, wait_bias)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);
@@ -2337,13 +2324,12 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
   }
 }
 
-void launch_bsolve_one(const DevicePattern& P, int n, const double* L, double* x, int nrhs, int ldx, double* y, double* y_next,
-                       int* state, int* state_next, int wait_bias, hipStream_t stream) {
-    const DevicePattern::OneDev& O = P.one_b;
-    if (O.nblocks <= 0) return;
+void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
+                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+    if (nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                              \
-    hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(O.nblocks), dim3(kThreads), 0, stream, O.sn, P.rows, O.wleft, O.slot0,       \
-                       O.slot_row, L, x, nrhs, ldx, n, O.nblocks, y, y_next, state, state_next, wait_bias)
+    hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.rows, P.one_wleft, L, x,    \
+                       nrhs, ldx, n, nblocks, y, y_next, state, state_next, wait_bias)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);

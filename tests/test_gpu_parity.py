@@ -918,53 +918,6 @@ def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
     assert plan.solve_status() == 0 and np.abs(x1 - 1.0).max() <= 1e-9
 
 
-# Larger plans: the bottom levels (every supernode outside the subtree launches a single block column) in ONE launch, the
-# subtree launch before and the level launches above the cut after it (backward: the other way round).  Taken by itself
-# from 64 such supernodes on (lap30, nd24k-class), forced here also where the plan is small (PARSY_SOLVE_ONE=3) and with
-# subtree launches forced so that the three parts are all there.
-@pytest.mark.parametrize("name,env", [("lap30", {}), ("nd24k", {}), ("mid3d", {"PARSY_SOLVE_ONE": "3"}),
-                                      ("ex15", {"PARSY_SOLVE_ONE": "3"}), ("lap30", {"PARSY_SUBTREES": "2"}),
-                                      ("nd24k", {"PARSY_SUBTREES": "2"}), ("small3d", {"PARSY_SOLVE_ONE": "3", "PARSY_SUBTREES": "2"})])
-@pytest.mark.parametrize("nrhs", [1, 4, 8])
-def test_bottom_levels_in_one_launch(api, oracle, monkeypatch, name, env, nrhs):
-    A, perm, sym = problem(name)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    plan = api.Plan(sym, 0)
-    assert plan.info["solve_one"] == 7 and plan.check() == 0
-    assert 0 < plan.info["solve_one_blocks"] < sym.nsuper + 64
-    lv, _ = plan.factor(sym.A2x)
-    assert plan.status() == 0
-    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
-    plan0 = api.Plan(sym, 0)
-    rng = np.random.default_rng(11)
-    b1 = oracle.rhs_init_blocked(sym, lv)
-    for rep in range(2):
-        B = np.stack([b1] + [rng.standard_normal(sym.n) for _ in range(nrhs - 1)], axis=1)
-        X, _ = plan.solve(lv, B)
-        assert plan.solve_status() == 0
-        X0, _ = plan0.solve(lv, B)
-        for q in range(nrhs):
-            xo = oracle.blocked_lsolve(sym, lv, B[:, q], "serial")
-            assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
-            assert np.abs(X[:, q] - X0[:, q]).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
-        assert np.abs(X[:, 0] - 1.0).max() <= 1e-9
-        Y = rng.standard_normal((sym.n, nrhs))
-        Z, _ = plan.solve2(lv, Y, forward=False)
-        assert plan.solve_status() == 0
-        for q in range(nrhs):
-            zo = oracle.blocked_ltsolve(sym, lv, Y[:, q])
-            assert np.abs(Z[:, q] - zo).max() <= SOLVE_TOL * max(1.0, np.abs(zo).max())
-    # a timeout in either part is reported
-    monkeypatch.setenv("PARSY_DEBUG_SOLVE_STALL", "1")
-    with pytest.raises(RuntimeError, match="timed out"):
-        plan.solve(lv, b1)
-    assert plan.solve_status() == -1
-    monkeypatch.delenv("PARSY_DEBUG_SOLVE_STALL")
-    x1, _ = plan.solve(lv, b1)
-    assert plan.solve_status() == 0 and np.abs(x1 - 1.0).max() <= 1e-9
-
-
 def test_one_launch_solve_timeout_is_reported(api, oracle, monkeypatch):
     A, perm, sym = problem("ex15")
     plan = api.Plan(sym, 0)
