@@ -145,6 +145,10 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     if (S.piece_width > 0) S.piece_width = ceil_div(std::max(S.piece_width, kBigTile), kBigTile) * kBigTile;
     if (S.piece_width < S.big_min_k) S.piece_width = 0;  // the pieces update each other through the BIG launches
     S.push_group = std::max(1, env_int("PARSY_PUSH_GROUP", kPushGroup));
+    // (early wave streams longer than split_chunks 16-wide chunks are cut into parts of about split_target, at most split_max)
+    const int split_chunks = env_int("PARSY_SPLIT_CHUNKS", kSplitChunks), split_target = std::max(1, env_int("PARSY_SPLIT_TARGET", kSplitTarget)),
+              split_max = std::max(1, env_int("PARSY_SPLIT_MAX", kSplitMaxParts));
+    const bool split_env = std::getenv("PARSY_SPLIT_CHUNKS") != nullptr;   // (set: one rule for every level -- diagnostics)
 
     std::vector<int> tree(P.sparent, P.sparent + ns);
     S.sparent = tree;
@@ -384,6 +388,16 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     }
     S.big_super_r = env_sr;
     S.big_super_c = env_sc;
+    // tiles per level: a level with few of them leaves the device empty while its longest early stream runs (ex15-class:
+    // 2 - 12 workgroups for 47 - 76 us per level, the critical path of the upper half of the tree) -- there the streams
+    // are cut finer (kSplitFew*)
+    std::vector<int64_t> level_tiles((size_t)std::max(S.cnlevels, 1), 0);
+    if (!S.solve_only)
+        for (int t = 0; t < nc; ++t)
+            if (!is_small(S.csn[t])) {
+                const int nbc = ceil_div(S.csn[t].w, kTile), nbr = ceil_div(S.csn[t].r, kTile);
+                level_tiles[(size_t)S.level_of[t]] += (int64_t)nbc * nbr - (int64_t)nbc * (nbc - 1) / 2;
+            }
     for (int t = 0; t < nc; ++t) {
         SnDesc& T = S.csn[t];
         big_tile0[t + 1] = big_tile0[t];
@@ -516,8 +530,10 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             // A launch ends with its longest wave stream: long EARLY streams are cut into parts that
             // separate workgroups apply to partial tiles (summed, in a fixed order, when the chain
             // launch loads the tile).  Every wave's list is cut where its own chunk count reaches p/nparts.
-            if ((tp & 1) == 0 && tw[tp] > kSplitChunks) {
-                const int nparts = std::min<int>(kSplitMaxParts, ceil_div(tw[tp], kSplitTarget));
+            const bool few = level_tiles[(size_t)lev_t] <= kSplitFewTiles && !split_env;
+            if ((tp & 1) == 0 && tw[tp] > (few ? kSplitFewChunks : split_chunks)) {
+                const int nparts = few ? std::min<int>(kSplitFewMaxParts, ceil_div(tw[tp], kSplitFewTarget))
+                                       : std::min<int>(split_max, ceil_div(tw[tp], split_target));
                 Schedule::SplitDesc sd{(int64_t)S.split_ranges.size(), S.n_split_doubles, nparts, 0};
                 S.n_split_doubles += (int64_t)(nparts - 1) * kTile * kTile;
                 S.split_ranges.resize(S.split_ranges.size() + (size_t)nparts * 8, 0);

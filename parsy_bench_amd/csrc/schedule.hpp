@@ -140,6 +140,10 @@ struct Launch {
 constexpr int kSplitChunks = 192;        // early wave streams longer than this (16-wide k chunks) are split ...
 constexpr int kSplitTarget = 128;        // ... into parts of about this length (at most kSplitMaxParts)
 constexpr int kSplitMaxParts = 4;
+constexpr int kSplitFewTiles = 128;      // levels with at most this many tiles: streams longer than kSplitFewChunks are cut into
+constexpr int kSplitFewChunks = 32;      // ... parts of about kSplitFewTarget, at most kSplitFewMaxParts (ex15-class 0.563 -> 0.485 ms,
+constexpr int kSplitFewTarget = 24;      // mid3d-class 1.00 -> 0.92 ms; on every level the nd24k-class input lost 5 %:
+constexpr int kSplitFewMaxParts = 8;     // profiles/r04_small_jobs.txt)
 constexpr int kWalkerBatch = 64;          // CHAIN: supernodes whose tiles are interleaved block column by block column
                                          // (upper bound; Schedule::walker_batch follows the device's CU count)
 constexpr int kBigTile = 128;             // tile edge of the BIG (LDS-staged GEMM) update kernel
