@@ -46,7 +46,9 @@ for name, reps in (("mid3d", 2 * FACTOR_REPS), ("lap30", FACTOR_REPS), ("nd24k",
 # right-hand side (wave kernels, armed hand-off buffer) and with five (workgroup kernels, flags); lap30 a second
 # time with subtree launches forced
 import os
-for name, reps, subtrees in (("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS // 2, "2"), ("nd24k", SOLVE_REPS, None),
+# (ex15, small3d: small plans -- blocks of <= 8 right-hand sides go through the ONE-launch kernels, hand-off buffers used in turn)
+for name, reps, subtrees in (("ex15", SOLVE_REPS, None), ("small3d", SOLVE_REPS, None),
+                             ("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS // 2, "2"), ("nd24k", SOLVE_REPS, None),
                              ("parabolic_fem", SOLVE_REPS // 2, None)):
     A, perm = M.workload(name)
     sym = I.analyze(A, perm)
@@ -80,5 +82,42 @@ for name, reps, subtrees in (("lap30", SOLVE_REPS, None), ("lap30", SOLVE_REPS /
         print(f"{name:13s} subtrees {subtrees or 'auto':4s} nrhs {nrhs}: {n_rounds} rounds, forward max rel deviation {worst:.2e}, "
               f"backward mismatches {bmis}, bad status {stat}", flush=True)
         bad += bmis + stat + (worst > 1e-12)
+# two plans of a small input, their ONE-launch solves in flight together on two streams (persistent workgroups of two
+# launches share the device: each waits only for earlier tickets of its own launch)
+for name in ("ex15", "small3d"):
+    A, perm = M.workload(name)
+    sym = I.analyze(A, perm)
+    values = torch.from_numpy(np.ascontiguousarray(sym.A2x)).to(dev)
+    plans = [api.Plan(sym, 0), api.Plan(sym, 0)]
+    assert plans[0].info["solve_one"] == 3
+    Ls = [torch.empty(int(sym.xsize), dtype=torch.float64, device=dev) for _ in plans]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for p, Lq in zip(plans, Ls):
+        p.factor_device(values.data_ptr(), Lq.data_ptr(), 0)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(4)
+    b = torch.from_numpy(rng.standard_normal(sym.n)).to(dev)
+    ref_f = b.clone(); plans[0].solve_device(Ls[0].data_ptr(), ref_f.data_ptr(), 1, sym.n, 0)
+    ref_b = b.clone(); plans[0].backsolve_device(Ls[0].data_ptr(), ref_b.data_ptr(), 1, sym.n, 0)
+    torch.cuda.synchronize()
+    xs = [b.clone(), b.clone()]
+    worst = 0.0; bmis = 0; stat = 0
+    for i in range(SOLVE_REPS):
+        back = i & 1
+        for p, Lq, x, st_ in zip(plans, Ls, xs, streams):
+            x.copy_(b)
+        torch.cuda.synchronize()
+        for p, Lq, x, st_ in zip(plans, Ls, xs, streams):
+            (p.backsolve_device if back else p.solve_device)(Lq.data_ptr(), x.data_ptr(), 1, sym.n, st_.cuda_stream)
+        torch.cuda.synchronize()
+        for p, x in zip(plans, xs):
+            stat += p.solve_status() != 0
+            if back:
+                bmis += not bool(torch.equal(x, ref_b))
+            else:
+                worst = max(worst, float((x - ref_f).abs().max() / ref_f.abs().max()))
+    print(f"{name:13s} two ONE-launch solves in flight: {SOLVE_REPS} rounds, forward max rel deviation {worst:.2e}, "
+          f"backward mismatches {bmis}, bad status {stat}", flush=True)
+    bad += bmis + stat + (worst > 1e-12)
 print("SOAK", "OK" if bad == 0 else "FAILED")
 sys.exit(1 if bad else 0)
