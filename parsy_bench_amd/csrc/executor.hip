@@ -186,8 +186,7 @@ void plan_free(parsy_plan* pl) {
         for (void* d : pl->owned) (void)hipFree(d);
         for (void* d : pl->launch_owned) (void)hipFree(d);
         if (pl->xscratch) (void)hipFree(pl->xscratch);
-        if (pl->one_y) (void)hipFree(pl->one_y);
-        if (pl->one_state) (void)hipFree(pl->one_state);
+        if (pl->one_y) (void)hipFree(pl->one_y);   // (one_state lives in the same allocation)
         if (pl->xt) (void)hipFree(pl->xt);
         if (pl->dinv) (void)hipFree(pl->dinv);
         if (pl->dp.bpart) (void)hipFree(pl->dp.bpart);
@@ -343,13 +342,17 @@ static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward
 // The buffers of the ONE-launch solves, made by the first of them: per direction two hand-off buffers (forward: one
 // slot per entry of the row-id array, backward: one per unknown; kOneMaxRhs right-hand sides), all armed, and two
 // {status, ticket} pairs, zero.  Every such solve then works through buffer / pair (its direction's count & 1) and
-// leaves the other one armed and zeroed for the next solve of its kind (k_solve_one, k_bsolve_block<.., ONE>) -- one
+// leaves the other one armed and zeroed for the next solve of its kind (k_solve_one, k_bsolve_one) -- one
 // enqueue per solve, no memset.
 static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*& y, double*& y_next, int*& st, int*& st_next) {
     const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * kOneMaxRhs, lb = (size_t)pl->S.n * kOneMaxRhs;
-    if (!pl->one_y) {
-        PARSY_HIP(hipMalloc((void**)&pl->one_y, 2 * (lf + lb) * sizeof(double)));
-        PARSY_HIP(hipMalloc((void**)&pl->one_state, 8 * sizeof(int)));
+    if (!pl->one_y || !pl->one_state) {
+        // (one allocation for both: a failure leaves nothing behind)
+        if (pl->one_y) (void)hipFree(pl->one_y);
+        pl->one_y = nullptr;
+        pl->one_state = nullptr;
+        PARSY_HIP(hipMalloc((void**)&pl->one_y, 2 * (lf + lb) * sizeof(double) + 8 * sizeof(int)));
+        pl->one_state = reinterpret_cast<int*>(pl->one_y + 2 * (lf + lb));
         pl->device_bytes += (int64_t)(2 * (lf + lb) * sizeof(double) + 8 * sizeof(int));
         PARSY_HIP(solve_arm_handoff(pl->one_y, (int64_t)(2 * (lf + lb)), stream));
         PARSY_HIP(hipMemsetAsync(pl->one_state, 0, 8 * sizeof(int), stream));
@@ -397,7 +400,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     }
     const int64_t need = (int64_t)ldx * nrhs;
     if (solve_takes_one_launch(pl, nrhs, true)) {
-        // a small plan: the whole solve is one launch (k_bsolve_block<.., ONE>)
+        // a small plan: the whole solve is one launch (k_bsolve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
         if (one_begin(pl, true, stream, y, y_next, st, st_next) != 0) return -1;

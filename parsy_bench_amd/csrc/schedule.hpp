@@ -266,7 +266,7 @@ struct Schedule {
     int64_t n_bpart_slots = 0;             // 64 doubles each
     std::vector<Launch> bsolve;
 
-    // ONE-launch solves (k_solve_one, k_bsolve_block<.., ONE>): a small plan's level launches are a job of launch
+    // ONE-launch solves (k_solve_one, k_bsolve_one): a small plan's level launches are a job of launch
     // latencies; one workgroup per block column, taken by ticket in level order, and every value handed over as the data
     // itself (a buffer armed with a NaN pattern: the data is the flag) instead of level barriers.  Forward: block p
     // (one_sn[p]: <= 64 columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below

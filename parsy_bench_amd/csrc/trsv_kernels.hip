@@ -1615,7 +1615,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 // ONE-launch solves of small plans (Schedule::solve_one): a job of a few thousand supernodes is ten to twenty level
 // launches of a few microseconds of work each -- the ex15-class forward solve took 0.126 ms, slower than one CPU
 // thread (0.0745 ms), all of it launch latency and hand-offs through memory.  Here a solve is ONE enqueue: one
-// workgroup per supernode, taken by ticket in level order (a workgroup only ever waits for supernodes with smaller
+// workgroup per block column, taken by ticket in level order (a workgroup only ever waits for blocks with smaller
 // tickets, which are held by workgroups that run or have finished: no deadlock at any residency), and instead of
 // level barriers every value is handed over as the data itself: the hand-off buffer holds the armed pattern when the
 // solve starts and a value is valid once it differs (8-byte agent-scope atomics both sides, as the chain launches'
@@ -1626,7 +1626,7 @@ void launch_solve_chain(const DevicePattern& P, int first, int count, const doub
 // (one_pull_*: all of them polled at once, one per thread), solves its diagonal block, publishes x and then its own
 // c's -- from its panel, which it staged in LDS BEFORE it waited (L does not depend on anybody).
 // The same sums as the level launches, in gather order (the reference's `omp atomic` order is schedule-dependent
-// as well: triangularSolve/Triangular_BCSC.h:139-157).  Two earlier forms, both measured on the ex15-class input:
+// as well: triangularSolve/Triangular_BCSC.h:139-157).  Earlier forms, all measured on the ex15-class input:
 // atomics on x + a dependency counter per supernode (three round trips per step) 0.098 ms; a pull through the
 // factorization's update lists (the top separators then stream every row inside their columns themselves, after
 // their last descendant) 0.175 ms; whole supernodes as tasks (the 124-column root then spends 24 us on its two block
