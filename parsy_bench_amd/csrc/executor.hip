@@ -344,8 +344,19 @@ static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward
 // {status, ticket} pairs, zero.  Every such solve then works through buffer / pair (its direction's count & 1) and
 // leaves the other one armed and zeroed for the next solve of its kind (k_solve_one, k_bsolve_one) -- one
 // enqueue per solve, no memset.
-static int one_begin(parsy_plan* pl, bool backward, hipStream_t stream, double*& y, double*& y_next, int*& st, int*& st_next) {
-    const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * kOneMaxRhs, lb = (size_t)pl->S.n * kOneMaxRhs;
+static int one_begin(parsy_plan* pl, bool backward, int nrhs, hipStream_t stream, double*& y, double*& y_next, int*& st,
+                     int*& st_next) {
+    // (the buffers hold 1, 4 or 8 right-hand sides -- nd24k-class: 12.5 MB per right-hand side for the forward slots --
+    // and are made again, larger, when a wider block comes: earlier solves on the stream are complete by then)
+    const int want = nrhs == 1 ? 1 : nrhs <= 4 ? 4 : kOneMaxRhs;
+    if (want > pl->one_cap && pl->one_y) {
+        PARSY_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(pl->one_y);
+        pl->one_y = nullptr;
+        pl->one_state = nullptr;
+    }
+    if (!pl->one_y) pl->one_cap = std::max(pl->one_cap, want);
+    const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * pl->one_cap, lb = (size_t)pl->S.n * pl->one_cap;
     if (!pl->one_y || !pl->one_state) {
         // (one allocation for both: a failure leaves nothing behind)
         if (pl->one_y) (void)hipFree(pl->one_y);
@@ -403,11 +414,11 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         // a small plan: the whole solve is one launch (k_bsolve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
-        if (one_begin(pl, true, stream, y, y_next, st, st_next) != 0) return -1;
+        if (one_begin(pl, true, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
         profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
-        launch_bsolve_one(pl->dp, (int)pl->S.one_sn.size(), pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
+        launch_bsolve_one(pl->dp, (int)pl->S.one_sn.size(), pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
@@ -583,11 +594,11 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         // a small plan: the whole solve is one launch (k_solve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
-        if (one_begin(pl, false, stream, y, y_next, st, st_next) != 0) return -1;
+        if (one_begin(pl, false, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
         profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
-        launch_solve_one(pl->dp, (int)pl->S.one_sn.size(), std::max<int64_t>(pl->S.one_nslots, 1), d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, stream);
+        launch_solve_one(pl->dp, (int)pl->S.one_sn.size(), std::max<int64_t>(pl->S.one_nslots, 1), d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -35,6 +35,7 @@ struct parsy_plan {
     double* one_y = nullptr;
     int* one_state = nullptr;
     unsigned one_calls[2] = {0, 0};   // forward, backward
+    int one_cap = 0;                  // right-hand sides the buffers are made for (1, 4 or 8: grown on demand)
     const int* solve_status_word = nullptr;   // where the last solve left its status (null: dp.sinfo)
 
     // buffers of the host-convenience calls

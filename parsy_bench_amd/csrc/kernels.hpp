@@ -71,12 +71,12 @@ void launch_chol_chain(const DevicePattern& P, int first, int count, int ticket,
 
 void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, bool subtrees, const double* L,
                         double* x, int nrhs, int ldx, int ldq, hipStream_t stream);
-// (y: the hand-off buffer armed for this solve -- forward: nslots x kOneMaxRhs, backward: n x kOneMaxRhs values --,
+// (y: the hand-off buffer armed for this solve -- forward: nslots x cap, backward: n x cap values, cap = 1, 4 or 8 right-hand sides --,
 // y_next: the one this solve arms for the next of its kind; state / state_next: {status, ticket} likewise)
 void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
-                      double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
+                      double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream);
 void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
-                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream);
+                       double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);
 void launch_solve_chain(const DevicePattern& P, int first, int count, const double* L, const double* dinv,

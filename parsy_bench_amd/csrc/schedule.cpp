@@ -1232,7 +1232,9 @@ static void build_solve_one(Schedule& S, bool sharded) {
     S.one_wleft.clear();
     const int mode = env_int("PARSY_SOLVE_ONE", 1);
     if (mode == 0 || sharded || ns == 0 || (int)S.levelSet.size() != ns) return;   // (a rank's share of the supernodes: level launches)
-    if (mode == 1 && (ns > kOneMaxSupernodes || S.xsize > kOneMaxEntries || S.max_width > kOneMaxWidth)) return;
+    if (mode == 1 && (S.xsize > kOneMaxEntries || ns > 2 * kOneMaxSupernodes ||
+                      (ns > kOneMaxSupernodes && S.xsize < kOneLargeEntries * (int64_t)ns)))
+        return;
     // the blocks in ticket order: level by level, a supernode's block columns from left to right
     std::vector<int32_t> blk_of_col((size_t)S.n, -1), blk_sn;
     for (int q = 0; q < ns; ++q) {
@@ -1284,7 +1286,7 @@ static void build_solve_one(Schedule& S, bool sharded) {
             S.one_pull_pos[(size_t)e] = col - S.one_sn[(size_t)owner].c0;
         }
     S.solve_one = true;
-    S.solve_one_back = mode == 2 || S.max_width <= kOneMaxWidthBack;
+    S.solve_one_back = true;
 }
 
 int64_t simulate_chain(const Schedule& S, int slots) {

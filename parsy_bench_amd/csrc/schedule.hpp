@@ -164,13 +164,12 @@ constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense whe
 constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
-constexpr int kOneMaxSupernodes = 4096;   // plans of at most this many supernodes and ...
-constexpr int64_t kOneMaxEntries = 1 << 21;   // ... this many stored entries of L ...
-constexpr int kOneMaxWidth = 640;         // ... whose widest supernode has at most this many columns -- a wide one is a chain of
-                                          // block columns inside the launch; mid3d-class, 580 wide: forward 0.136 ms against 0.183 ms
-                                          // of the level launches -- solve in ONE launch when
-constexpr int kOneMaxWidthBack = 192;     // (the backward solve: its kernel streams tall panels badly -- mid3d-class 0.58 against
-                                          // 0.22 ms -- and is taken up to this width only)
+constexpr int kOneMaxSupernodes = 8192;         // plans of at most this many supernodes -- or twice as many when the supernodes
+constexpr int64_t kOneLargeEntries = 4096;      // hold at least this many entries of L on average (a 3-D problem: 64^3 grid, 13 583
+                                                // supernodes, 1.12 -> 0.97 ms; a 500 x 500 grid, 26 092 supernodes of 600 entries, loses:
+                                                // 0.35 -> 0.46 ms, as does the parabolic_fem-class input) -- and at most
+constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries solve in ONE launch per direction (Flan-class, forced:
+                                                // 4.6 -> 7.1 ms forward, 5.8 -> 6.2 backward) when
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)

@@ -1654,8 +1654,8 @@ __device__ __forceinline__ double one_poll(const double* p, int* info, int wait_
 // what every workgroup of a ONE-launch solve does first: its part (entries [e0, e0 + len) per right-hand side, stride
 // ldy) of the NEXT solve's buffer is armed, and the first ticket zeroes the next solve's {status, ticket}
 __device__ __forceinline__ void one_arm_next(double* __restrict__ y_next, int* __restrict__ state_next, int64_t ldy, int64_t e0,
-                                             int len, int task, int tid) {
-    for (int e = tid; e < len * kOneMaxRhs; e += kThreads) {
+                                             int len, int task, int tid, int cap) {
+    for (int e = tid; e < len * cap; e += kThreads) {   // (cap: right-hand sides the buffers are made for)
         const int q = e / len, c = e - q * len;
         reinterpret_cast<long long*>(y_next)[(int64_t)q * ldy + e0 + c] = kXArmed;
     }
@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
                                                         double* __restrict__ x, int nrhs, int ldx, int64_t nslots,
                                                         double* __restrict__ y, double* __restrict__ y_next,
                                                         int* __restrict__ state, int* __restrict__ state_next,
-                                                        int wait_bias) {
+                                                        int wait_bias, int cap) {
     __shared__ double Dg[kTile * kLdDiag];  // the diagonal block (column-major), then its inverse in place (see below);
                                             // at the end: the parts of the products below
     __shared__ double invd[kTile];
@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
     const double* __restrict__ G = L + D.px;
     const int64_t s0 = slot0[t];
     ONESTAMP(0);
-    one_arm_next(y_next, state_next, nslots, s0, nb, t, tid);
+    one_arm_next(y_next, state_next, nslots, s0, nb, t, tid, cap);
     // ---- what does not depend on the other blocks: the right-hand side, the panel below the columns (small: LDS), the
     // diagonal block and its inverse
     for (int e = tid; e < kTile * NQ; e += kThreads) {
@@ -1754,6 +1754,12 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
             const int c = e / nb, k = e - c * nb;
             s_pan[c * ldp + k] = G[(int64_t)c * ld + w + k];
         }
+    // (a larger panel: the first 256 rows below, one per thread, wait in REGISTERS -- the rows after them are streamed at the end)
+    double pre[kTile];
+    if (!staged && nb > 0) {
+#pragma unroll
+        for (int c = 0; c < kTile; ++c) pre[c] = G[(int64_t)min(c, w - 1) * ld + w + min(tid, nb - 1)];
+    }
     const int wpad = (w + 15) & ~15;
     for (int e = tid; e < wpad * wpad; e += kThreads) {
         const int c = e / wpad, i = e - c * wpad;
@@ -1860,6 +1866,13 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_x[c][q], acc[q]);
                 }
+            } else if (k == tid) {
+#pragma unroll
+                for (int c = 0; c < kTile; ++c)
+                    if (c < w) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[c], s_x[c][q], acc[q]);
+                    }
             } else {
                 for (int c0 = 0; c0 < w; c0 += 8) {   // (eight loads in flight per thread)
                     double lv[8];
@@ -1896,14 +1909,15 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
                                                          double* __restrict__ x, int nrhs, int ldx, int n, int nblocks,
                                                          double* __restrict__ y, double* __restrict__ y_next,
                                                          int* __restrict__ state, int* __restrict__ state_next,
-                                                         int wait_bias) {
+                                                         int wait_bias, int cap) {
     __shared__ double Dg[kTile * kLdDiag];  // the diagonal block (column-major), then its inverse in place; at the end: parts
     __shared__ double invd[kTile];
     __shared__ double s_t[16 * 17];
     __shared__ double s_m[kTile / 16][16 * 17];
     __shared__ double s_b[kTile][NQ];       // y_blk, then t
     __shared__ double s_xb[kOneRows][NQ];   // x of the rows below
-    __shared__ double s_pan[kOneStage];     // the rows below the block's columns, [c][k - w] (row stride nb | 1)
+    __shared__ double s_pan[kOneStage + kTile];   // the rows below the block's columns, [c][k - w] (row stride nb | 1; a larger
+                                                  // panel: its first 64 rows, stride 65)
     __shared__ int s_task;
     static_assert(4 * kTile * 8 <= kTile * kLdDiag, "the products' parts reuse Dg");
     const int tid = threadIdx.x;
@@ -1916,18 +1930,40 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     // row k >= w of the block's window: a later column of its supernode (the first w0 - w rows below) or lR
     const int w_left = blk_w0[t];           // columns of the supernode from this block's first one on
     const int32_t* __restrict__ ri = rows + D.pi;
-    one_arm_next(y_next, state_next, n, D.c0, w, s_task, tid);
+    one_arm_next(y_next, state_next, n, D.c0, w, s_task, tid, cap);
     for (int e = tid; e < kTile * NQ; e += kThreads) {
         const int q = e / kTile, c = e - q * kTile;
         s_b[c][q] = (c < w && q < nrhs) ? x[(int64_t)q * ldx + D.c0 + c] : 0.0;
     }
-    const bool xb_staged = nb <= kOneRows;                  // the x of the rows below fits in LDS
-    const bool staged = xb_staged && w * ldp <= kOneStage;  // ... and so does the panel below
+    const bool staged = nb <= kOneRows && w * ldp <= kOneStage;   // the panel below and the x of its rows fit in LDS
     if (staged)
         for (int e = tid; e < w * nb; e += kThreads) {
             const int c = e / nb, k = e - c * nb;
             s_pan[c * ldp + k] = G[(int64_t)c * ld + w + k];
         }
+    // A larger panel: its first 64 rows -- in a wide supernode the next block column, whose x arrives last -- in LDS all the
+    // same; the rows after them in chunks of kOneRows, the farthest first (their x has been there for long): wave v takes
+    // the columns v, v + 4, ..., lane l the rows l, l + 64, ... of a chunk -- 64 values of L per lane, in REGISTERS; the
+    // first chunk's are asked for here, before the polls
+    const int near = staged ? nb : min(nb, kTile), ldn = kTile + 1;
+    if (!staged)
+        for (int e = tid; e < w * near; e += kThreads) {
+            const int c = e / near, k = e - c * near;
+            s_pan[c * ldn + k] = G[(int64_t)c * ld + w + k];
+        }
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int kPc = kTile / (kThreads / 64), kPr = kOneRows / 64;   // columns per wave, rows per lane of a chunk
+    double pre[kPc][kPr];
+    auto preload = [&](int k0) {
+#pragma unroll
+        for (int ci = 0; ci < kPc; ++ci) {
+            const double* __restrict__ col = G + (int64_t)min(wave + (kThreads / 64) * ci, w - 1) * ld + w;
+#pragma unroll
+            for (int j = 0; j < kPr; ++j) pre[ci][j] = col[min(k0 + lane + 64 * j, nb - 1)];
+        }
+    };
+    const int nfar = nb - near, nchunks = (nfar + kOneRows - 1) / kOneRows;   // (0 when staged)
+    if (nchunks > 0) preload(near + (nchunks - 1) * kOneRows);
     const int wpad = (w + 15) & ~15;
     for (int e = tid; e < wpad * wpad; e += kThreads) {
         const int c = e / wpad, i = e - c * wpad;
@@ -1942,24 +1978,59 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
         return k >= b ? s_m[b >> 4][(c - b) * 17 + (k - b)] : Dg[k * kLdDiag + c];
     };
     bool ok = true;
-    if (xb_staged) {
-        // ---- the x of the rows below: one row per thread and right-hand side, all polls in flight together
-        for (int k = tid; k < nb; k += kThreads) {
-            const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
+    // the x of (a chunk of) the rows below: one row per thread and right-hand side, all polls in flight together
+    auto gather = [&](int k0, int len) {
+        for (int k = tid; k < len; k += kThreads) {
+            const int row = w + k0 + k < w_left ? D.c0 + w + k0 + k : ri[w + k0 + k];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) s_xb[k][q] = q < nrhs ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok) : 0.0;
         }
+    };
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int k0 = near + ch * kOneRows, len = min(kOneRows, nb - k0);
+        if (ch < nchunks - 1) {
+            __syncthreads();   // (the chunk before is consumed)
+            preload(k0);
+        }
+        gather(k0, len);
         __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < kPc; ++ci) {
+            const int c = wave + (kThreads / 64) * ci;
+            double acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int j = 0; j < kPr; ++j) {
+                const int k = lane + 64 * j;
+                if (k < len) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[ci][j], s_xb[k][q], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+            }
+            if (lane == 0 && c < w) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];   // (column c belongs to this wave alone)
+            }
+        }
     }
-    if (staged) {
-        // ---- t = y_blk - panel' x(below): four lanes per column share the sum
-        const int c = tid >> 2, part = tid & 3;
+    if (near > 0) {
+        // ---- the rows in LDS (all of a small panel): t = y_blk - panel' x(below), four lanes per column share the sum
+        if (nchunks > 0) __syncthreads();
+        gather(0, near);
+        __syncthreads();
+        const int c = tid >> 2, part = tid & 3, ldl = staged ? ldp : ldn;
         double acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
         if (c < w)
-            for (int k = part; k < nb; k += 4) {
-                const double lv = s_pan[c * ldp + k];
+            for (int k = part; k < near; k += 4) {
+                const double lv = s_pan[c * ldl + k];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_xb[k][q], acc[q]);
             }
@@ -1971,35 +2042,6 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
         if (part == 0 && c < w) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];
-        }
-    } else {
-        // a tall or wide panel: streamed, one wave per column at a time, lanes along the rows (as k_bsolve_block)
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int c = wave; c < w; c += kThreads / 64) {
-            double acc[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-            for (int k = lane; k < nb; k += 64) {
-                const double lv = G[(int64_t)c * ld + w + k];
-                if (xb_staged) {
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_xb[k][q], acc[q]);
-                } else {
-                    const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (q < nrhs) acc[q] = fma(lv, one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok), acc[q]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];
-            }
         }
     }
     __syncthreads();
@@ -2032,11 +2074,11 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
 }
 
 void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
-                      double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+                      double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
     if (nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                               \
     hipLaunchKernelGGL(k_solve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.one_slot0, P.one_pull_ptr,    \
-                       P.one_pull_slot, P.one_pull_pos, L, x, nrhs, ldx, nslots, y, y_next, state, state_next, wait_bias)
+                       P.one_pull_slot, P.one_pull_pos, L, x, nrhs, ldx, nslots, y, y_next, state, state_next, wait_bias, cap)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);
@@ -2325,11 +2367,11 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
 }
 
 void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
-                       double* y, double* y_next, int* state, int* state_next, int wait_bias, hipStream_t stream) {
+                       double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
     if (nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                              \
     hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.rows, P.one_wleft, L, x,    \
-                       nrhs, ldx, n, nblocks, y, y_next, state, state_next, wait_bias)
+                       nrhs, ldx, n, nblocks, y, y_next, state, state_next, wait_bias, cap)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);

@@ -55,11 +55,14 @@ def test_factor_residual_dense(api, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
-@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 6, 8, 16, 19, 64, 70])
-def test_solve_matches_oracle(api, oracle, name, nrhs):
+@pytest.mark.parametrize("nrhs,one", [(1, "0"), (1, "1"), (2, "0"), (3, "1"), (3, "0"), (5, "1"), (5, "0"), (6, "0"), (8, "1"), (8, "0"),
+                                      (16, "1"), (19, "1"), (64, "1"), (70, "1")])
+def test_solve_matches_oracle(api, oracle, monkeypatch, name, nrhs, one):
     """From 2 right-hand sides on the wide supernodes' chain, from 6 on the narrow supernodes too take the
     many-right-hand-side kernels (64 per pass over a panel, MFMA products): every column is checked against the
-    oracle's one-vector solve."""
+    oracle's one-vector solve.  one = "1": the product (blocks of <= 8 right-hand sides of these plans
+    go through the ONE-launch kernels), "0": the level launches for every block."""
+    monkeypatch.setenv("PARSY_SOLVE_ONE", one)
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(1)
     b1 = oracle.rhs_init_blocked(sym, lo)  # b = L * 1  (common/Util.h:277)
@@ -79,6 +82,7 @@ def test_solve_on_row_major_x_matches_oracle(api, oracle, monkeypatch, name, nrh
     and out; by itself only for factors with >= 200 entries per row and >= 16 right-hand sides): forced here
     (PARSY_XT_MIN), every column against the oracle, and the result must equal the right-hand-side-major path's to
     rounding (the scatter into x is made of atomics either way)."""
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")   # (the level launches: the ONE-launch kernels keep the caller's layout)
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(3)
     B = rng.standard_normal((sym.n, nrhs))
@@ -98,6 +102,7 @@ def test_solve_flag_protocol_chain_matches_oracle(api, oracle, monkeypatch, nrhs
     """PARSY_OLD_MRHS_CHAIN=1: the chain launches of rounds 1-2 (flags + staged copies per block column; 8 right-hand
     sides per pass below 16) stay available as a fallback and stay correct."""
     monkeypatch.setenv("PARSY_OLD_MRHS_CHAIN", "1")
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
     monkeypatch.setenv("PARSY_MRHS_MIN", "16")
     A, sym, plan, lv, lo = _factor_both(api, oracle, "lap30")
     rng = np.random.default_rng(2)
@@ -592,10 +597,12 @@ def test_unfused_fallback_paths(api, oracle, monkeypatch):
 # backward solve and the end-to-end solve A x = b
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "mid3d", "lap30"])
-@pytest.mark.parametrize("nrhs", [1, 5, 16, 19, 64, 70])
-def test_backward_solve_matches_checker(api, oracle, name, nrhs):
+@pytest.mark.parametrize("nrhs,one", [(1, "0"), (1, "1"), (5, "0"), (5, "1"), (16, "1"), (19, "1"), (64, "1"), (70, "1")])
+def test_backward_solve_matches_checker(api, oracle, monkeypatch, name, nrhs, one):
     """One, a few (4 per pass) and many right-hand sides (from 16 on: 64 per pass over L, products on the matrix
-    cores -- k_bsolve_block_mrhs): every column against the checker's transposed solve."""
+    cores -- k_bsolve_block_mrhs): every column against the checker's transposed solve.  one: as in
+    test_solve_matches_oracle."""
+    monkeypatch.setenv("PARSY_SOLVE_ONE", one)
     A, sym, plan, lv, lo = _factor_both(api, oracle, name)
     rng = np.random.default_rng(9)
     Y = rng.standard_normal((sym.n, nrhs))
@@ -611,6 +618,7 @@ def test_backward_solve_with_the_rows_below_summed_first(api, oracle, monkeypatc
     k_bsolve_below (512-row chunks over the whole device, partial sums added up by the chain in a fixed order) where a
     level's chain launch has few workgroups; PARSY_BSOLVE_BELOW=2 takes that path for every wide supernode, 0 never.
     Each against the checker, bitwise reproducible, and the plan check covers the slots."""
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")   # (the level launches: k_bsolve_below belongs to them)
     A, perm, sym = problem(name)
     rng = np.random.default_rng(12)
     y = rng.standard_normal(sym.n)
@@ -842,6 +850,7 @@ def test_factor_with_split_chain_launches(api, oracle, monkeypatch, name, piece,
 # ---------------------------------------------------------------------------
 def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypatch):
     from parsy_bench_amd import inspector as I
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")   # (the level launches; the ONE-launch kernels' timeout: test further down)
     A, perm, sym = problem("lap30")   # has supernodes wider than a tile: chain launches in both solves
     plan = api.Plan(sym, 0)
     assert plan.info["max_width"] > 64
@@ -874,10 +883,10 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
 # ---------------------------------------------------------------------------
 # ONE-launch solves of small plans (k_solve_one, k_bsolve_one): one workgroup per block column taken by ticket
 # in level order, every value handed over as the data itself (an armed buffer) instead of level launches.  By itself
-# for plans of <= 4096 supernodes and blocks of <= 8 right-hand sides: the small inputs of the tests above take it.
-# Here also forced onto inputs whose top separators are up to 28 block columns wide; repeated solves (two hand-off
-# buffers used in turn, no memset), both directions alternating, against the oracle / the checker and against the level
-# launches (PARSY_SOLVE_ONE=0).
+# for plans of <= 8192 supernodes (16 384 large ones) and blocks of <= 8 right-hand sides: every input of this file but the
+# Flan- and parabolic_fem-class ones.  Here: inputs whose top separators are up to 41 block columns wide; repeated solves
+# (two hand-off buffers used in turn, no memset; the buffers grow with the widest block seen), both directions alternating,
+# against the oracle / the checker and against the level launches (PARSY_SOLVE_ONE=0).
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny2d", "small3d", "ex15", "13x13x13:27", "24x24x2:27", "mid3d", "lap30", "nd24k"])
 @pytest.mark.parametrize("nrhs", [1, 3, 8])
@@ -939,14 +948,15 @@ def test_one_launch_solve_timeout_is_reported(api, oracle, monkeypatch):
     assert plan.solve_status() == 0
 
 
-@pytest.mark.parametrize("nrhs", [1, 5, 64])
-def test_right_hand_side_with_the_armed_nan_pattern_does_not_stall(api, oracle, nrhs):
+@pytest.mark.parametrize("nrhs,one", [(1, "0"), (1, "1"), (5, "0"), (5, "1"), (64, "1")])
+def test_right_hand_side_with_the_armed_nan_pattern_does_not_stall(api, oracle, monkeypatch, nrhs, one):
     """The chain launches of the solves hand x over as the data itself (a hand-off buffer armed with a signalling-NaN
     pattern: a value is valid once it differs).  A right-hand side that happens to carry that very pattern must not
     turn into a 2 s timeout: what is published is the result of arithmetic (a quiet NaN), and a value equal to the
     pattern would be published as a quiet NaN -- the solve completes, status 0, the NaN propagates to the rows that
     depend on it and nowhere else."""
     import time
+    monkeypatch.setenv("PARSY_SOLVE_ONE", one)             # ("1": blocks of <= 8 go through the ONE-launch kernels' buffers)
     A, perm, sym = problem("lap30")
     plan = api.Plan(sym, 0)
     lv, _ = plan.factor(sym.A2x)
