@@ -150,8 +150,9 @@ typedef struct parsy_plan_info {
     double dense_flops;            /* part of big_flops in dense entries (full 128 x 128 blocks below the diagonal): k_chol_dense */
     int64_t dense_entries;
     int32_t solve_one;             /* a small plan -- blocks of at most 8 right-hand sides are solved in ONE launch instead of
-                                    * one per level (k_solve_one / k_bsolve_one): bit 0 the forward, bit 1 the backward solve */
-    int32_t pad_;
+                                    * one per level (k_solve_one / k_bsolve_one): bit 0 the forward, bit 1 the backward solve;
+                                    * bit 2: the subtree launch of the narrow supernodes stays beside it */
+    int32_t solve_one_blocks;      /* block columns (workgroups) of the forward ONE launch */
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

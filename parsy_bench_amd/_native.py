@@ -57,7 +57,7 @@ class PlanInfo(C.Structure):
         ("solve_subtrees", C.c_int32), ("solve_subtree_supernodes", C.c_int32),
         ("backsolve_launches", C.c_int32), ("dense_tasks", C.c_int32),
         ("dense_flops", C.c_double), ("dense_entries", C.c_int64),
-        ("solve_one", C.c_int32), ("pad_", C.c_int32),
+        ("solve_one", C.c_int32), ("solve_one_blocks", C.c_int32),
     ]
 
     def as_dict(self):

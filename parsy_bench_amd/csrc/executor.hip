@@ -59,12 +59,25 @@ int plan_upload_launches(parsy_plan* pl) {
         pl->dp.bpart = nullptr;
     }
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
-    if (upload(pl, S.one_sn, pl->dp.one_sn, true)) return -1;
-    if (upload(pl, S.one_slot0, pl->dp.one_slot0, true)) return -1;
-    if (upload(pl, S.one_wleft, pl->dp.one_wleft, true)) return -1;
-    if (upload(pl, S.one_pull_ptr, pl->dp.one_pull_ptr, true)) return -1;
-    if (upload(pl, S.one_pull_slot, pl->dp.one_pull_slot, true)) return -1;
-    if (upload(pl, S.one_pull_pos, pl->dp.one_pull_pos, true)) return -1;
+    {
+        auto up = [&](const Schedule::OneLists& O, DevicePattern::OneDev& D) {
+            D = DevicePattern::OneDev();
+            if (upload(pl, O.sn, D.sn, true) || upload(pl, O.slot0, D.slot0, true) || upload(pl, O.wleft, D.wleft, true) ||
+                upload(pl, O.pull_ptr, D.pull_ptr, true) || upload(pl, O.pull_slot, D.pull_slot, true) ||
+                upload(pl, O.pull_pos, D.pull_pos, true))
+                return -1;
+            D.nblocks = (int)O.sn.size();
+            D.nslots = std::max<int64_t>(O.nslots, 1);
+            return 0;
+        };
+        if (up(S.one_f, pl->dp.one_f)) return -1;
+        if (S.one_b.sn.empty()) pl->dp.one_b = pl->dp.one_f;
+        else if (up(S.one_b, pl->dp.one_b)) return -1;
+        // (the hand-off buffers are sized by the lists: made again by the next ONE-launch solve)
+        if (pl->one_y) (void)hipFree(pl->one_y);
+        pl->one_y = nullptr;
+        pl->one_state = nullptr;
+    }
     {
         void* d = nullptr;
         PARSY_HIP(hipMalloc(&d, (size_t)std::max(S.n_chain_launches, 1) * sizeof(int)));
@@ -335,8 +348,14 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
 // stale; on wrap-around the flags are cleared first, so that no old value can pass for a new one), its own
 // status word and ticket counters zeroed.
 // (one: a ONE-launch solve -- its counters follow the status word; no flags, epochs or chain tickets)
+// (how many right-hand sides: 8 where the launch has at most kOneSmallBlocks blocks -- ex15-class, 8: 0.130 -> 0.087 ms --, else
+// 4 -- from 6 on the level launches use the matrix cores: nd24k-class, 8: 0.75 vs 1.24 ms this way; 4: 0.81 -> 0.60 --, and 1 for
+// the backward solve beside a subtree launch -- parabolic_fem-class, 4: 0.79 vs 0.86 ms)
 static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward) {
-    return (backward ? pl->S.solve_one_back : pl->S.solve_one) && nrhs <= kOneMaxRhs;
+    if (!(backward ? pl->S.solve_one_back : pl->S.solve_one)) return false;
+    const size_t nblocks = backward ? pl->S.one_back().sn.size() : pl->S.one_f.sn.size();
+    const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks) ? kOneMaxRhs : (backward && pl->S.one_subtrees) ? 1 : 4;
+    return nrhs <= max_rhs;
 }
 
 // The buffers of the ONE-launch solves, made by the first of them: per direction two hand-off buffers (forward: one
@@ -356,7 +375,7 @@ static int one_begin(parsy_plan* pl, bool backward, int nrhs, hipStream_t stream
         pl->one_state = nullptr;
     }
     if (!pl->one_y) pl->one_cap = std::max(pl->one_cap, want);
-    const size_t lf = (size_t)std::max<int64_t>(pl->S.one_nslots, 1) * pl->one_cap, lb = (size_t)pl->S.n * pl->one_cap;
+    const size_t lf = (size_t)pl->dp.one_f.nslots * pl->one_cap, lb = (size_t)pl->S.n * pl->one_cap;
     if (!pl->one_y || !pl->one_state) {
         // (one allocation for both: a failure leaves nothing behind)
         if (pl->one_y) (void)hipFree(pl->one_y);
@@ -411,14 +430,16 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     }
     const int64_t need = (int64_t)ldx * nrhs;
     if (solve_takes_one_launch(pl, nrhs, true)) {
-        // a small plan: the whole solve is one launch (k_bsolve_one)
+        // the whole solve -- or everything above the subtree launch, which follows -- is ONE launch (k_bsolve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
         if (one_begin(pl, true, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
-        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
-        launch_bsolve_one(pl->dp, (int)pl->S.one_sn.size(), pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
+        profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->dp.one_b.nblocks);
+        launch_bsolve_one(pl->dp, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
+        if (pl->S.one_subtrees && pl->S.n_bsolve_subtrees > 0)
+            run_range(pl, pl->S.bsolve, pl->S.bsolve.size() - 1, pl->S.bsolve.size(), nullptr, d_L, d_x, nrhs, ldx, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
@@ -591,14 +612,16 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         return -1;
     }
     if (solve_takes_one_launch(pl, nrhs, false)) {
-        // a small plan: the whole solve is one launch (k_solve_one)
+        // the whole solve -- or everything above the subtree launch, which comes first -- is ONE launch (k_solve_one)
         double *y = nullptr, *y_next = nullptr;
         int *st = nullptr, *st_next = nullptr;
         if (one_begin(pl, false, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
-        profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, (int)pl->S.one_sn.size());
-        launch_solve_one(pl->dp, (int)pl->S.one_sn.size(), std::max<int64_t>(pl->S.one_nslots, 1), d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
+        pl->solve_ldq = 0;
+        if (pl->S.one_subtrees && pl->S.n_solve_subtrees > 0) run_range(pl, pl->S.solve, 0, 1, nullptr, d_L, d_x, nrhs, ldx, stream);
+        profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, pl->dp.one_f.nblocks);
+        launch_solve_one(pl->dp, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -48,13 +48,17 @@ struct DevicePattern {           // device copies of Schedule arrays
     int* sinfo = nullptr;        // status of the last solve: 0 ok, < 0 a hand-off wait timed out (own word: a solve
                                  // never touches the factorization's status)
     int* stickets = nullptr;     // one counter per chain launch of the forward / backward solve
-    // ONE-launch solves of small plans (Schedule::solve_one)
-    const SnDesc* one_sn = nullptr;         // forward: the block columns (<= 64 columns each) in ticket order
-    const int64_t* one_slot0 = nullptr;     // ... and the first hand-off slot of each
-    const int32_t* one_wleft = nullptr;     // ... and the columns of its supernode from its first column on
-    const int32_t* one_pull_ptr = nullptr;  // forward: per supernode its gather list [ptr[t], ptr[t + 1]) of
-    const int32_t* one_pull_slot = nullptr; // ... (slot of the hand-off buffer,
-    const int32_t* one_pull_pos = nullptr;  //      column of the supernode)
+    // ONE-launch solves (Schedule::OneLists; one_b = one_f where the backward solve shares the forward lists)
+    struct OneDev {
+        const SnDesc* sn = nullptr;          // the block columns (<= 64 columns each) in ticket order
+        const int64_t* slot0 = nullptr;      // the first hand-off slot of each
+        const int32_t* wleft = nullptr;      // the columns of its supernode from its first column on
+        const int32_t* pull_ptr = nullptr;   // per block its gather list [ptr[p], ptr[p + 1]) of
+        const int32_t* pull_slot = nullptr;  // ... (slot of the hand-off buffer,
+        const int32_t* pull_pos = nullptr;   //      column of the block)
+        int nblocks = 0;
+        int64_t nslots = 1;
+    } one_f, one_b;
 };
 
 // lValues[a_dst[q]] = values[q]
@@ -73,9 +77,9 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
                         double* x, int nrhs, int ldx, int ldq, hipStream_t stream);
 // (y: the hand-off buffer armed for this solve -- forward: nslots x cap, backward: n x cap values, cap = 1, 4 or 8 right-hand sides --,
 // y_next: the one this solve arms for the next of its kind; state / state_next: {status, ticket} likewise)
-void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
+void launch_solve_one(const DevicePattern& P, const double* L, double* x, int nrhs, int ldx,
                       double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream);
-void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
+void launch_bsolve_one(const DevicePattern& P, int n, const double* L, double* x, int nrhs, int ldx,
                        double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream);
 void launch_solve_panel(const DevicePattern& P, int first, int count, const double* L, double* x,
                         double* xscratch, int nrhs, int ldx, hipStream_t stream);

@@ -1214,31 +1214,20 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     build_solve_one(S, active != nullptr || active_pieces != nullptr);
 }
 
-// ONE-launch solves of small plans (schedule.hpp: Schedule::solve_one).  Forward: the supernodes are taken block column
-// by block column (<= 64 columns: one_sn, a window of the supernode's panel like a piece of the Cholesky view); what
-// block p subtracts from the x of a row below its columns -- a later column of its supernode or a row of an ancestor --
-// goes into slot one_slot0[p] + (row - w) of a hand-off buffer (written once, so the data can be its own flag); the
-// block that owns that row gathers its slots -- listed here per owner: (slot, column of the owner).  Backward: the same
-// blocks from the last one to the first.  PARSY_SOLVE_ONE=0: never, 2: whatever the size (tests).
-static void build_solve_one(Schedule& S, bool sharded) {
+// ONE-launch solves (schedule.hpp: Schedule::OneLists).  The lists of the launch that holds the supernodes of `member`:
+// the supernodes are taken block column by block column (<= 64 columns, a window of the supernode's panel like a piece of
+// the Cholesky view); what block p subtracts from the x of a row below its columns -- a later column of its supernode or
+// a row of an ancestor -- goes into slot slot0[p] + (row - w) of a hand-off buffer (written once, so the data can be its
+// own flag); the block that owns that row gathers its slots -- listed here per owner: (slot, column of the owner).
+static void build_one_lists(const Schedule& S, const std::vector<uint8_t>& member, Schedule::OneLists& O) {
     const int ns = S.nsuper;
-    S.solve_one = S.solve_one_back = false;
-    S.one_sn.clear();
-    S.one_slot0.clear();
-    S.one_nslots = 0;
-    S.one_pull_ptr.clear();
-    S.one_pull_slot.clear();
-    S.one_pull_pos.clear();
-    S.one_wleft.clear();
-    const int mode = env_int("PARSY_SOLVE_ONE", 1);
-    if (mode == 0 || sharded || ns == 0 || (int)S.levelSet.size() != ns) return;   // (a rank's share of the supernodes: level launches)
-    if (mode == 1 && (S.xsize > kOneMaxEntries || ns > 2 * kOneMaxSupernodes ||
-                      (ns > kOneMaxSupernodes && S.xsize < kOneLargeEntries * (int64_t)ns)))
-        return;
+    O.clear();
+    O.member = member;
     // the blocks in ticket order: level by level, a supernode's block columns from left to right
     std::vector<int32_t> blk_of_col((size_t)S.n, -1), blk_sn;
     for (int q = 0; q < ns; ++q) {
         const int t = S.levelSet[(size_t)q];
+        if (!member[(size_t)t]) continue;
         const SnDesc& T = S.sn[t];
         for (int cb = 0; cb < T.w; cb += kTile) {
             SnDesc B = T;
@@ -1248,45 +1237,78 @@ static void build_solve_one(Schedule& S, bool sharded) {
             B.px = T.px + (int64_t)cb * T.r + cb;
             B.pi = T.pi + cb;
             B.ld = T.r;
-            for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = (int32_t)S.one_sn.size();
-            S.one_slot0.push_back(S.one_nslots);
-            S.one_wleft.push_back(T.w - cb);
-            S.one_nslots += B.r - B.w;
-            S.one_sn.push_back(B);
+            for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = (int32_t)O.sn.size();
+            O.slot0.push_back(O.nslots);
+            O.wleft.push_back(T.w - cb);
+            O.nslots += B.r - B.w;
+            O.sn.push_back(B);
             blk_sn.push_back(t);
         }
     }
-    const int nb = (int)S.one_sn.size();
-    if (S.one_nslots > INT32_MAX / 2) {
-        S.one_sn.clear();
-        return;
-    }
+    const int nb = (int)O.sn.size();
+    if (O.nslots > INT32_MAX / 2) throw std::runtime_error("schedule: too many hand-off slots for a ONE-launch solve");
     // column of the row k (counted inside block p's window of the panel): a later column of the supernode, or lR
     auto col_of = [&](int p, int k) {
         const SnDesc& T = S.sn[blk_sn[(size_t)p]];
-        const int kk = (S.one_sn[(size_t)p].c0 - T.c0) + k;   // row of the supernode's panel
+        const int kk = (O.sn[(size_t)p].c0 - T.c0) + k;   // row of the supernode's panel
         return kk < T.w ? T.c0 + kk : S.rows[(size_t)T.pi + kk];
     };
-    S.one_pull_ptr.assign((size_t)nb + 1, 0);
+    O.pull_ptr.assign((size_t)nb + 1, 0);
     for (int p = 0; p < nb; ++p)
-        for (int k = S.one_sn[(size_t)p].w; k < S.one_sn[(size_t)p].r; ++k) {
+        for (int k = O.sn[(size_t)p].w; k < O.sn[(size_t)p].r; ++k) {
             const int owner = blk_of_col[(size_t)col_of(p, k)];
-            if (owner <= p) throw std::runtime_error("schedule: a row below a block's columns is not owned by a later block");
-            S.one_pull_ptr[(size_t)owner + 1]++;
+            if (owner <= p) throw std::runtime_error("schedule: a row below a block's columns is not owned by a later block of the launch");
+            O.pull_ptr[(size_t)owner + 1]++;
         }
-    for (int p = 0; p < nb; ++p) S.one_pull_ptr[(size_t)p + 1] += S.one_pull_ptr[(size_t)p];
-    S.one_pull_slot.resize((size_t)S.one_pull_ptr[(size_t)nb]);
-    S.one_pull_pos.resize(S.one_pull_slot.size());
-    std::vector<int32_t> at(S.one_pull_ptr.begin(), S.one_pull_ptr.end() - 1);
+    for (int p = 0; p < nb; ++p) O.pull_ptr[(size_t)p + 1] += O.pull_ptr[(size_t)p];
+    O.pull_slot.resize((size_t)O.pull_ptr[(size_t)nb]);
+    O.pull_pos.resize(O.pull_slot.size());
+    std::vector<int32_t> at(O.pull_ptr.begin(), O.pull_ptr.end() - 1);
     for (int p = 0; p < nb; ++p)
-        for (int k = S.one_sn[(size_t)p].w; k < S.one_sn[(size_t)p].r; ++k) {
+        for (int k = O.sn[(size_t)p].w; k < O.sn[(size_t)p].r; ++k) {
             const int col = col_of(p, k), owner = blk_of_col[(size_t)col];
             const int32_t e = at[(size_t)owner]++;
-            S.one_pull_slot[(size_t)e] = (int32_t)(S.one_slot0[(size_t)p] + (k - S.one_sn[(size_t)p].w));
-            S.one_pull_pos[(size_t)e] = col - S.one_sn[(size_t)owner].c0;
+            O.pull_slot[(size_t)e] = (int32_t)(O.slot0[(size_t)p] + (k - O.sn[(size_t)p].w));
+            O.pull_pos[(size_t)e] = col - O.sn[(size_t)owner].c0;
         }
-    S.solve_one = true;
-    S.solve_one_back = true;
+}
+
+// Which solves go into ONE launch (schedule.hpp).  PARSY_SOLVE_ONE=0: never, 1: by size, 2: whatever the size (tests).
+static void build_solve_one(Schedule& S, bool sharded) {
+    const int ns = S.nsuper;
+    S.solve_one = S.solve_one_back = S.one_subtrees = S.one_forced = false;
+    S.one_f.clear();
+    S.one_b.clear();
+    const int mode = env_int("PARSY_SOLVE_ONE", 1);
+    if (mode == 0 || sharded || ns == 0 || (int)S.levelSet.size() != ns) return;   // (a rank's share of the supernodes: level launches)
+    // with subtree launches: the supernodes outside them (the launch must be the first of `solve` / the last of `bsolve`)
+    const bool sub = S.n_solve_subtrees > 0 || S.n_bsolve_subtrees > 0;
+    std::vector<uint8_t> mf((size_t)ns, 1), mb((size_t)ns, 1);
+    int64_t nf = ns, nbk = ns;
+    if (sub) {
+        nf = nbk = 0;
+        for (int t = 0; t < ns; ++t) {
+            mf[(size_t)t] = S.solve_subtree[t] < 0;
+            mb[(size_t)t] = S.bsolve_subtree[t] < 0;
+            nf += mf[(size_t)t];
+            nbk += mb[(size_t)t];
+        }
+        int nfused_f = 0, nfused_b = 0;
+        for (const Launch& l : S.solve) nfused_f += l.fused == 2 && l.kind == kLaunchSolveSmall;
+        for (const Launch& l : S.bsolve) nfused_b += l.fused == 2 && l.kind == kLaunchBackBlock;
+        const bool first_ok = nfused_f == (S.n_solve_subtrees > 0) && (nfused_f == 0 || S.solve.front().fused == 2);
+        const bool last_ok = nfused_b == (S.n_bsolve_subtrees > 0) && (nfused_b == 0 || S.bsolve.back().fused == 2);
+        if (!first_ok || !last_ok || nf == 0 || nbk == 0) return;
+    }
+    const int64_t nmax = std::max(nf, nbk);
+    if (mode == 1 && (S.xsize > kOneMaxEntries || nmax > 2 * kOneMaxSupernodes ||
+                      (nmax > kOneMaxSupernodes && S.xsize < kOneLargeEntries * (int64_t)ns)))
+        return;
+    build_one_lists(S, mf, S.one_f);
+    if (mb != mf) build_one_lists(S, mb, S.one_b);
+    S.one_subtrees = sub;
+    S.one_forced = mode == 2;
+    S.solve_one = S.solve_one_back = true;
 }
 
 int64_t simulate_chain(const Schedule& S, int slots) {
@@ -1559,74 +1581,88 @@ static void check_solve_launches(const Schedule& S, const std::function<void(con
     }
 }
 
-// The ONE-launch solves: the blocks tile the supernodes in ticket order; every row below a block's columns has a slot
-// of its own and is gathered exactly once, by the block that owns its column, at the right column, from a block with an
-// earlier ticket (the backward solve takes the same blocks in reverse order).
+// The ONE-launch solves: the members are all supernodes or -- with subtree launches -- the ones outside the direction's
+// subtree launch; the blocks tile the members in ticket order; every row below a block's columns has a slot of its own and
+// is gathered exactly once, by the block that owns its column, at the right column, from a block with an earlier ticket
+// (the backward solve takes the same blocks in reverse order).
 template <class Fail>
-static void check_solve_one(const Schedule& S, Fail&& fail) {
-    if (!S.solve_one) return;
-    const int ns = S.nsuper, nb = (int)S.one_sn.size();
-    if ((int)S.levelSet.size() != ns || (int)S.one_pull_ptr.size() != nb + 1 || (int)S.one_slot0.size() != nb ||
-        (int)S.one_wleft.size() != nb || S.one_pull_slot.size() != S.one_pull_pos.size() ||
-        (int64_t)S.one_pull_slot.size() != S.one_nslots || S.one_pull_ptr[(size_t)nb] != (int32_t)S.one_pull_slot.size()) {
-        fail("one-launch solve: lists of the wrong length");
+static void check_one_lists(const Schedule& S, const Schedule::OneLists& O, const std::vector<int32_t>* subtree, const char* dir,
+                            Fail&& fail) {
+    const int ns = S.nsuper, nb = (int)O.sn.size();
+    const std::string who = std::string("one-launch ") + dir + " solve: ";
+    if ((int)O.member.size() != ns || (int)O.pull_ptr.size() != nb + 1 || (int)O.slot0.size() != nb || (int)O.wleft.size() != nb ||
+        O.pull_slot.size() != O.pull_pos.size() || (int64_t)O.pull_slot.size() != O.nslots ||
+        O.pull_ptr[(size_t)nb] != (int32_t)O.pull_slot.size()) {
+        fail(who + "lists of the wrong length");
         return;
     }
-    // the blocks: windows of the supernodes' panels, left to right, supernodes in level order
-    std::vector<int32_t> blk_of_col((size_t)S.n, -1);
+    for (int t = 0; t < ns; ++t)
+        if ((O.member[(size_t)t] != 0) != (subtree ? (*subtree)[(size_t)t] < 0 : true))
+            fail(who + "supernode " + std::to_string(t) + " is on the wrong side of the subtree launch");
+    std::vector<int32_t> blk_of_col((size_t)S.n, -1), slot_blk((size_t)O.nslots, -1), slot_col((size_t)O.nslots, -1);
     {
         int p = 0;
         int64_t slots = 0;
         for (int q = 0; q < ns; ++q) {
-            const SnDesc& T = S.sn[S.levelSet[(size_t)q]];
-            for (int cb = 0; cb < T.w; cb += kTile, ++p) {
-                if (p >= nb) break;
-                const SnDesc& B = S.one_sn[(size_t)p];
-                if (B.c0 != T.c0 + cb || B.w != std::min(kTile, T.w - cb) || B.r != T.r - cb || B.ld != T.r ||
-                    B.px != T.px + (int64_t)cb * T.r + cb || B.pi != T.pi + cb || S.one_slot0[(size_t)p] != slots ||
-                    S.one_wleft[(size_t)p] != T.w - cb)
-                    fail("one-launch solve: block " + std::to_string(p) + " is not a block column of its supernode");
+            const int t = S.levelSet[(size_t)q];
+            if (!O.member[(size_t)t]) continue;
+            const SnDesc& T = S.sn[t];
+            for (int cb = 0; cb < T.w && p < nb; cb += kTile, ++p) {
+                const SnDesc& B = O.sn[(size_t)p];
+                const int wbk = std::min(kTile, T.w - cb);
+                if (B.c0 != T.c0 + cb || B.w != wbk || B.r != T.r - cb || B.ld != T.r || B.px != T.px + (int64_t)cb * T.r + cb ||
+                    B.pi != T.pi + cb || O.slot0[(size_t)p] != slots || O.wleft[(size_t)p] != T.w - cb)
+                    fail(who + "block " + std::to_string(p) + " is not a block column of its supernode");
+                for (int kk = cb + wbk; kk < T.r; ++kk) {
+                    slot_blk[(size_t)(slots + (kk - cb - wbk))] = p;
+                    slot_col[(size_t)(slots + (kk - cb - wbk))] = kk < T.w ? T.c0 + kk : S.rows[(size_t)T.pi + kk];
+                }
                 slots += B.r - B.w;
                 for (int c = B.c0; c < B.c0 + B.w; ++c) blk_of_col[(size_t)c] = p;
             }
         }
-        if (p != nb || slots != S.one_nslots) {
-            fail("one-launch solve: the blocks do not tile the supernodes");
+        if (p != nb || slots != O.nslots) {
+            fail(who + "the blocks do not tile the supernodes");
             return;
         }
     }
-    std::vector<int32_t> slot_blk((size_t)S.one_nslots, -1), slot_col((size_t)S.one_nslots, -1);
-    for (int p = 0; p < nb; ++p) {
-        const SnDesc& B = S.one_sn[(size_t)p];
-        for (int k = B.w; k < B.r; ++k) {
-            const int64_t slot = S.one_slot0[(size_t)p] + (k - B.w);
-            slot_blk[(size_t)slot] = p;
-        }
-    }
-    // columns of the slots through the supernodes (independent of one_sn's construction)
-    {
-        int p = 0;
-        for (int q = 0; q < ns; ++q) {
-            const SnDesc& T = S.sn[S.levelSet[(size_t)q]];
-            for (int cb = 0; cb < T.w; cb += kTile, ++p) {
-                const int wbk = std::min(kTile, T.w - cb);
-                for (int kk = cb + wbk; kk < T.r; ++kk)
-                    slot_col[(size_t)(S.one_slot0[(size_t)p] + (kk - cb - wbk))] = kk < T.w ? T.c0 + kk : S.rows[(size_t)T.pi + kk];
-            }
-        }
-    }
-    std::vector<uint8_t> seen((size_t)S.one_nslots, 0);
+    std::vector<uint8_t> seen((size_t)O.nslots, 0);
     for (int p = 0; p < nb; ++p)
-        for (int32_t e = S.one_pull_ptr[(size_t)p]; e < S.one_pull_ptr[(size_t)p + 1]; ++e) {
-            const int32_t slot = S.one_pull_slot[(size_t)e], pos = S.one_pull_pos[(size_t)e];
-            const bool in = slot >= 0 && slot < S.one_nslots;
-            if (!in || seen[(size_t)slot] || pos < 0 || pos >= S.one_sn[(size_t)p].w ||
-                slot_col[(size_t)slot] != S.one_sn[(size_t)p].c0 + pos || slot_blk[(size_t)slot] >= p) {
-                fail("one-launch solve: bad entry " + std::to_string(e) + " in the gather list of block " + std::to_string(p));
+        for (int32_t e = O.pull_ptr[(size_t)p]; e < O.pull_ptr[(size_t)p + 1]; ++e) {
+            const int32_t slot = O.pull_slot[(size_t)e], pos = O.pull_pos[(size_t)e];
+            const bool in = slot >= 0 && slot < O.nslots;
+            if (!in || seen[(size_t)slot] || pos < 0 || pos >= O.sn[(size_t)p].w || slot_col[(size_t)slot] != O.sn[(size_t)p].c0 + pos ||
+                slot_blk[(size_t)slot] >= p) {
+                fail(who + "bad entry " + std::to_string(e) + " in the gather list of block " + std::to_string(p));
                 continue;
             }
             seen[(size_t)slot] = 1;
         }
+    for (int64_t sl = 0; sl < O.nslots; ++sl)
+        if (!seen[(size_t)sl]) fail(who + "slot " + std::to_string(sl) + " is never gathered");
+}
+
+template <class Fail>
+static void check_solve_one(const Schedule& S, Fail&& fail) {
+    if (!S.solve_one) return;
+    if ((int)S.levelSet.size() != S.nsuper) {
+        fail("one-launch solve: no level sets");
+        return;
+    }
+    check_one_lists(S, S.one_f, S.one_subtrees ? &S.solve_subtree : nullptr, "forward", fail);
+    if (!S.one_b.sn.empty()) check_one_lists(S, S.one_b, S.one_subtrees ? &S.bsolve_subtree : nullptr, "backward", fail);
+    else if (S.one_subtrees)
+        for (int t = 0; t < S.nsuper; ++t)
+            if ((S.solve_subtree[t] < 0) != (S.bsolve_subtree[t] < 0)) {
+                fail("one-launch backward solve: shares the forward lists although the subtree launches differ");
+                break;
+            }
+    if (S.one_subtrees) {
+        if (S.n_solve_subtrees > 0 && (S.solve.empty() || S.solve.front().fused != 2))
+            fail("one-launch forward solve: the subtree launch is not the first launch");
+        if (S.n_bsolve_subtrees > 0 && (S.bsolve.empty() || S.bsolve.back().fused != 2))
+            fail("one-launch backward solve: the subtree launch is not the last launch");
+    }
 }
 
 int64_t check_schedule(const Schedule& S, std::string& what) {

@@ -164,12 +164,13 @@ constexpr double kDenseMinShare = 0.25;    // a BIG launch uses k_chol_dense whe
 constexpr double kDenseMinFill = 0.70;     // in a split launch an entry goes to k_chol_dense when its window holds at least this share of 128 x 128
 constexpr double kDenseAllShare = 0.06;    // ... and takes the launch's ragged entries too when they are at most this share of its products
 constexpr int kPushGroup = 1;             // pieces whose updates of the pieces further right are merged (PARSY_PUSH_GROUP)
-constexpr int kOneMaxSupernodes = 8192;         // plans of at most this many supernodes -- or twice as many when the supernodes
+constexpr int kOneMaxSupernodes = 8192;         // plans of at most this many supernodes (outside the subtree launches) -- or twice as many when the supernodes
 constexpr int64_t kOneLargeEntries = 4096;      // hold at least this many entries of L on average (a 3-D problem: 64^3 grid, 13 583
                                                 // supernodes, 1.12 -> 0.97 ms; a 500 x 500 grid, 26 092 supernodes of 600 entries, loses:
                                                 // 0.35 -> 0.46 ms, as does the parabolic_fem-class input) -- and at most
 constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries solve in ONE launch per direction (Flan-class, forced:
                                                 // 4.6 -> 7.1 ms forward, 5.8 -> 6.2 backward) when
+constexpr int kOneSmallBlocks = 1024;     // launches of at most this many blocks take up to kOneMaxRhs right-hand sides, larger ones 4
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
@@ -265,20 +266,32 @@ struct Schedule {
     int64_t n_bpart_slots = 0;             // 64 doubles each
     std::vector<Launch> bsolve;
 
-    // ONE-launch solves (k_solve_one, k_bsolve_one): a small plan's level launches are a job of launch
-    // latencies; one workgroup per block column, taken by ticket in level order, and every value handed over as the data
-    // itself (a buffer armed with a NaN pattern: the data is the flag) instead of level barriers.  Forward: block p
-    // (one_sn[p]: <= 64 columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below
-    // its columns to slot one_slot0[p] + k - w (one slot per such row, written once), and the block that owns the row
-    // gathers its slots: [one_pull_ptr[p], one_pull_ptr[p + 1]) of (slot, column of the block).  Backward (k_bsolve_one):
-    // the same blocks in reverse order; x itself is handed over (n values per right-hand side).
-    bool solve_one = false, solve_one_back = false;   // forward / backward solve (the lists are built when the first is set)
-    std::vector<SnDesc> one_sn;          // the block columns in ticket order (level by level, left to right)
-    std::vector<int64_t> one_slot0;
-    std::vector<int32_t> one_wleft;      // per block: columns of its supernode from the block's first column on (backward:
-                                         // the first one_wleft - w rows below the block are the supernode's later columns)
-    int64_t one_nslots = 0;
-    std::vector<int32_t> one_pull_ptr, one_pull_slot, one_pull_pos;
+    // ONE-launch solves (k_solve_one, k_bsolve_one): level launches of a few microseconds of work each are a job of
+    // launch latencies; instead one workgroup per block column, taken by ticket in level order, and every value handed
+    // over as the data itself (a buffer armed with a NaN pattern: the data is the flag).  Forward: block p (sn[p]: <= 64
+    // columns of a supernode, a window of its panel) writes what it subtracts from the x of row k below its columns to
+    // slot slot0[p] + k - w (one slot per such row, written once), and the block that owns the row gathers its slots:
+    // [pull_ptr[p], pull_ptr[p + 1]) of (slot, column of the block).  Backward: the same blocks in reverse order; x itself
+    // is handed over (n values per right-hand side).
+    // Which supernodes (member): all of them, or -- plans with subtree launches (one_subtrees) -- the ones outside the
+    // direction's subtree launch: forward = that launch (one wave per subtree of tiny supernodes: thousands of them are
+    // too light for a workgroup each), then the ONE launch for everything above; backward the other way round.  A member's
+    // ancestors are members, so every row below a member's columns is owned by a member.
+    struct OneLists {
+        std::vector<SnDesc> sn;           // the block columns in ticket order (level by level, left to right)
+        std::vector<int64_t> slot0;
+        std::vector<int32_t> wleft;       // per block: columns of its supernode from the block's first column on (backward:
+                                          // the first wleft - w rows below the block are the supernode's later columns)
+        int64_t nslots = 0;
+        std::vector<int32_t> pull_ptr, pull_slot, pull_pos;
+        std::vector<uint8_t> member;      // per supernode
+        void clear() { *this = OneLists(); }
+    };
+    bool solve_one = false, solve_one_back = false;   // forward / backward solve
+    bool one_subtrees = false;           // the subtree launches stay: first launch of `solve`, last of `bsolve`
+    bool one_forced = false;             // PARSY_SOLVE_ONE=2: whatever the size, and for every block of <= kOneMaxRhs right-hand sides
+    OneLists one_f, one_b;               // (one_b.sn empty: the backward solve uses one_f -- the same supernodes)
+    const OneLists& one_back() const { return one_b.sn.empty() ? one_f : one_b; }
 
     std::vector<uint8_t> active;       // per supernode, 1 = processed by the launches (solves)
     std::vector<uint8_t> active_piece; // per piece of the Cholesky view, 1 = factored by the launches

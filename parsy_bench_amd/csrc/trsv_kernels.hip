@@ -2073,12 +2073,13 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     }
 }
 
-void launch_solve_one(const DevicePattern& P, int nblocks, int64_t nslots, const double* L, double* x, int nrhs, int ldx,
-                      double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
-    if (nblocks <= 0) return;
+void launch_solve_one(const DevicePattern& P, const double* L, double* x, int nrhs, int ldx, double* y, double* y_next,
+                      int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
+    const DevicePattern::OneDev& O = P.one_f;
+    if (O.nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                               \
-    hipLaunchKernelGGL(k_solve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.one_slot0, P.one_pull_ptr,    \
-                       P.one_pull_slot, P.one_pull_pos, L, x, nrhs, ldx, nslots, y, y_next, state, state_next, wait_bias, cap)
+    hipLaunchKernelGGL(k_solve_one<NQ>, dim3(O.nblocks), dim3(kThreads), 0, stream, O.sn, O.slot0, O.pull_ptr, O.pull_slot, \
+                       O.pull_pos, L, x, nrhs, ldx, O.nslots, y, y_next, state, state_next, wait_bias, cap)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);
@@ -2366,12 +2367,13 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_block(const SnDesc* __restr
   }
 }
 
-void launch_bsolve_one(const DevicePattern& P, int nblocks, int n, const double* L, double* x, int nrhs, int ldx,
-                       double* y, double* y_next, int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
-    if (nblocks <= 0) return;
+void launch_bsolve_one(const DevicePattern& P, int n, const double* L, double* x, int nrhs, int ldx, double* y, double* y_next,
+                       int* state, int* state_next, int wait_bias, int cap, hipStream_t stream) {
+    const DevicePattern::OneDev& O = P.one_b;
+    if (O.nblocks <= 0) return;
 #define PARSY_ONE_LAUNCH(NQ)                                                                                              \
-    hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(nblocks), dim3(kThreads), 0, stream, P.one_sn, P.rows, P.one_wleft, L, x,    \
-                       nrhs, ldx, n, nblocks, y, y_next, state, state_next, wait_bias, cap)
+    hipLaunchKernelGGL(k_bsolve_one<NQ>, dim3(O.nblocks), dim3(kThreads), 0, stream, O.sn, P.rows, O.wleft, L, x, nrhs,    \
+                       ldx, n, O.nblocks, y, y_next, state, state_next, wait_bias, cap)
     if (nrhs == 1) PARSY_ONE_LAUNCH(1);
     else if (nrhs <= 4) PARSY_ONE_LAUNCH(4);
     else PARSY_ONE_LAUNCH(8);

@@ -927,6 +927,47 @@ def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
     assert plan.solve_status() == 0 and np.abs(x1 - 1.0).max() <= 1e-9
 
 
+# Plans with subtree launches (thousands of tiny supernodes, one wave per subtree): those launches stay -- first in the
+# forward solve, last in the backward one -- and the ONE launch holds everything above them.  The parabolic_fem-class input
+# takes that form by itself (forward: blocks of <= 4 right-hand sides, backward: one; PARSY_SOLVE_ONE=2: every block of <= 8);
+# forced onto others with PARSY_SUBTREES=2.
+@pytest.mark.parametrize("name,env", [("parabolic_fem", {}), ("parabolic_fem", {"PARSY_SOLVE_ONE": "2"}),
+                                      ("lap30", {"PARSY_SUBTREES": "2", "PARSY_SOLVE_ONE": "2"}),
+                                      ("nd24k", {"PARSY_SUBTREES": "2", "PARSY_SOLVE_ONE": "2"}),
+                                      ("mid3d", {"PARSY_SUBTREES": "2"}), ("ex15", {"PARSY_SUBTREES": "2"})])
+@pytest.mark.parametrize("nrhs", [1, 4, 8])
+def test_one_launch_solves_beside_the_subtree_launches(api, oracle, monkeypatch, name, env, nrhs):
+    A, perm, sym = problem(name)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    assert info["solve_one"] == 7 and info["solve_subtrees"] > 0 and plan.check() == 0
+    assert 0 < info["solve_one_blocks"]
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
+    plan0 = api.Plan(sym, 0)
+    rng = np.random.default_rng(11)
+    b1 = oracle.rhs_init_blocked(sym, lv)
+    for rep in range(2):
+        B = np.stack([b1] + [rng.standard_normal(sym.n) for _ in range(nrhs - 1)], axis=1)
+        X, _ = plan.solve(lv, B)
+        assert plan.solve_status() == 0
+        X0, _ = plan0.solve(lv, B)
+        for q in range(nrhs):
+            xo = oracle.blocked_lsolve(sym, lv, B[:, q], "serial")
+            assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+            assert np.abs(X[:, q] - X0[:, q]).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max())
+        assert np.abs(X[:, 0] - 1.0).max() <= 1e-9
+        Y = rng.standard_normal((sym.n, nrhs))
+        Z, _ = plan.solve2(lv, Y, forward=False)
+        assert plan.solve_status() == 0
+        for q in range(nrhs):
+            zo = oracle.blocked_ltsolve(sym, lv, Y[:, q])
+            assert np.abs(Z[:, q] - zo).max() <= SOLVE_TOL * max(1.0, np.abs(zo).max())
+
+
 def test_one_launch_solve_timeout_is_reported(api, oracle, monkeypatch):
     A, perm, sym = problem("ex15")
     plan = api.Plan(sym, 0)

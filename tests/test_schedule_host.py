@@ -266,10 +266,11 @@ def test_solve_launches_are_consistent(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,auto,forced", [("tiny2d", 3, 3), ("ex15", 3, 3), ("small3d", 3, 3), ("13x13x13:27", 3, 3),
-                                              ("24x24x2:27", 3, 3), ("mid3d", 3, 3), ("lap30", 3, 3), ("nd24k", 3, 3), ("parabolic_fem", 0, 3)])
+                                              ("24x24x2:27", 3, 3), ("mid3d", 3, 3), ("lap30", 3, 3), ("nd24k", 3, 3), ("parabolic_fem", 7, 7)])
 def test_one_launch_solve_lists(name, auto, forced, monkeypatch):
     """Plans of <= 8192 supernodes (16 384 when they hold >= 4096 entries on average) and <= 2^28 stored entries solve in
-    ONE launch per direction (info: bit 0 forward, bit 1 backward): that the block columns
+    ONE launch per direction (info: bit 0 forward, bit 1 backward; bit 2: only the supernodes outside the subtree launches,
+    which stay -- those are what counts then): that the block columns
     tile the supernodes in ticket order, that every row below a block's columns has its own hand-off slot and is
     gathered exactly once by the block that owns it, and the block-column runs of the backward solve are checked by
     parsy_plan_check; a rank's share of the supernodes keeps the level launches; PARSY_SOLVE_ONE=0 / 2 switch it (2:

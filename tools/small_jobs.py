@@ -35,7 +35,7 @@ for name in sys.argv[1:] or ["ex15"]:
         f = timed(lambda: plan.factor_device(values.data_ptr(), L.data_ptr(), 0), 5, 50)
         b = torch.empty(sym.n, dtype=torch.float64, device=dev)
         plan.rhs_ones_device(L.data_ptr(), b.data_ptr(), 0)
-        for nrhs in (1, 4):
+        for nrhs in [int(v) for v in os.environ.get("SMALL_JOBS_NRHS", "1,4").split(",")]:
             B = b.repeat(nrhs).contiguous()
             X = B.clone()
             fs = timed(lambda: plan.solve_device(L.data_ptr(), X.data_ptr(), nrhs, sym.n, 0), 5, 50)
