@@ -1670,7 +1670,9 @@ __device__ unsigned long long g_onestamp[4096 * 8];
 #define ONESTAMP(i) do { } while (0)
 #endif
 static constexpr int kOneRows = 256;     // rows below a block whose x the backward solve keeps in LDS
-static constexpr int kOneStage = 4096;   // doubles of a block's rows below its columns staged in LDS (larger: streamed)
+// doubles of a block's rows below its columns staged in LDS (a larger panel waits in registers); forward, by right-hand
+// sides carried: what leaves room for TWO workgroups per compute unit beside the other arrays (80 KB each)
+template <int NQ> struct OneStage { static constexpr int fwd = NQ <= 4 ? 4096 : 3584, bwd = 4096; };
 // The inverse M of a diagonal block (<= 64 x 64, column-major in Dg, identity padded to wpad), in place.  First the 16 x 16
 // diagonal sub-blocks (block_invert16), copied dense into s_m; then, block row by block row from the bottom up and inside
 // a row from right to left,
@@ -1729,7 +1731,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
     __shared__ double s_m[kTile / 16][16 * 17];   // the inverses of the 16 x 16 diagonal sub-blocks, dense (zero above the diagonal)
     __shared__ double s_b[kTile][NQ];       // the block's right-hand side minus what the gathered slots say
     __shared__ double s_x[kTile][NQ];       // its solution
-    __shared__ double s_pan[kOneStage];     // the rows below the block's columns, [c][k - w] (row stride nb | 1)
+    __shared__ double s_pan[OneStage<NQ>::fwd];     // the rows below the block's columns, [c][k - w] (row stride nb | 1)
     __shared__ int s_task;
     static_assert(4 * kTile * 8 <= kTile * kLdDiag, "the products' parts reuse Dg");
     const int tid = threadIdx.x;
@@ -1748,7 +1750,7 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
         const int q = e / kTile, c = e - q * kTile;
         s_b[c][q] = (c < w && q < nrhs) ? x[(int64_t)q * ldx + D.c0 + c] : 0.0;
     }
-    const bool staged = w * ldp <= kOneStage;
+    const bool staged = w * ldp <= OneStage<NQ>::fwd;
     if (staged)
         for (int e = tid; e < w * nb; e += kThreads) {
             const int c = e / nb, k = e - c * nb;
@@ -1916,7 +1918,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     __shared__ double s_m[kTile / 16][16 * 17];
     __shared__ double s_b[kTile][NQ];       // y_blk, then t
     __shared__ double s_xb[kOneRows][NQ];   // x of the rows below
-    __shared__ double s_pan[kOneStage + kTile];   // the rows below the block's columns, [c][k - w] (row stride nb | 1; a larger
+    __shared__ double s_pan[OneStage<NQ>::bwd + kTile];   // the rows below the block's columns, [c][k - w] (row stride nb | 1; a larger
                                                   // panel: its first 64 rows, stride 65)
     __shared__ int s_task;
     static_assert(4 * kTile * 8 <= kTile * kLdDiag, "the products' parts reuse Dg");
@@ -1935,7 +1937,7 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
         const int q = e / kTile, c = e - q * kTile;
         s_b[c][q] = (c < w && q < nrhs) ? x[(int64_t)q * ldx + D.c0 + c] : 0.0;
     }
-    const bool staged = nb <= kOneRows && w * ldp <= kOneStage;   // the panel below and the x of its rows fit in LDS
+    const bool staged = nb <= kOneRows && w * ldp <= OneStage<NQ>::bwd;   // the panel below and the x of its rows fit in LDS
     if (staged)
         for (int e = tid; e < w * nb; e += kThreads) {
             const int c = e / nb, k = e - c * nb;
