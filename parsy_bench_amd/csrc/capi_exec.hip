@@ -336,8 +336,8 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
         if (l.kind == parsy::kLaunchDense) o->dense_tasks += l.count;
     o->dense_flops = S.dense_flops;
     o->dense_entries = S.n_dense_entries;
-    o->solve_one = (S.solve_one ? 1 : 0) | (S.solve_one_back ? 2 : 0) | (S.solve_one && S.one_subtrees ? 4 : 0);
-    o->solve_one_blocks = S.solve_one ? (int32_t)S.one_f.sn.size() : 0;
+    o->solve_one = (S.solve_one ? 1 : 0) | (S.solve_one_back ? 2 : 0) | ((S.solve_one || S.solve_one_back) && S.one_subtrees ? 4 : 0);
+    o->solve_one_blocks = S.solve_one ? (int32_t)S.one_f.sn.size() : S.solve_one_back ? (int32_t)S.one_back().sn.size() : 0;
     return 0;
 }
 

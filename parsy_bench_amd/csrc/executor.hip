@@ -74,9 +74,10 @@ int plan_upload_launches(parsy_plan* pl) {
         if (S.one_b.sn.empty()) pl->dp.one_b = pl->dp.one_f;
         else if (up(S.one_b, pl->dp.one_b)) return -1;
         // (the hand-off buffers are sized by the lists: made again by the next ONE-launch solve)
-        if (pl->one_y) (void)hipFree(pl->one_y);
-        pl->one_y = nullptr;
-        pl->one_state = nullptr;
+        for (double*& q : pl->one_y) {
+            if (q) (void)hipFree(q);
+            q = nullptr;
+        }
     }
     {
         void* d = nullptr;
@@ -199,7 +200,10 @@ void plan_free(parsy_plan* pl) {
         for (void* d : pl->owned) (void)hipFree(d);
         for (void* d : pl->launch_owned) (void)hipFree(d);
         if (pl->xscratch) (void)hipFree(pl->xscratch);
-        if (pl->one_y) (void)hipFree(pl->one_y);   // (one_state lives in the same allocation)
+        for (double*& q : pl->one_y) {   // (the state words live in the same allocations)
+            if (q) (void)hipFree(q);
+            q = nullptr;
+        }
         if (pl->xt) (void)hipFree(pl->xt);
         if (pl->dinv) (void)hipFree(pl->dinv);
         if (pl->dp.bpart) (void)hipFree(pl->dp.bpart);
@@ -365,36 +369,32 @@ static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward
 // enqueue per solve, no memset.
 static int one_begin(parsy_plan* pl, bool backward, int nrhs, hipStream_t stream, double*& y, double*& y_next, int*& st,
                      int*& st_next) {
-    // (the buffers hold 1, 4 or 8 right-hand sides -- nd24k-class: 12.5 MB per right-hand side for the forward slots --
-    // and are made again, larger, when a wider block comes: earlier solves on the stream are complete by then)
+    // (a direction's buffers hold 1, 4 or 8 right-hand sides -- nd24k-class: 12.5 MB per right-hand side for the forward
+    // slots -- and are made again, larger, when a wider block comes: earlier solves on the stream are complete by then)
+    const int d = backward ? 1 : 0;
     const int want = nrhs == 1 ? 1 : nrhs <= 4 ? 4 : kOneMaxRhs;
-    if (want > pl->one_cap && pl->one_y) {
+    if (want > pl->one_cap[d] && pl->one_y[d]) {
         PARSY_HIP(hipStreamSynchronize(stream));
-        (void)hipFree(pl->one_y);
-        pl->one_y = nullptr;
-        pl->one_state = nullptr;
+        (void)hipFree(pl->one_y[d]);
+        pl->one_y[d] = nullptr;
     }
-    if (!pl->one_y) pl->one_cap = std::max(pl->one_cap, want);
-    const size_t lf = (size_t)pl->dp.one_f.nslots * pl->one_cap, lb = (size_t)pl->S.n * pl->one_cap;
-    if (!pl->one_y || !pl->one_state) {
-        // (one allocation for both: a failure leaves nothing behind)
-        if (pl->one_y) (void)hipFree(pl->one_y);
-        pl->one_y = nullptr;
-        pl->one_state = nullptr;
-        PARSY_HIP(hipMalloc((void**)&pl->one_y, 2 * (lf + lb) * sizeof(double) + 8 * sizeof(int)));
-        pl->one_state = reinterpret_cast<int*>(pl->one_y + 2 * (lf + lb));
-        pl->device_bytes += (int64_t)(2 * (lf + lb) * sizeof(double) + 8 * sizeof(int));
-        PARSY_HIP(solve_arm_handoff(pl->one_y, (int64_t)(2 * (lf + lb)), stream));
-        PARSY_HIP(hipMemsetAsync(pl->one_state, 0, 8 * sizeof(int), stream));
-        pl->one_calls[0] = pl->one_calls[1] = 0;
+    if (!pl->one_y[d]) {
+        pl->one_cap[d] = std::max(pl->one_cap[d], want);
+        const size_t len = (size_t)(backward ? pl->S.n : pl->dp.one_f.nslots) * pl->one_cap[d];
+        // (the two {status, ticket} pairs live behind the two buffers: one allocation)
+        PARSY_HIP(hipMalloc((void**)&pl->one_y[d], 2 * len * sizeof(double) + 4 * sizeof(int)));
+        pl->device_bytes += (int64_t)(2 * len * sizeof(double) + 4 * sizeof(int));
+        PARSY_HIP(solve_arm_handoff(pl->one_y[d], (int64_t)(2 * len), stream));
+        PARSY_HIP(hipMemsetAsync(pl->one_y[d] + 2 * len, 0, 4 * sizeof(int), stream));
+        pl->one_calls[d] = 0;
     }
-    const unsigned k = pl->one_calls[backward]++ & 1u;
-    double* base = backward ? pl->one_y + 2 * lf : pl->one_y;
-    const size_t len = backward ? lb : lf;
-    y = base + k * len;
-    y_next = base + (k ^ 1u) * len;
-    st = pl->one_state + (backward ? 4 : 0) + 2 * k;
-    st_next = pl->one_state + (backward ? 4 : 0) + 2 * (k ^ 1u);
+    const size_t len = (size_t)(backward ? pl->S.n : pl->dp.one_f.nslots) * pl->one_cap[d];
+    int* state = reinterpret_cast<int*>(pl->one_y[d] + 2 * len);
+    const unsigned k = pl->one_calls[d]++ & 1u;
+    y = pl->one_y[d] + k * len;
+    y_next = pl->one_y[d] + (k ^ 1u) * len;
+    st = state + 2 * k;
+    st_next = state + 2 * (k ^ 1u);
     pl->solve_status_word = st;
     const char* stall = std::getenv("PARSY_DEBUG_SOLVE_STALL");
     pl->solve_wait_bias = (stall && stall[0] == '1') ? (1 << 20) : 0;
@@ -437,7 +437,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
         profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->dp.one_b.nblocks);
-        launch_bsolve_one(pl->dp, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
+        launch_bsolve_one(pl->dp, pl->S.n, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap[1], stream);
         if (pl->S.one_subtrees && pl->S.n_bsolve_subtrees > 0)
             run_range(pl, pl->S.bsolve, pl->S.bsolve.size() - 1, pl->S.bsolve.size(), nullptr, d_L, d_x, nrhs, ldx, stream);
         run_end(pl, stream);
@@ -621,7 +621,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         pl->solve_ldq = 0;
         if (pl->S.one_subtrees && pl->S.n_solve_subtrees > 0) run_range(pl, pl->S.solve, 0, 1, nullptr, d_L, d_x, nrhs, ldx, stream);
         profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, pl->dp.one_f.nblocks);
-        launch_solve_one(pl->dp, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap, stream);
+        launch_solve_one(pl->dp, d_L, d_x, nrhs, ldx, y, y_next, st, st_next, pl->solve_wait_bias, pl->one_cap[0], stream);
         run_end(pl, stream);
         PARSY_HIP(hipGetLastError());
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));

@@ -32,10 +32,9 @@ struct parsy_plan {
     int64_t xscratch_len = 0;
     // ONE-launch solves (Schedule::solve_one): per direction two hand-off buffers (a solve works through the one its
     // predecessor armed and arms the other: no memset between solves) and two {status, ticket} pairs, used in turn
-    double* one_y = nullptr;
-    int* one_state = nullptr;
-    unsigned one_calls[2] = {0, 0};   // forward, backward
-    int one_cap = 0;                  // right-hand sides the buffers are made for (1, 4 or 8: grown on demand)
+    double* one_y[2] = {nullptr, nullptr};   // forward, backward: two buffers + the two state pairs behind them
+    unsigned one_calls[2] = {0, 0};
+    int one_cap[2] = {0, 0};                 // right-hand sides the buffers are made for (1, 4 or 8: grown on demand)
     const int* solve_status_word = nullptr;   // where the last solve left its status (null: dp.sinfo)
 
     // buffers of the host-convenience calls

@@ -170,6 +170,7 @@ constexpr int64_t kOneLargeEntries = 4096;      // hold at least this many entri
                                                 // 0.35 -> 0.46 ms, as does the parabolic_fem-class input) -- and at most
 constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries solve in ONE launch per direction (Flan-class, forced:
                                                 // 4.6 -> 7.1 ms forward, 5.8 -> 6.2 backward) when
+constexpr int kOneMaxSupernodesBack = 32768;    // the backward solve above a subtree launch: up to this many supernodes outside it
 constexpr int kOneSmallBlocks = 1024;     // launches of at most this many blocks take up to kOneMaxRhs right-hand sides, larger ones 4
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...

@@ -1876,7 +1876,8 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
                         for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[c], s_x[c][q], acc[q]);
                     }
             } else {
-                for (int c0 = 0; c0 < w; c0 += 8) {   // (eight loads in flight per thread)
+                for (int c0 = 0; c0 < w; c0 += 8) {   // (eight loads in flight per thread; all 64 at once measured slower:
+                                                      // nd24k-class 0.335 -> 0.439 ms)
                     double lv[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) lv[i] = G[(int64_t)min(c0 + i, w - 1) * ld + w + k];
@@ -1954,18 +1955,19 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
             s_pan[c * ldn + k] = G[(int64_t)c * ld + w + k];
         }
     const int wave = tid >> 6, lane = tid & 63;
-    constexpr int kPc = kTile / (kThreads / 64), kPr = kOneRows / 64;   // columns per wave, rows per lane of a chunk
-    double pre[kPc][kPr];
-    auto preload = [&](int k0) {
+    // (chunks of kOneRows / 2 rows, two register sets: the loads of the chunk after are in flight while one is multiplied)
+    constexpr int kChunk = kOneRows / 2, kPc = kTile / (kThreads / 64), kPr = kChunk / 64;   // columns per wave, rows per lane
+    double pre[2][kPc][kPr];
+    auto preload = [&](double (&dst)[kPc][kPr], int k0) {
 #pragma unroll
         for (int ci = 0; ci < kPc; ++ci) {
             const double* __restrict__ col = G + (int64_t)min(wave + (kThreads / 64) * ci, w - 1) * ld + w;
 #pragma unroll
-            for (int j = 0; j < kPr; ++j) pre[ci][j] = col[min(k0 + lane + 64 * j, nb - 1)];
+            for (int j = 0; j < kPr; ++j) dst[ci][j] = col[min(k0 + lane + 64 * j, nb - 1)];
         }
     };
-    const int nfar = nb - near, nchunks = (nfar + kOneRows - 1) / kOneRows;   // (0 when staged)
-    if (nchunks > 0) preload(near + (nchunks - 1) * kOneRows);
+    const int nfar = nb - near, nchunks = (nfar + kChunk - 1) / kChunk;   // (0 when staged)
+    if (nchunks > 0) preload(pre[0], near + (nchunks - 1) * kChunk);
     const int wpad = (w + 15) & ~15;
     for (int e = tid; e < wpad * wpad; e += kThreads) {
         const int c = e / wpad, i = e - c * wpad;
@@ -1988,13 +1990,37 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
             for (int q = 0; q < NQ; ++q) s_xb[k][q] = q < nrhs ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok) : 0.0;
         }
     };
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
-        const int k0 = near + ch * kOneRows, len = min(kOneRows, nb - k0);
-        if (ch < nchunks - 1) {
-            __syncthreads();   // (the chunk before is consumed)
-            preload(k0);
+    // far chunks, the farthest first; step i uses register set i & 1 and the half i & 1 of s_xb, and asks for the chunk
+    // after it -- its part of L and, with a PLAIN load, its x -- before it multiplies (one barrier per chunk: the half
+    // written next was read two steps ago).  The plain load is the fast path: far rows were published long ago and the
+    // line is in the L2 for every block that reads it; it can only see the armed pattern too early (a line cached before
+    // the value was stored: values of earlier solves do not survive the launch boundary), and then the poll takes over.
+    double xv[2][NQ];
+    double facc[kPc];
+#pragma unroll
+    for (int ci = 0; ci < kPc; ++ci) facc[ci] = 0.0;
+    auto x_ahead = [&](double (&dst)[NQ], int ch) {
+        const int k0 = near + ch * kChunk, k = min(k0 + (tid & (kChunk - 1)), nb - 1);
+        const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dst[q] = q < nrhs ? y[(int64_t)q * n + row] : 0.0;
+    };
+    if (nchunks > 0) x_ahead(xv[0], nchunks - 1);
+    auto far_step = [&](double (&cur)[kPc][kPr], double (&nxt)[kPc][kPr], double (&xc)[NQ], double (&xn)[NQ], int step) {
+        const int ch = nchunks - 1 - step, k0 = near + ch * kChunk, len = min(kChunk, nb - k0), half = (step & 1) * kChunk;
+        if (ch > 0) {
+            preload(nxt, near + (ch - 1) * kChunk);
+            x_ahead(xn, ch - 1);
         }
-        gather(k0, len);
+        if (tid < len) {
+            const int row = w + k0 + tid < w_left ? D.c0 + w + k0 + tid : ri[w + k0 + tid];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double v = xc[q];
+                if (q < nrhs && __double_as_longlong(v) == kXArmed) v = one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok);
+                s_xb[half + tid][q] = v;
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int ci = 0; ci < kPc; ++ci) {
@@ -2007,18 +2033,36 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
                 const int k = lane + 64 * j;
                 if (k < len) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[ci][j], s_xb[k][q], acc[q]);
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(cur[ci][j], s_xb[half + k][q], acc[q]);
                 }
             }
+            if (NQ == 1) {
+                facc[ci] += acc[0];   // (one right-hand side: the lanes' parts are added up once, after the last chunk)
+            } else {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+                for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+                    for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+                }
+                if (lane == 0 && c < w) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];   // (column c belongs to this wave alone)
+                }
             }
-            if (lane == 0 && c < w) {
+        }
+    };
+    for (int step = 0; step < nchunks; step += 2) {
+        far_step(pre[0], pre[1], xv[0], xv[1], step);
+        if (step + 1 < nchunks) far_step(pre[1], pre[0], xv[1], xv[0], step + 1);
+    }
+    if (NQ == 1 && nchunks > 0) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) s_b[c][q] -= acc[q];   // (column c belongs to this wave alone)
-            }
+        for (int ci = 0; ci < kPc; ++ci) {
+            double v = facc[ci];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            const int c = wave + (kThreads / 64) * ci;
+            if (lane == 0 && c < w) s_b[c][0] -= v;
         }
     }
     if (near > 0) {
