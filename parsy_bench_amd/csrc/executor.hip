@@ -354,11 +354,13 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
 // (one: a ONE-launch solve -- its counters follow the status word; no flags, epochs or chain tickets)
 // (how many right-hand sides: 8 where the launch has at most kOneSmallBlocks blocks -- ex15-class, 8: 0.130 -> 0.087 ms --, else
 // 4 -- from 6 on the level launches use the matrix cores: nd24k-class, 8: 0.75 vs 1.24 ms this way; 4: 0.81 -> 0.60 --, and 1 for
-// the backward solve beside a subtree launch -- parabolic_fem-class, 4: 0.79 vs 0.86 ms)
+// the backward solve beside a subtree launch -- parabolic_fem-class, 4: 0.79 vs 0.86 ms -- and for the much larger plans)
 static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward) {
     if (!(backward ? pl->S.solve_one_back : pl->S.solve_one)) return false;
     const size_t nblocks = backward ? pl->S.one_back().sn.size() : pl->S.one_f.sn.size();
-    const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks) ? kOneMaxRhs : (backward && pl->S.one_subtrees) ? 1 : 4;
+    const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks) ? kOneMaxRhs
+                        : (pl->S.one_big || (backward && pl->S.one_subtrees))    ? 1
+                                                                                 : 4;
     return nrhs <= max_rhs;
 }
 

@@ -1276,7 +1276,7 @@ static void build_one_lists(const Schedule& S, const std::vector<uint8_t>& membe
 // Which solves go into ONE launch (schedule.hpp).  PARSY_SOLVE_ONE=0: never, 1: by size, 2: whatever the size (tests).
 static void build_solve_one(Schedule& S, bool sharded) {
     const int ns = S.nsuper;
-    S.solve_one = S.solve_one_back = S.one_subtrees = S.one_forced = false;
+    S.solve_one = S.solve_one_back = S.one_subtrees = S.one_forced = S.one_big = false;
     S.one_f.clear();
     S.one_b.clear();
     const int mode = env_int("PARSY_SOLVE_ONE", 1);
@@ -1304,10 +1304,11 @@ static void build_solve_one(Schedule& S, bool sharded) {
         return S.xsize <= kOneMaxEntries && members <= 2 * kOneMaxSupernodes &&
                (members <= kOneMaxSupernodes || S.xsize >= kOneLargeEntries * (int64_t)ns);
     };
-    const bool ok_f = mode == 2 || fits(nf);
-    // (the backward solve also above the subtree launch of a much larger plan: Flan-class, 15 000 supernodes outside it,
-    // 5.76 -> 5.14 ms; the forward solve loses there: 4.59 -> 4.91)
-    const bool ok_b = mode == 2 || fits(nbk) || (sub && nbk <= kOneMaxSupernodesBack);
+    // (also above the subtree launch of a much larger plan, one right-hand side at a time: Flan-class, 15 000 supernodes outside
+    // it, backward 5.76 -> 4.55 ms, forward 4.59 -> 4.27)
+    const bool ok_f = mode == 2 || fits(nf) || (sub && nf <= kOneMaxSupernodesBig);
+    const bool ok_b = mode == 2 || fits(nbk) || (sub && nbk <= kOneMaxSupernodesBig);
+    S.one_big = mode != 2 && (!fits(nf) || !fits(nbk));
     if (!ok_f && !ok_b) return;
     if (ok_f) build_one_lists(S, mf, S.one_f);
     if (ok_b && (!ok_f || mb != mf)) build_one_lists(S, mb, S.one_b);

@@ -170,7 +170,7 @@ constexpr int64_t kOneLargeEntries = 4096;      // hold at least this many entri
                                                 // 0.35 -> 0.46 ms, as does the parabolic_fem-class input) -- and at most
 constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries solve in ONE launch per direction (Flan-class, forced:
                                                 // 4.6 -> 7.1 ms forward, 5.8 -> 6.2 backward) when
-constexpr int kOneMaxSupernodesBack = 32768;    // the backward solve above a subtree launch: up to this many supernodes outside it
+constexpr int kOneMaxSupernodesBig = 32768;     // above a subtree launch, one right-hand side at a time: up to this many supernodes outside it
 constexpr int kOneSmallBlocks = 1024;     // launches of at most this many blocks take up to kOneMaxRhs right-hand sides, larger ones 4
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
@@ -290,6 +290,7 @@ struct Schedule {
     };
     bool solve_one = false, solve_one_back = false;   // forward / backward solve
     bool one_subtrees = false;           // the subtree launches stay: first launch of `solve`, last of `bsolve`
+    bool one_big = false;                // taken by the rule for much larger plans: one right-hand side at a time
     bool one_forced = false;             // PARSY_SOLVE_ONE=2: whatever the size, and for every block of <= kOneMaxRhs right-hand sides
     OneLists one_f, one_b;               // (one_b.sn empty: the backward solve uses one_f -- the same supernodes)
     const OneLists& one_back() const { return one_b.sn.empty() ? one_f : one_b; }

@@ -1817,6 +1817,9 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
     }
     __syncthreads();
     ONESTAMP(3);
+    auto publish = [&](int k, int q, double v) {
+        __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // ---- what this block subtracts from the rows below its columns: published, one slot per row.  Up to 256 staged
     // rows: the columns are dealt over P = 4 / 2 / 1 groups of threads, the parts added up through LDS
     const int nbp = (nb + 63) & ~63;
@@ -1857,43 +1860,98 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
                     __hip_atomic_store(&y[(int64_t)q * nslots + s0 + kk], unarmed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    } else {
+    } else if (staged) {
         for (int k = tid; k < nb; k += kThreads) {
             double acc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-            if (staged) {
-                for (int c = 0; c < w; ++c) {
-                    const double lv = s_pan[c * ldp + k];
+            for (int c = 0; c < w; ++c) {
+                const double lv = s_pan[c * ldp + k];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_x[c][q], acc[q]);
-                }
-            } else if (k == tid) {
-#pragma unroll
-                for (int c = 0; c < kTile; ++c)
-                    if (c < w) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[c], s_x[c][q], acc[q]);
-                    }
-            } else {
-                for (int c0 = 0; c0 < w; c0 += 8) {   // (eight loads in flight per thread; all 64 at once measured slower:
-                                                      // nd24k-class 0.335 -> 0.439 ms)
-                    double lv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) lv[i] = G[(int64_t)min(c0 + i, w - 1) * ld + w + k];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (c0 + i < w) {
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) acc[q] = fma(lv[i], s_x[c0 + i][q], acc[q]);
-                        }
-                }
+                for (int q = 0; q < NQ; ++q) acc[q] = fma(lv, s_x[c][q], acc[q]);
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (q < nrhs)
-                    __hip_atomic_store(&y[(int64_t)q * nslots + s0 + k], unarmed(acc[q]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                if (q < nrhs) publish(k, q, acc[q]);
+        }
+    } else {
+        // a larger panel: the first 256 rows from the registers they have been waiting in ...
+        if (tid < nb) {
+            double acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int c = 0; c < kTile; ++c)
+                if (c < w) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fma(pre[c], s_x[c][q], acc[q]);
+                }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < nrhs) publish(tid, q, acc[q]);
+        }
+        // ... the rows after them in chunks of 128, two register sets (as the backward kernel's far rows): wave v takes the
+        // columns v, v + 4, ..., lane l the rows l and l + 64 of a chunk and sums its 16 columns in place; the four waves'
+        // parts meet in LDS (the inverse's place) and one thread per row publishes.  The loads of the chunk after next go
+        // out as soon as a set is multiplied.
+        if (nb > kThreads) {
+            constexpr int kChunk = 128, kPc = kTile / (kThreads / 64), kPr = kChunk / 64;
+            constexpr int kHalves = NQ <= 4 ? 2 : 1;   // (8 right-hand sides: one buffer of parts, two barriers per chunk)
+            static_assert(kHalves * (kThreads / 64) * kChunk * NQ <= kTile * kLdDiag, "the waves' parts reuse Dg");
+            const int wave = tid >> 6, lane = tid & 63;
+            const int nchunks = (nb - kThreads + kChunk - 1) / kChunk;
+            double fs[2][kPc][kPr];
+            auto fetch = [&](double (&dst)[kPc][kPr], int ch) {
+                const int k0 = kThreads + ch * kChunk;
+#pragma unroll
+                for (int ci = 0; ci < kPc; ++ci) {
+                    const double* __restrict__ col = G + (int64_t)min(wave + (kThreads / 64) * ci, w - 1) * ld + w;
+#pragma unroll
+                    for (int jr = 0; jr < kPr; ++jr) dst[ci][jr] = col[min(k0 + lane + 64 * jr, nb - 1)];
+                }
+            };
+            fetch(fs[0], 0);
+            if (nchunks > 1) fetch(fs[1], 1);
+            double* __restrict__ part = Dg;   // [half][wave][row of the chunk][q]
+            auto step = [&](double (&cur)[kPc][kPr], int ch) {
+                const int k0 = kThreads + ch * kChunk, len = min(kChunk, nb - k0);
+                const int half = (kHalves == 2 ? (ch & 1) : 0) * ((kThreads / 64) * kChunk * NQ);
+                double pr[kPr][NQ];
+#pragma unroll
+                for (int jr = 0; jr < kPr; ++jr)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) pr[jr][q] = 0.0;
+#pragma unroll
+                for (int ci = 0; ci < kPc; ++ci) {
+                    const int c = wave + (kThreads / 64) * ci;
+                    if (c < w) {
+#pragma unroll
+                        for (int jr = 0; jr < kPr; ++jr)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) pr[jr][q] = fma(cur[ci][jr], s_x[c][q], pr[jr][q]);
+                    }
+                }
+                if (ch + 2 < nchunks) fetch(cur, ch + 2);
+                if (kHalves == 1) __syncthreads();   // (the parts of the chunk before are read)
+#pragma unroll
+                for (int jr = 0; jr < kPr; ++jr)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) part[half + ((wave * kChunk) + lane + 64 * jr) * NQ + q] = pr[jr][q];
+                __syncthreads();
+                if (tid < len) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int wv = 0; wv < kThreads / 64; ++wv) v += part[half + (wv * kChunk + tid) * NQ + q];
+                        if (q < nrhs) publish(k0 + tid, q, v);
+                    }
+                }
+            };
+            for (int ch = 0; ch < nchunks; ch += 2) {
+                step(fs[0], ch);
+                if (ch + 1 < nchunks) step(fs[1], ch + 1);
+            }
         }
     }
     ONESTAMP(4);
