@@ -666,10 +666,10 @@ def main():
                     ks = pmc["kernels"]
                     # the profiled program runs as many forward (and backward) solves as factorizations; the inverse
                     # diagonal blocks are formed once per solve of either kind
-                    fwd = [v for k, v in ks.items() if k.startswith(("k_solve_small", "k_solve_tiny", "k_solve_chain"))]
+                    fwd = [v for k, v in ks.items() if k.startswith(("k_solve_small", "k_solve_tiny", "k_solve_chain", "k_solve_one"))]
                     nsolves = pmc["factorizations_in_the_profiled_run"]
                     solve_traffic = (sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in fwd) / max(nsolves, 1)
-                                     + ks["k_diag_inverse"]["hbm_bytes_per_launch"])
+                                     + ks.get("k_diag_inverse", {}).get("hbm_bytes_per_launch", 0.0))
             except (OSError, ValueError, KeyError):
                 pass
             solve_bytes = 8.0 * sym.xsize + 4.0 * sym.ssize + 16.0 * sym.n * nrhs
@@ -679,7 +679,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (solve_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s_ms > 0 else 0.0,
                 "algorithmic_bytes_per_solve": solve_bytes, "traffic": solve_traffic,
-                "traffic_unit": "HBM-side bytes per forward solve (k_diag_inverse + k_solve_tiny + k_solve_small + k_solve_chain_w, same PMC summary)",
+                "traffic_unit": "HBM-side bytes per forward solve (k_diag_inverse + k_solve_*, same PMC summary)",
                 "kind_ms_per_solve": {k: v / sruns for k, v in ps["ms"].items() if v > 0},
             }
 
@@ -693,7 +693,7 @@ def main():
                     bwd = [v for k, v in ks.items() if k.startswith("k_bsolve")]
                     nsolves = pmc["factorizations_in_the_profiled_run"]
                     back_traffic = (sum(v["read_bytes_in_run"] + v["write_bytes_in_run"] for v in bwd) / max(nsolves, 1)
-                                    + ks["k_diag_inverse"]["hbm_bytes_per_launch"])
+                                    + ks.get("k_diag_inverse", {}).get("hbm_bytes_per_launch", 0.0))
             except (OSError, ValueError, KeyError):
                 pass
             # the backward solve L' x = y reads the same bytes as the forward one: every stored value of L once, the

@@ -1304,11 +1304,12 @@ static void build_solve_one(Schedule& S, bool sharded) {
         return S.xsize <= kOneMaxEntries && members <= 2 * kOneMaxSupernodes &&
                (members <= kOneMaxSupernodes || S.xsize >= kOneLargeEntries * (int64_t)ns);
     };
-    // (also above the subtree launch of a much larger plan, one right-hand side at a time: Flan-class, 15 000 supernodes outside
-    // it, backward 5.76 -> 4.55 ms, forward 4.59 -> 4.27)
-    const bool ok_f = mode == 2 || fits(nf) || (sub && nf <= kOneMaxSupernodesBig);
+    // (the backward solve also above the subtree launch of a much larger plan, one right-hand side at a time: Flan-class, 15 000
+    // supernodes outside it, 5.76 -> 4.55 ms.  The forward solve there: 4.27 or 4.65 ms from one process to the next against
+    // 4.60 - 4.64 of the level launches, and 560 MB of hand-off slots: it stays with the level launches)
+    const bool ok_f = mode == 2 || fits(nf);
     const bool ok_b = mode == 2 || fits(nbk) || (sub && nbk <= kOneMaxSupernodesBig);
-    S.one_big = mode != 2 && (!fits(nf) || !fits(nbk));
+    S.one_big = mode != 2 && !fits(nbk);
     if (!ok_f && !ok_b) return;
     if (ok_f) build_one_lists(S, mf, S.one_f);
     if (ok_b && (!ok_f || mb != mf)) build_one_lists(S, mb, S.one_b);
