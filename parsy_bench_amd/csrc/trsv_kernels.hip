@@ -1651,6 +1651,22 @@ __device__ __forceinline__ double one_poll(const double* p, int* info, int wait_
         else __builtin_amdgcn_s_sleep(8);   // (the late ones poll at leisure)
     }
 }
+// the values of NQ right-hand sides of one slot: the loads go out together, the polls only where a value is not there yet
+// (one after the other they were NQ round trips per slot)
+template <int NQ>
+__device__ __forceinline__ void one_poll_n(const double* p, int64_t stride, int nrhs, double (&v)[NQ], int* info, int wait_bias,
+                                           bool& ok) {
+    long long b[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        b[q] = q < nrhs ? __hip_atomic_load(reinterpret_cast<const long long*>(p + (int64_t)q * stride), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT)
+                        : 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        v[q] = q >= nrhs ? 0.0 : (b[q] == kXArmed || wait_bias != 0) ? one_poll(p + (int64_t)q * stride, info, wait_bias, ok)
+                                                                     : __longlong_as_double(b[q]);
+}
 // what every workgroup of a ONE-launch solve does first: its part (entries [e0, e0 + len) per right-hand side, stride
 // ldy) of the NEXT solve's buffer is armed, and the first ticket zeroes the next solve's {status, ticket}
 __device__ __forceinline__ void one_arm_next(double* __restrict__ y_next, int* __restrict__ state_next, int64_t ldy, int64_t e0,
@@ -1782,9 +1798,11 @@ __global__ __launch_bounds__(kThreads) void k_solve_one(const SnDesc* __restrict
         for (int e = pull_ptr[t] + tid; e < pull_ptr[t + 1]; e += kThreads) {
             const int64_t slot = pull_slot[e];
             const int pos = pull_pos[e];
+            double v[NQ];
+            one_poll_n<NQ>(&y[slot], nslots, nrhs, v, state, wait_bias, ok);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (q < nrhs) unsafeAtomicAdd(&s_b[pos][q], -one_poll(&y[(int64_t)q * nslots + slot], state, wait_bias, ok));
+                if (q < nrhs) unsafeAtomicAdd(&s_b[pos][q], -v[q]);
         }
     }
     __syncthreads();
@@ -2044,8 +2062,10 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
     auto gather = [&](int k0, int len) {
         for (int k = tid; k < len; k += kThreads) {
             const int row = w + k0 + k < w_left ? D.c0 + w + k0 + k : ri[w + k0 + k];
+            double v[NQ];
+            one_poll_n<NQ>(&y[row], n, nrhs, v, state, wait_bias, ok);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) s_xb[k][q] = q < nrhs ? one_poll(&y[(int64_t)q * n + row], state, wait_bias, ok) : 0.0;
+            for (int q = 0; q < NQ; ++q) s_xb[k][q] = v[q];
         }
     };
     // far chunks, the farthest first; step i uses register set i & 1 and the half i & 1 of s_xb, and asks for the chunk
