@@ -153,6 +153,11 @@ typedef struct parsy_plan_info {
                                     * one per level (k_solve_one / k_bsolve_one): bit 0 the forward, bit 1 the backward solve;
                                     * bit 2: the subtree launch of the narrow supernodes stays beside it */
     int32_t solve_one_blocks;      /* block columns (workgroups) of the forward ONE launch */
+    int32_t sub_mrhs_trees;        /* subtrees of the solves' subtree launch for many right-hand sides (one wave per subtree and
+                                    * 16 right-hand sides, the subtree's traffic in LDS); 0: that form is not available */
+    int32_t sub_mrhs_slots;        /* ... and the LDS slots (16 right-hand sides each) of the largest */
+    int32_t sub_mrhs_tiers;        /* launches of that form per solve: the subtrees at the bottom of the etree, then bands of levels */
+    int32_t sub_mrhs_cover_level;  /* ... which replace every level launch up to this etree level (-1: only the subtree launch) */
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

@@ -58,6 +58,8 @@ class PlanInfo(C.Structure):
         ("backsolve_launches", C.c_int32), ("dense_tasks", C.c_int32),
         ("dense_flops", C.c_double), ("dense_entries", C.c_int64),
         ("solve_one", C.c_int32), ("solve_one_blocks", C.c_int32),
+        ("sub_mrhs_trees", C.c_int32), ("sub_mrhs_slots", C.c_int32),
+        ("sub_mrhs_tiers", C.c_int32), ("sub_mrhs_cover_level", C.c_int32),
     ]
 
     def as_dict(self):

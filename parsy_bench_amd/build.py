@@ -19,7 +19,7 @@ LIB = PKG / "libparsy_amd.so"
 OBJ = PKG / "build"
 
 HOST_SOURCES = ["inspector.cpp", "gen.cpp", "ordering.cpp", "capi_host.cpp", "schedule.cpp", "dist.cpp", "capi_dist.cpp"]
-HIP_SOURCES = ["executor.hip", "chol_kernels.hip", "trsv_kernels.hip", "capi_exec.hip", "mg.hip"]
+HIP_SOURCES = ["executor.hip", "chol_kernels.hip", "trsv_kernels.hip", "trsv_sub_kernels.hip", "capi_exec.hip", "mg.hip"]
 ARCH = "gfx950"
 
 

@@ -338,6 +338,10 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->dense_entries = S.n_dense_entries;
     o->solve_one = (S.solve_one ? 1 : 0) | (S.solve_one_back ? 2 : 0) | ((S.solve_one || S.solve_one_back) && S.one_subtrees ? 4 : 0);
     o->solve_one_blocks = S.solve_one ? (int32_t)S.one_f.sn.size() : S.solve_one_back ? (int32_t)S.one_back().sn.size() : 0;
+    o->sub_mrhs_trees = (int32_t)S.sub_trees.size();
+    o->sub_mrhs_slots = S.sub_max_slots;
+    o->sub_mrhs_tiers = (int32_t)S.sub_tiers.size();
+    o->sub_mrhs_cover_level = S.sub_cover_level;
     return 0;
 }
 

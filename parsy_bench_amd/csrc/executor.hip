@@ -59,6 +59,11 @@ int plan_upload_launches(parsy_plan* pl) {
         pl->dp.bpart = nullptr;
     }
     if (upload(pl, S.bsolve_pairs, pl->dp.bsolve_pairs, true)) return -1;
+    if (upload(pl, S.sub_members, pl->dp.sub_members, true) || upload(pl, S.sub_trees, pl->dp.sub_trees, true) ||
+        upload(pl, S.sub_slots, pl->dp.sub_slots, true) || upload(pl, S.sub_out_rows, pl->dp.sub_out_rows, true))
+        return -1;
+    // (trees whose workgroup would not get its LDS: the subtree launches keep the level kernels' form)
+    pl->dp.sub_ntiers = (!S.sub_tiers.empty() && solve_sub_prepare(S.sub_max_slots) == 0) ? (int)S.sub_tiers.size() : 0;
     {
         auto up = [&](const Schedule::OneLists& O, DevicePattern::OneDev& D) {
             D = DevicePattern::OneDev();
@@ -242,6 +247,13 @@ static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& c
     ++cursor;
 }
 
+// The subtree launches of a solve with this many right-hand sides take the form of one wave per subtree and 16 right-
+// hand sides (trsv_sub_kernels.hip; PARSY_SUB_MRHS_MIN, 0: never)
+static bool sub_tiers_usable(const parsy_plan* pl, int nrhs) {
+    const int m = solve_sub_mrhs_min();
+    return pl->dp.sub_ntiers > 0 && m > 0 && nrhs >= m;
+}
+
 // Enqueue the launches seq[i0, i1).  The state that orders the two streams (which level-completion events have been
 // recorded, which side launches are in flight, the profiling cursor) lives in the plan, so that a factorization can
 // be enqueued level by level (parsy_factor_level) with the caller's own work -- the exchange step of a
@@ -305,7 +317,13 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                 }
                 break;
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, l.fused != 0, L, stream); break;
-            case kLaunchSolveSmall: launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, pl->solve_ldq, stream); break;
+            case kLaunchSolveSmall:
+                // (the subtree launch with many right-hand sides: a wave per subtree and 16 right-hand sides, traffic in LDS)
+                if (l.fused == 2 && sub_tiers_usable(pl, nrhs) && pl->S.sub_tiers[0].ntrees == l.count)
+                    launch_solve_sub_mrhs(pl->dp, pl->S.sub_tiers[0], Lc, x, nrhs, ldx, pl->solve_ldq, stream);
+                else
+                    launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, pl->solve_ldq, stream);
+                break;
             case kLaunchSolvePanel:
                 if (l.fused && nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain)
                     launch_solve_blocks_mrhs(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx,
@@ -326,6 +344,10 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                 if (l.fused == 1 && nrhs == 1) {   // one right-hand side: the wave dataflow over block-column pairs
                     launch_bsolve_chain_w(pl->dp, l.lds_bytes, l.wait_level, Lc, pl->dinv, x, pl->xscratch, l.jb,
                                           pl->solve_wait_bias, stream);
+                    break;
+                }
+                if (l.fused == 2 && sub_tiers_usable(pl, nrhs) && pl->S.sub_tiers[0].ntrees == l.count) {
+                    launch_bsolve_sub_mrhs(pl->dp, pl->S.sub_tiers[0], Lc, x, nrhs, ldx, stream);
                     break;
                 }
                 launch_bsolve_block(pl->dp, l.first, l.count, Lc, pl->dinv, x, pl->xscratch, nrhs, ldx, l.fused,
@@ -474,7 +496,21 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
         launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     }
-    run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
+    if (sub_tiers_usable(pl, nrhs) && pl->S.sub_cover_level >= 0) {
+        run_begin(pl);
+        for (size_t li = 0; li < pl->S.bsolve.size(); ++li) {
+            const Launch& l = pl->S.bsolve[li];
+            if (l.fused == 2 || l.level <= pl->S.sub_cover_level) continue;
+            run_range(pl, pl->S.bsolve, li, li + 1, nullptr, d_L, d_x, nrhs, ldx, stream);
+        }
+        for (size_t k = pl->S.sub_tiers.size(); k-- > 0;) {
+            profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->S.sub_tiers[k].ntrees);
+            launch_bsolve_sub_mrhs(pl->dp, pl->S.sub_tiers[k], d_L, d_x, nrhs, ldx, stream);
+        }
+        run_end(pl, stream);
+    } else {
+        run_launches(pl, pl->S.bsolve, nullptr, d_L, d_x, nrhs, ldx, stream);
+    }
     PARSY_HIP(hipGetLastError());
     PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
     pl->epoch += passes;
@@ -678,7 +714,23 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     pl->solve_ldq = ldq;
     if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, true, stream);
-    run_launches(pl, pl->S.solve, nullptr, d_L, use_xt ? pl->xt : d_x, nrhs, ldx, stream);
+    if (sub_tiers_usable(pl, nrhs) && pl->S.sub_cover_level >= 0) {
+        // the bands of levels that are one launch each (tiers), then the level launches above them
+        double* xw = use_xt ? pl->xt : d_x;
+        run_begin(pl);
+        for (const SubTier& T : pl->S.sub_tiers) {
+            profile_mark(pl, kLaunchSolveSmall, stream, pl->run_cursor, 0, 0, T.ntrees);
+            launch_solve_sub_mrhs(pl->dp, T, d_L, xw, nrhs, ldx, ldq, stream);
+        }
+        for (size_t li = 0; li < pl->S.solve.size(); ++li) {
+            const Launch& l = pl->S.solve[li];
+            if (l.fused == 2 || l.level <= pl->S.sub_cover_level) continue;
+            run_range(pl, pl->S.solve, li, li + 1, nullptr, d_L, xw, nrhs, ldx, stream);
+        }
+        run_end(pl, stream);
+    } else {
+        run_launches(pl, pl->S.solve, nullptr, d_L, use_xt ? pl->xt : d_x, nrhs, ldx, stream);
+    }
     if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, false, stream);
     pl->solve_ldq = 0;
     PARSY_HIP(hipGetLastError());

@@ -38,6 +38,12 @@ struct DevicePattern {           // device copies of Schedule arrays
     const PanelDesc* bsolve_below = nullptr;   // k_bsolve_below tasks
     double* bpart = nullptr;                   // their partial sums (64 doubles per slot; allocated by the first backward solve)
     const PanelDesc* bsolve_blocks = nullptr;  // backward solve: (supernode, block column) per workgroup  // supernodes solved by SOLVE_CHAIN (need inverse blocks)
+    // the solves' subtree launch for many right-hand sides (Schedule::sub_*; sub_ntrees == 0: not available)
+    const SubMember* sub_members = nullptr;
+    const SubTree* sub_trees = nullptr;
+    const uint16_t* sub_slots = nullptr;
+    const int32_t* sub_out_rows = nullptr;
+    int sub_ntiers = 0;
     int* info = nullptr;         // first failed pivot column + 1 (0x7f7f7f7f = none, < 0: wait timed out)
     int* flags = nullptr;        // solve chain: per block column, epoch of the pass that published it
     int* tflags = nullptr;       // Cholesky chain: per tile, epoch of the factorization that published it
@@ -90,6 +96,14 @@ void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, cons
                               double* x, double* xscratch, int nrhs, int ldx, int ldq, int ticket, int wait_bias,
                               hipStream_t stream);
 void launch_transpose_x(double* x, int64_t ldx, double* xt, int64_t ldq, int n, int nrhs, bool to_rows, hipStream_t stream);
+// the subtree launch of a solve with many right-hand sides: one wave per (subtree, 16 right-hand sides), the subtree's
+// traffic in LDS (trsv_sub_kernels.hip); ldq > 0: X row-major with that row stride
+void launch_solve_sub_mrhs(const DevicePattern& P, const SubTier& T, const double* L, double* x, int nrhs, int ldx, int ldq,
+                           hipStream_t stream);
+void launch_bsolve_sub_mrhs(const DevicePattern& P, const SubTier& T, const double* L, double* x, int nrhs, int ldx,
+                            hipStream_t stream);
+int solve_sub_prepare(int max_slots);   // once per plan: LDS beyond 64 KB per workgroup needs the kernels' attribute (-1: refused)
+int solve_sub_mrhs_min();   // right-hand sides from which those kernels take the subtree launches (PARSY_SUB_MRHS_MIN; 0: never)
 int solve_mrhs_min();
 int solve_small_mrhs_min();
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);

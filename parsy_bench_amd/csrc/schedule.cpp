@@ -25,24 +25,30 @@ static int env_int(const char* name, int dflt) {
 // Subtrees of the etree that consist of eligible supernodes only and cost at most `cap`, as large as
 // possible: subtree[s] = its subtree (numbered from the last root down) or -1.  `parent` must be a
 // postordered forest (parent[s] > s); otherwise no subtree is formed.
+// slots (optional): per supernode (columns, rows below); a subtree's columns plus the rows below its root must not
+// exceed slot_cap (the LDS slots of the solves' subtree kernels for many right-hand sides).
 static int find_subtrees(const std::vector<int>& parent, const std::vector<uint8_t>& eligible,
-                         const std::vector<double>& cost, double cap, std::vector<int32_t>& subtree) {
+                         const std::vector<double>& cost, double cap, std::vector<int32_t>& subtree,
+                         const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr, int64_t slot_cap = 0) {
     const int ns = (int)parent.size();
     subtree.assign(ns, -1);
     std::vector<uint8_t> whole(eligible);  // the supernode and everything below it is eligible
     std::vector<double> sub(cost);
+    std::vector<int64_t> cols(slots ? ns : 0);
+    for (int s = 0; s < ns && slots; ++s) cols[s] = (*slots)[s].first;
     for (int s = 0; s < ns; ++s) {
         const int p = parent[s];
         if (p < 0) continue;
         if (p <= s) return 0;
         if (!whole[s]) whole[p] = 0;
         sub[p] += sub[s];
+        if (slots) cols[p] += cols[s];
     }
     int count = 0;
     for (int s = ns - 1; s >= 0; --s) {
         const int p = parent[s];
         if (p >= 0 && subtree[p] >= 0) subtree[s] = subtree[p];
-        else if (whole[s] && sub[s] <= cap) subtree[s] = count++;
+        else if (whole[s] && sub[s] <= cap && (!slots || cols[s] + (*slots)[s].second <= slot_cap)) subtree[s] = count++;
     }
     return count;
 }
@@ -259,12 +265,13 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
     if (per_cu > 0) {
         const int cus = compute_units > 0 ? compute_units : 256;
         std::vector<uint8_t> elig(ns, 0);
-        auto cut = [&](std::vector<double>& cost, double min_cost, std::vector<int32_t>& subtree) {
+        auto cut = [&](std::vector<double>& cost, double min_cost, std::vector<int32_t>& subtree,
+                       const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr) {
             double total = 0;
             int64_t members = 0;
             {   // everything that could be in a subtree at all
                 std::vector<int32_t> all;
-                find_subtrees(tree, elig, cost, 1e300, all);
+                find_subtrees(tree, elig, cost, 1e300, all, slots, kSubMaxSlots);
                 for (int t = 0; t < ns; ++t)
                     if (all[t] >= 0) {
                         total += cost[t];
@@ -272,7 +279,8 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                     }
             }
             if (!forced && members < (int64_t)kSubtreeMinPerSlot * per_cu * cus) return 0;
-            return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)per_cu * cus)), subtree);
+            return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)per_cu * cus)), subtree, slots,
+                                 kSubMaxSlots);
         };
         if (!S.solve_only) {
             S.chol_cost.assign(ns, 0.0);
@@ -288,11 +296,13 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         }
         S.solve_cost.assign(ns, 0.0);
         // solves: the subtrees of TINY supernodes (one wave walks one: the wave-per-supernode solve kernel)
+        std::vector<std::pair<int32_t, int32_t>> slots((size_t)ns);
         for (int t = 0; t < ns; ++t) {
             elig[t] = S.sn[t].w <= kTinyWidth;
             S.solve_cost[t] = 2e3 + (double)S.sn[t].w * S.sn[t].r;
+            slots[(size_t)t] = {S.sn[t].w, S.sn[t].r - S.sn[t].w};
         }
-        S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree);
+        S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree, &slots);
         // (the backward solve walks the same subtrees from their roots down)
         S.bsolve_subtree = S.solve_subtree;
         S.n_bsolve_subtrees = S.n_solve_subtrees;
@@ -661,6 +671,212 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
 
 static void build_solve_one(Schedule& S, bool sharded);
 
+// The lists of the solves' subtree launches for many right-hand sides (schedule.hpp: SubMember, SubTree, SubTier).
+// append_sub_tier lays out one tier from its trees (supernodes in index order: descendants first).  A row below a member
+// that is a column of a member of the same tree maps to that column's slot, any other row to the tree's list of outside
+// rows (for a whole subtree: the rows below its root).
+// Column slots are a STACK: a member's columns start where its parent's end (the root's at 0), so the slots in use at
+// any time are those of a path to the root -- the members are walked in postorder, and everything a walk has pending
+// (forward: sums for members not yet solved; backward: x of the members already solved that a later one reads) belongs
+// to the ancestors of the member in hand.  Siblings share slot numbers; the forward kernel hands a slot back as zero
+// when it reads it.  Both walks are replayed here and the tier is not made if a slot would be shared at the same time.
+static bool append_sub_tier(Schedule& S, const std::vector<std::vector<int32_t>>& trees, int top_level, int max_slots) {
+    const size_t members0 = S.sub_members.size(), trees0 = S.sub_trees.size(), slots0 = S.sub_slots.size(),
+                 outs0 = S.sub_out_rows.size();
+    auto drop = [&] {
+        S.sub_members.resize(members0);
+        S.sub_trees.resize(trees0);
+        S.sub_slots.resize(slots0);
+        S.sub_out_rows.resize(outs0);
+        return false;
+    };
+    if (trees.empty()) return false;
+    std::vector<int32_t> col_slot((size_t)S.n, -1);   // per column: its slot in the tree being laid out
+    std::vector<int32_t> out_slot((size_t)S.n, -1);   // per row: its outside slot, likewise
+    std::vector<int32_t> root_slot((size_t)S.nsuper, -1);  // per supernode of the tree: slot of its first column
+    std::vector<int32_t> owner;                       // replay: the column a slot belongs to (-1: free)
+    SubTier tier{(int32_t)trees0, 0, 0, top_level};
+    for (const std::vector<int32_t>& tree : trees) {
+        SubTree T{};
+        T.m0 = (int32_t)S.sub_members.size();
+        T.out0 = (int32_t)S.sub_out_rows.size();
+        // slots: parents before children
+        for (size_t q = tree.size(); q-- > 0;) {
+            const int32_t t = tree[q];
+            const SnDesc& D = S.sn[t];
+            const int p = S.sparent[(size_t)t];
+            const int32_t off = (p >= 0 && root_slot[(size_t)p] >= 0) ? root_slot[(size_t)p] + S.sn[p].w : 0;
+            root_slot[(size_t)t] = off;
+            for (int c = 0; c < D.w; ++c) col_slot[(size_t)D.c0 + c] = off + c;
+            T.ncols = std::max(T.ncols, off + D.w);
+        }
+        // outside rows in ascending order
+        std::vector<int32_t> outs;
+        for (int32_t t : tree) {
+            const SnDesc& D = S.sn[t];
+            for (int k = D.w; k < D.r; ++k) {
+                const int32_t row = S.rows[(size_t)D.pi + k];
+                if (col_slot[(size_t)row] < 0 && out_slot[(size_t)row] < 0) {
+                    out_slot[(size_t)row] = 0;
+                    outs.push_back(row);
+                }
+            }
+        }
+        std::sort(outs.begin(), outs.end());
+        T.nout = (int32_t)outs.size();
+        for (int32_t j = 0; j < T.nout; ++j) out_slot[(size_t)outs[(size_t)j]] = T.ncols + j;
+        S.sub_out_rows.insert(S.sub_out_rows.end(), outs.begin(), outs.end());
+        const int32_t trash = T.ncols + T.nout;
+        bool ok = trash + 1 <= max_slots && trash + 1 <= 65535;
+        // members: a supernode's 16-column blocks from left to right (row k of block j = row 16 j + k of the panel)
+        auto row_id = [&](const SnDesc& D, int k) { return k < D.w ? D.c0 + k : S.rows[(size_t)D.pi + k]; };
+        auto slot_of = [&](int32_t row) { return col_slot[(size_t)row] >= 0 ? col_slot[(size_t)row] : out_slot[(size_t)row]; };
+        for (size_t q = 0; q < tree.size() && ok; ++q) {
+            const SnDesc& D = S.sn[tree[q]];
+            for (int j0 = 0; j0 < D.w; j0 += kTinyWidth) {
+                const int wb = std::min(kTinyWidth, D.w - j0);
+                SubMember M{D.px + (int64_t)j0 * D.r + j0, D.c0 + j0, wb, D.r - j0, root_slot[(size_t)tree[q]] + j0,
+                            (int32_t)(S.sub_slots.size() / 16), D.r};
+                for (int k0 = wb; k0 < M.r; k0 += 16)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int v = 0; v < 4; ++v) {
+                            const int k = k0 + 4 * v + kq;
+                            S.sub_slots.push_back((uint16_t)(k < M.r ? slot_of(row_id(D, j0 + k)) : trash));
+                        }
+                S.sub_members.push_back(M);
+            }
+        }
+        T.m1 = (int32_t)S.sub_members.size();
+        // replay of the forward walk: a column slot is taken by the first sum that goes to it and freed when its member
+        // is solved; of the backward walk: written when its member is solved, read by the members after it
+        owner.assign((size_t)T.ncols, -1);
+        for (size_t q = 0; q < tree.size() && ok; ++q) {
+            const SnDesc& D = S.sn[tree[q]];
+            for (int c = 0; c < D.w && ok; ++c) {
+                int32_t& o = owner[(size_t)col_slot[(size_t)D.c0 + c]];
+                ok = o < 0 || o == D.c0 + c;
+                o = -1;
+            }
+            for (int k = D.w; k < D.r && ok; ++k) {
+                const int32_t row = S.rows[(size_t)D.pi + k];
+                if (col_slot[(size_t)row] < 0) continue;
+                int32_t& o = owner[(size_t)col_slot[(size_t)row]];
+                ok = o < 0 || o == row;
+                o = row;
+            }
+        }
+        for (int32_t o : owner) ok = ok && o < 0;   // (every sum was consumed: its column's member came later)
+        owner.assign((size_t)T.ncols, -1);
+        for (size_t q = tree.size(); q-- > 0 && ok;) {
+            const SnDesc& D = S.sn[tree[q]];
+            for (int k = D.w; k < D.r && ok; ++k) {
+                const int32_t row = S.rows[(size_t)D.pi + k];
+                if (col_slot[(size_t)row] >= 0) ok = owner[(size_t)col_slot[(size_t)row]] == row;
+            }
+            for (int c = 0; c < D.w; ++c) owner[(size_t)col_slot[(size_t)D.c0 + c]] = D.c0 + c;
+        }
+        for (int32_t t : tree) {
+            const SnDesc& D = S.sn[t];
+            for (int c = 0; c < D.w; ++c) col_slot[(size_t)D.c0 + c] = -1;
+            root_slot[(size_t)t] = -1;
+        }
+        for (int32_t row : outs) out_slot[(size_t)row] = -1;
+        if (!ok) return drop();
+        tier.max_slots = std::max(tier.max_slots, trash + 1);
+        S.sub_trees.push_back(T);
+    }
+    tier.ntrees = (int32_t)(S.sub_trees.size() - trees0);
+    S.sub_tiers.push_back(tier);
+    S.sub_max_slots = std::max(S.sub_max_slots, tier.max_slots);
+    return true;
+}
+
+// Tier 0: the subtrees of the forward solve's subtree launch as solve_small_list / solve_small_ranges lay them out.
+// Tiers above: bands of levels whose active supernodes are all at most kSubTierMaxWidth wide, every supernode not yet in a
+// tier in the tree of its highest ancestor inside the band; a band grows while that leaves at least kSubTierMinTrees
+// trees (PARSY_SUB_TIER_MIN_TREES; 0: no bands) whose slots fit.
+static void build_sub_tiers(Schedule& S) {
+    S.sub_members.clear();
+    S.sub_trees.clear();
+    S.sub_slots.clear();
+    S.sub_out_rows.clear();
+    S.sub_tiers.clear();
+    S.sub_max_slots = 0;
+    S.sub_cover_level = -1;
+    const int ns = S.nsuper;
+    std::vector<uint8_t> covered((size_t)ns, 0);
+    {
+        std::vector<std::vector<int32_t>> trees(S.solve_small_ranges.size() / 2);
+        for (size_t b = 0; b < trees.size(); ++b)
+            trees[b].assign(S.solve_small_list.begin() + S.solve_small_ranges[2 * b],
+                            S.solve_small_list.begin() + S.solve_small_ranges[2 * b + 1]);
+        if (trees.empty() || !append_sub_tier(S, trees, -1, kSubMaxSlots + 1)) return;
+        for (const auto& tr : trees)
+            for (int32_t t : tr) covered[(size_t)t] = 1;
+    }
+    const int min_trees = env_int("PARSY_SUB_TIER_MIN_TREES", kSubTierMinTrees);
+    if (min_trees <= 0) return;
+    std::vector<int> level((size_t)ns, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) level[(size_t)S.levelSet[q]] = l;
+    // bands may reach up to the level below the first one with a wide (or, shards: with an inactive) supernode
+    int lmax = S.nlevels - 1;
+    for (int t = 0; t < ns; ++t)
+        if (!covered[(size_t)t] && (S.sn[t].w > kSubTierMaxWidth || !S.active[t])) lmax = std::min(lmax, level[(size_t)t] - 1);
+    // (a band must also cover every level below it completely: nothing uncovered may lie under a tier-0 subtree's level)
+    auto trees_of_band = [&](int top, std::vector<std::vector<int32_t>>& trees) {
+        std::vector<int32_t> root_of((size_t)ns, -1), tree_of((size_t)ns, -1);
+        trees.clear();
+        for (int t = ns - 1; t >= 0; --t) {   // parents first
+            if (covered[(size_t)t] || level[(size_t)t] > top) continue;
+            const int p = S.sparent[(size_t)t];
+            if (p >= 0 && tree_of[(size_t)p] >= 0) tree_of[(size_t)t] = tree_of[(size_t)p];
+            else {
+                tree_of[(size_t)t] = (int32_t)trees.size();
+                trees.emplace_back();
+            }
+        }
+        for (int t = 0; t < ns; ++t)
+            if (tree_of[(size_t)t] >= 0) trees[(size_t)tree_of[(size_t)t]].push_back(t);
+    };
+    int next = 0;   // lowest level with an uncovered supernode
+    while (true) {
+        next = S.nlevels;
+        for (int t = 0; t < ns; ++t)
+            if (!covered[(size_t)t]) next = std::min(next, level[(size_t)t]);
+        if (next > lmax) break;
+        // the highest top with enough trees
+        std::vector<std::vector<int32_t>> trees, best;
+        int best_top = -1;
+        for (int top = next; top <= lmax; ++top) {
+            trees_of_band(top, trees);
+            if ((int)trees.size() < min_trees) break;
+            best.swap(trees);
+            best_top = top;
+        }
+        if (best_top < 0) break;
+        // heaviest trees first
+        std::vector<double> cost(best.size(), 0.0);
+        for (size_t b = 0; b < best.size(); ++b)
+            for (int32_t t : best[b]) cost[b] += 2e3 + (double)S.sn[t].w * S.sn[t].r;
+        std::vector<size_t> order(best.size());
+        for (size_t b = 0; b < order.size(); ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+        std::vector<std::vector<int32_t>> sorted(best.size());
+        for (size_t b = 0; b < order.size(); ++b) sorted[b].swap(best[order[b]]);
+        bool ok = append_sub_tier(S, sorted, best_top, kSubTierMaxSlots + 1);
+        while (!ok && best_top > next) {   // (slots: a lower band)
+            --best_top;
+            trees_of_band(best_top, sorted);
+            ok = append_sub_tier(S, sorted, best_top, kSubTierMaxSlots + 1);
+        }
+        if (!ok) break;
+        for (const auto& tr : sorted)
+            for (int32_t t : tr) covered[(size_t)t] = 1;
+        S.sub_cover_level = best_top;
+    }
+}
+
 void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pieces) {
     const int ns = S.nsuper;
     // PARSY_FORCE_UNFUSED=1 schedules the solve's fallback form everywhere (per-block-column
@@ -828,6 +1044,11 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     S.small_ranges.clear();
     S.solve_small_ranges.clear();
     S.bsolve_ranges.clear();
+    S.sub_members.clear();
+    S.sub_trees.clear();
+    S.sub_slots.clear();
+    S.sub_out_rows.clear();
+    S.sub_max_slots = 0;
     S.bsolve_blocks.clear();
     S.bsolve_pairs.clear();
     for (int lev = 0; lev < S.cnlevels && !S.solve_only; ++lev) {
@@ -1084,6 +1305,7 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
             }
         }
     }
+    build_sub_tiers(S);
     // ---- backward solve: root level first.  Per level one chain launch for the block columns of
     // the wide supernodes (last block column first: block jb waits for the published x of blocks
     // jb+1.. of its supernode; every workgroup of the launch must be resident) and one launch for the

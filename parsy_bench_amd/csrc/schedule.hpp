@@ -111,6 +111,42 @@ struct PanelDesc {    // one workgroup of the PANEL / SOLVE_PANEL kernels
     int32_t pad;
 };
 
+// Subtree launches of the solves with many right-hand sides (k_solve_sub_mrhs / k_bsolve_sub_mrhs): ONE WAVE walks a
+// subtree for 16 right-hand sides and keeps everything the subtree's supernodes hand to each other in LDS -- one
+// slot (16 doubles) per column of a path to the subtree's root and per row outside it that a member touches.  Forward:
+// the slots accumulate `L21 * y` (reference Triangular_BCSC.h:139-157: x[Li[l]] -= tmp[k]); a member's x block is its
+// right-hand side minus its slots, and only the outside slots leave the wave, once, as atomics.  Backward: the slots
+// hold x itself (outside rows gathered once).
+// A member is a block of at most 16 columns: a supernode, or -- wider supernodes -- one of its 16-column blocks (a
+// window of its panel: ld = rows of the supernode), the later blocks standing to the earlier ones as a parent to its
+// child.  TIERS: tier 0 = the subtrees of narrow supernodes the bottom of the etree is cut into (the subtree launch of
+// the few-right-hand-side kernels), tier k > 0 = a band of levels above, every supernode of it in the tree of its
+// highest ancestor inside the band: one launch per tier instead of one or two per level (sub_tiers).
+struct SubMember {    // in the order of the walk (index order inside a subtree)
+    int64_t px;       // offset in lValues of the block's first diagonal entry
+    int32_t c0, w, r; // first column, width (<= kTinyWidth), rows from the diagonal entry down
+    int32_t slot0;    // slot of its first column
+    int32_t so;       // first 16-row chunk of its rows below in sub_slots
+    int32_t ld;       // leading dimension of the panel
+};
+struct SubTree {      // one per workgroup of a tier's launch
+    int32_t m0, m1;   // members [m0, m1) of sub_members
+    int32_t ncols;    // slots [0, ncols): the members' columns (a stack)
+    int32_t nout;     // slots [ncols, ncols + nout): rows outside, ids sub_out_rows[out0 ..); slot ncols + nout: padding rows
+    int32_t out0;
+    int32_t pad[3];
+};
+struct SubTier {
+    int32_t tree0, ntrees;   // its trees in sub_trees
+    int32_t max_slots;       // ncols + nout + 1 of the largest
+    int32_t top_level;       // the band of etree levels it ends with (tier 0: -1 -- not a band)
+};
+constexpr int kSubMaxSlots = 320;   // subtrees of the solves are cut so that columns + outside rows of the root fit
+                                    // (x 17 doubles of LDS per wave)
+constexpr int kSubTierMaxWidth = 64;     // bands end below the first supernode wider than this ...
+constexpr int kSubTierMinTrees = 256;    // ... and where fewer trees than this would be left (PARSY_SUB_TIER_MIN_TREES)
+constexpr int kSubTierMaxSlots = 448;    // ... or a tree would need more slots
+
 enum LaunchKind : int32_t {
     kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,
     kLaunchBackBelow = 4,   // backward solve, one right-hand side: the part of a tall wide supernode's sums that comes from
@@ -223,6 +259,17 @@ struct Schedule {
     int n_chol_subtrees = 0, n_solve_subtrees = 0, n_bsolve_subtrees = 0;
     // (begin, end) pairs into small_list / solve_small_list / bsolve_blocks, one per workgroup of a subtree launch
     std::vector<int32_t> small_ranges, solve_small_ranges, bsolve_ranges;
+    // the solves' subtree launch for many right-hand sides (SubMember / SubTree above); sub_slots: per 16-row chunk of a
+    // member's rows below 16 slot numbers, entry 4 kq + v = slot of row 16 chunk + 4 v + kq (the lane order of the
+    // matrix cores' result registers)
+    std::vector<SubMember> sub_members;
+    std::vector<SubTree> sub_trees;
+    std::vector<uint16_t> sub_slots;
+    std::vector<int32_t> sub_out_rows;
+    std::vector<SubTier> sub_tiers;   // (empty: that form of the launches does not exist)
+    int sub_cover_level = -1;         // every active supernode of the levels <= this is in a tier: a solve with many right-hand
+                                      // sides skips the level launches up to it
+    int sub_max_slots = 0;            // slots of the largest tree of any tier
 
     // Cholesky launch data
     std::vector<int32_t> small_list;

@@ -1107,6 +1107,40 @@ def test_subtree_launches_match_level_launches(api, oracle, monkeypatch, name, p
             assert np.abs(Xb[:, q] - xb).max() <= SOLVE_TOL * max(1.0, np.abs(xb).max())
 
 
+# The subtree launch of a solve with many right-hand sides: one wave per (subtree, 16 right-hand sides), what the members
+# hand to each other in LDS, the outside rows as one atomic per subtree (k_solve_sub_mrhs / k_bsolve_sub_mrhs; taken from 6
+# right-hand sides on, PARSY_SUB_MRHS_MIN=0: the level kernels' subtree form).  Every column against the oracle, both forms,
+# both layouts of X.
+# Bands of levels above the subtrees take the same form (tiers: one launch per band instead of one or two per level; wider
+# supernodes as chains of 16-column blocks), by themselves where a band leaves >= 256 trees: forced here with
+# PARSY_SUB_TIER_MIN_TREES (0: the subtree launch only).
+@pytest.mark.parametrize("name,per_cu,min_trees", [("tiny2d", 1, 0), ("ex15", 1, 4), ("ex15", 16, 0), ("ex15", 16, 16), ("mid3d", 1, 2),
+                                                   ("lap30", 2, 8), ("lap30", 2, 0), ("24x24x2:27", 1, 2), ("nd24k", 16, 16)])
+@pytest.mark.parametrize("nrhs", [6, 8, 16, 19, 64, 70])
+def test_subtree_launches_with_many_right_hand_sides(api, oracle, monkeypatch, name, per_cu, min_trees, nrhs):
+    if name == "nd24k" and nrhs not in (8, 70):
+        pytest.skip("the larger input: two block sizes")
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
+    monkeypatch.setenv("PARSY_SUBTREES", str(per_cu))
+    monkeypatch.setenv("PARSY_SUB_TIER_MIN_TREES", str(min_trees))
+    A, sym, plan, lv, lo = _factor_both(api, oracle, name)
+    assert plan.info["solve_subtrees"] > 0 and plan.info["sub_mrhs_tiers"] >= (2 if min_trees else 1)
+    assert (plan.info["sub_mrhs_cover_level"] >= 0) == (min_trees > 0)
+    rng = np.random.default_rng(77)
+    B = rng.standard_normal((sym.n, nrhs))
+    ref_f = np.stack([oracle.blocked_lsolve(sym, lo, B[:, q], "serial") for q in range(nrhs)], axis=1)
+    ref_b = np.stack([oracle.blocked_ltsolve(sym, lo, B[:, q]) for q in range(nrhs)], axis=1)
+    for sub_min, xt in (("0", "0"), ("6", "0"), ("6", "6")):
+        monkeypatch.setenv("PARSY_SUB_MRHS_MIN", sub_min)
+        monkeypatch.setenv("PARSY_XT_MIN", xt)
+        X, _ = plan.solve(lo, B)
+        assert plan.solve_status() == 0
+        assert np.abs(X - ref_f).max() <= SOLVE_TOL * max(1.0, np.abs(ref_f).max()), (sub_min, xt)
+        Xb, _ = plan.solve2(lo, B, forward=False)
+        assert plan.solve_status() == 0
+        assert np.abs(Xb - ref_b).max() <= SOLVE_TOL * max(1.0, np.abs(ref_b).max()), (sub_min, xt)
+
+
 def test_subtree_launches_report_a_bad_pivot(api, oracle, monkeypatch):
     """A non-positive pivot inside a subtree: same failing column as the reference's (first one in column order)."""
     from parsy_bench_amd import inspector as I
