@@ -249,9 +249,10 @@ static void profile_mark(parsy_plan* pl, int kind, hipStream_t stream, size_t& c
 
 // The subtree launches of a solve with this many right-hand sides take the form of one wave per subtree and 16 right-
 // hand sides (trsv_sub_kernels.hip; PARSY_SUB_MRHS_MIN, 0: never)
-static bool sub_tiers_usable(const parsy_plan* pl, int nrhs) {
+// (the kernels address x by a 32-bit byte offset from a wave-uniform base: 16 rows or right-hand sides of either stride)
+static bool sub_tiers_usable(const parsy_plan* pl, int nrhs, int ldx) {
     const int m = solve_sub_mrhs_min();
-    return pl->dp.sub_ntiers > 0 && m > 0 && nrhs >= m;
+    return pl->dp.sub_ntiers > 0 && m > 0 && nrhs >= m && ldx < (1 << 24) && nrhs < (1 << 20);
 }
 
 // Enqueue the launches seq[i0, i1).  The state that orders the two streams (which level-completion events have been
@@ -319,7 +320,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
             case kLaunchChain: launch_chol_chain(pl->dp, l.first, l.count, l.jb, pl->epoch, l.fused != 0, L, stream); break;
             case kLaunchSolveSmall:
                 // (the subtree launch with many right-hand sides: a wave per subtree and 16 right-hand sides, traffic in LDS)
-                if (l.fused == 2 && sub_tiers_usable(pl, nrhs) && pl->S.sub_tiers[0].ntrees == l.count)
+                if (l.fused == 2 && sub_tiers_usable(pl, nrhs, ldx) && pl->S.sub_tiers[0].ntrees == l.count)
                     launch_solve_sub_mrhs(pl->dp, pl->S.sub_tiers[0], Lc, x, nrhs, ldx, pl->solve_ldq, stream);
                 else
                     launch_solve_small(pl->dp, l.first, l.count, l.jb, l.fused == 2, Lc, x, nrhs, ldx, pl->solve_ldq, stream);
@@ -346,7 +347,7 @@ static void run_range(parsy_plan* pl, const std::vector<Launch>& seq, size_t i0,
                                           pl->solve_wait_bias, stream);
                     break;
                 }
-                if (l.fused == 2 && sub_tiers_usable(pl, nrhs) && pl->S.sub_tiers[0].ntrees == l.count) {
+                if (l.fused == 2 && sub_tiers_usable(pl, nrhs, ldx) && pl->S.sub_tiers[0].ntrees == l.count) {
                     launch_bsolve_sub_mrhs(pl->dp, pl->S.sub_tiers[0], Lc, x, nrhs, ldx, stream);
                     break;
                 }
@@ -496,7 +497,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
         launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     }
-    if (sub_tiers_usable(pl, nrhs) && pl->S.sub_cover_level >= 0) {
+    if (sub_tiers_usable(pl, nrhs, ldx) && pl->S.sub_cover_level >= 0) {
         run_begin(pl);
         for (size_t li = 0; li < pl->S.bsolve.size(); ++li) {
             const Launch& l = pl->S.bsolve[li];
@@ -714,7 +715,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     pl->solve_ldq = ldq;
     if (use_xt) launch_transpose_x(d_x, ldx, pl->xt, ldq, pl->S.n, nrhs, true, stream);
-    if (sub_tiers_usable(pl, nrhs) && pl->S.sub_cover_level >= 0) {
+    if (sub_tiers_usable(pl, nrhs, ldx) && pl->S.sub_cover_level >= 0) {
         // the bands of levels that are one launch each (tiers), then the level launches above them
         double* xw = use_xt ? pl->xt : d_x;
         run_begin(pl);

@@ -816,6 +816,12 @@ static void build_sub_tiers(Schedule& S) {
     }
     const int min_trees = env_int("PARSY_SUB_TIER_MIN_TREES", kSubTierMinTrees);
     if (min_trees <= 0) return;
+    // Bands pay where the level launches they replace are chains of latencies -- factors of few entries per row (2-D
+    // problems: parabolic_fem-class, 67 entries per row: levels 3-6 of 64 right-hand sides 307 -> 133 us forward).  The
+    // trees of a 3-D factor carry hundreds of outside rows each (Flan-class: 442 slots = 63 KB of LDS per wave, two waves
+    // per compute unit: 4.4 ms for what the level kernels do in 2.1), so there only the subtrees keep this form (3.7 ->
+    // 2.1 ms).  PARSY_SUB_TIER_MIN_TREES set: whatever the factor (tests).
+    if (std::getenv("PARSY_SUB_TIER_MIN_TREES") == nullptr && S.xsize >= (int64_t)kSubTierMaxDensity * S.n) return;
     std::vector<int> level((size_t)ns, 0);
     for (int l = 0; l < S.nlevels; ++l)
         for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) level[(size_t)S.levelSet[q]] = l;

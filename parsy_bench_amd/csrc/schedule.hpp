@@ -144,8 +144,9 @@ struct SubTier {
 constexpr int kSubMaxSlots = 320;   // subtrees of the solves are cut so that columns + outside rows of the root fit
                                     // (x 17 doubles of LDS per wave)
 constexpr int kSubTierMaxWidth = 64;     // bands end below the first supernode wider than this ...
-constexpr int kSubTierMinTrees = 256;    // ... and where fewer trees than this would be left (PARSY_SUB_TIER_MIN_TREES)
+constexpr int kSubTierMinTrees = 512;    // ... and where fewer trees than this would be left (PARSY_SUB_TIER_MIN_TREES)
 constexpr int kSubTierMaxSlots = 448;    // ... or a tree would need more slots
+constexpr int kSubTierMaxDensity = 200;  // bands only for factors of fewer stored entries per row than this
 
 enum LaunchKind : int32_t {
     kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,

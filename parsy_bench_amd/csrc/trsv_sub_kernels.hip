@@ -36,6 +36,17 @@ typedef double double4_s __attribute__((ext_vector_type(4)));
 // member's work -- 1: the stores of x, 2: the outside rows (flush / gather), 4: the products of the rows below and their
 // LDS traffic, 8: the 4 x 4 inverses, 16: the products of the diagonal solve, 32: the loads of the rows below, 64: the
 // loads of the right-hand side.
+// Stamps build (tools/build_variant.sh substamps -DPARSY_SUBSTAMPS, tools/sub_stamps.py): wave 0 of the first 2048
+// workgroups of the forward kernel writes the shader clock at the marks below (8 per member, the first 7 members).
+#ifdef PARSY_SUBSTAMPS
+__device__ unsigned long long g_substamp[2048 * 64];
+#define SUB_STAMP(i) do { if (lane == 0 && g == 0 && blockIdx.x < 2048 && (i) < 64) g_substamp[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" void parsy_debug_substamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_substamp), sizeof(unsigned long long) * 2048 * 64);
+}
+#else
+#define SUB_STAMP(i) do { } while (0)
+#endif
 #ifdef PARSY_SUBABL
 #define SUB_ABL(bit) ((abl & (bit)) != 0)
 #else
@@ -56,19 +67,32 @@ struct SubPre {                  // what is loaded a member ahead -- raw: rows /
 // Every load is unconditional and nothing is done with the values here (addresses past the panel are clamped into it):
 // the wave must not wait for any of them before the member in hand is finished.  What a clamped load brings -- an entry
 // of L: finite -- meets a zero of x in every product (columns past the member's width, the slot of the padding rows).
+// panel entry at a 32-bit BYTE offset from a wave-uniform base: the load takes the base from scalar registers and one
+// 32-bit offset register per lane (no 64-bit address arithmetic per load)
+__device__ __forceinline__ double sub_ldg(const double* __restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void sub_stg(double* __restrict__ base, unsigned byte_off, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 template <bool BACK>
-__device__ __forceinline__ void sub_load(const SubMember& M, const double* __restrict__ L, const double* __restrict__ xl,
-                                         const uint2* __restrict__ slots, unsigned sr, int l15, int kq, SubPre& P, int abl = 0) {
+__device__ __forceinline__ void sub_load(const SubMember& M, const double* __restrict__ L, const double* __restrict__ xq,
+                                         unsigned lq8, const uint2* __restrict__ slots, unsigned sr, int l15, int kq, SubPre& P,
+                                         int abl = 0) {
     const double* __restrict__ G = L + M.px;
-    const int w = M.w, r = M.r, ld = M.ld;
-    const int il = min(l15, w - 1);
+    const int w = M.w, r = M.r;
+    const unsigned ld8 = 8u * (unsigned)M.ld;
+    const unsigned il = (unsigned)min(l15, w - 1);
+    // forward: column 4 st + kq of the block, rows from l15; backward: column l15, rows from 4 st + kq
+    unsigned col[4];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int cl = min(4 * st + kq, w - 1);
-        P.d[st] = BACK ? G[il * ld + cl] : G[cl * ld + il];
-    }
+    for (int st = 0; st < 4; ++st) col[st] = BACK ? il * ld8 : (unsigned)min(4 * st + kq, w - 1) * ld8;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) P.b[v] = SUB_ABL(64) ? 1.0 : xl[(uint64_t)(unsigned)(M.c0 + min(4 * v + kq, w - 1)) * sr];
+    for (int st = 0; st < 4; ++st) P.d[st] = BACK ? sub_ldg(G, col[0] + 8u * (unsigned)min(4 * st + kq, w - 1)) : sub_ldg(G, col[st] + 8u * il);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        P.b[v] = SUB_ABL(64) ? 1.0 : sub_ldg(xq + (uint64_t)(unsigned)M.c0 * sr, lq8 + 8u * sr * (unsigned)min(4 * v + kq, w - 1));
     const int nch = SUB_ABL(32) ? 0 : (r - w + 15) >> 4;
 #pragma unroll
     for (int ch = 0; ch < kSubPre; ++ch) {
@@ -76,8 +100,8 @@ __device__ __forceinline__ void sub_load(const SubMember& M, const double* __res
             const int k0 = w + 16 * ch;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                if (BACK) P.a[ch][st] = G[il * ld + min(k0 + 4 * st + kq, r - 1)];
-                else P.a[ch][st] = G[min(4 * st + kq, w - 1) * ld + min(k0 + l15, r - 1)];
+                if (BACK) P.a[ch][st] = sub_ldg(G, col[0] + 8u * (unsigned)min(k0 + 4 * st + kq, r - 1));
+                else P.a[ch][st] = sub_ldg(G, col[st] + 8u * (unsigned)min(k0 + l15, r - 1));
             }
             P.sw[ch] = slots[(int64_t)(M.so + ch) * 4 + kq];
         }
@@ -171,22 +195,39 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
     double* Ls = smem;
     double* Iv = smem + 16 * kSubLd;
     double* acc = smem + kSubFixed;
+    SUB_STAMP(0);
     const SubTree T = trees[tree];
     const int q0 = 16 * g;
     const bool qok = q0 + l15 < nrhs;
-    double* __restrict__ xl = x + (int64_t)(q0 + (qok ? l15 : 0)) * sq;   // this lane's right-hand side
-    const int nsl = T.ncols + T.nout + 1;
+    // x of (row, this lane's right-hand side): a wave-uniform base + a 32-bit byte offset per lane (the launch checks
+    // that 16 rows / right-hand sides of either stride stay below 4 GB)
+    double* __restrict__ xq = x + (int64_t)q0 * sq;
+    const unsigned lq8 = 8u * (unsigned)((qok ? l15 : 0) * sq);
+    const int trash = T.ncols + T.nout, nsl = trash + 1;
     SubPre cur, nxt;
+    double4_s Xp = {0, 0, 0, 0};   // the member before: its x is stored a member late (below)
+    int pc0 = 0, pw = 0;
     SubMember Mc = members[T.m0];
     SubMember Mn = members[min(T.m0 + 1, T.m1 - 1)];   // (descriptors: two members ahead, operands: one)
-    sub_load<false>(Mc, L, xl, slots, sr, l15, kq, cur, abl);
+    sub_load<false>(Mc, L, xq, lq8, slots, sr, l15, kq, cur, abl);
     for (int e = lane; e < nsl * kSubLd; e += 64) acc[e] = 0.0;
     __builtin_amdgcn_wave_barrier();
+    SUB_STAMP(1);
     // (the LDS operations of one wave are executed in order: no barrier anywhere)
     for (int m = T.m0; m < T.m1; ++m) {
         const SubMember Mnn = members[min(m + 2, T.m1 - 1)];
         sub_arrived(cur);
-        if (m + 1 < T.m1) sub_load<false>(Mn, L, xl, slots, sr, l15, kq, nxt, abl);
+        SUB_STAMP(8 + 8 * (m - T.m0) + 0);
+        // the x of the member before goes out here, AHEAD of the next loads: the wait at the top of the next member
+        // then finds stores that have had a whole member's time (stored right away they were the youngest operations
+        // in flight at that wait, and it waited for their acknowledgements)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = 4 * v + kq;
+            if (c < pw && qok && !SUB_ABL(1)) sub_stg(xq + (uint64_t)(unsigned)pc0 * sr, lq8 + 8u * sr * (unsigned)c, Xp[v]);
+        }
+        if (m + 1 < T.m1) sub_load<false>(Mn, L, xq, lq8, slots, sr, l15, kq, nxt, abl);
+        SUB_STAMP(8 + 8 * (m - T.m0) + 1);
         const int w = Mc.w, r = Mc.r;
         // the diagonal block's 4 x 4 inverses
         double d[4];
@@ -197,15 +238,26 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
         if (!SUB_ABL(8)) sub_inv4(Ls, Iv, l15, kq);
         __builtin_amdgcn_wave_barrier();
         const double ainv = SUB_ABL(8) ? 1.0 : Iv[16 * (l15 >> 2) + 4 * (l15 & 3) + kq];
-        // x_s = b_s - (what the members before subtracted)
+#ifdef PARSY_SUBSTAMPS
+        asm volatile("" ::"v"(ainv));
+#endif
+        SUB_STAMP(8 + 8 * (m - T.m0) + 2);
+        // x_s = b_s - (what the members before subtracted); the slots go back to the stack as zeros (a sibling's subtree
+        // uses them next) -- lanes of rows past the member's width write to the padding slot
         double4_s X;
+        {
+            double* sl[4];
+            double a[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = 4 * v + kq;
-            double* slot = &acc[(Mc.slot0 + min(c, w - 1)) * kSubLd + l15];
-            const double a = *slot;
-            if (c < w) *slot = 0.0;   // (the slot goes back to the stack: a sibling's subtree uses it next)
-            X[v] = (c < w && qok) ? cur.b[v] - a : 0.0;
+            for (int v = 0; v < 4; ++v) {
+                const int c = 4 * v + kq;
+                sl[v] = &acc[(c < w ? Mc.slot0 + c : trash) * kSubLd + l15];
+                a[v] = *sl[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *sl[v] = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) X[v] = (4 * v + kq < w && qok) ? cur.b[v] - a[v] : 0.0;
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -217,11 +269,14 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, t, X, 0, 0, 0);
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, X[b], X, 0, 0, 0);
         }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = 4 * v + kq;
-            if (c < w && qok && !SUB_ABL(1)) xl[(uint64_t)(unsigned)(Mc.c0 + c) * sr] = X[v];
-        }
+#ifdef PARSY_SUBSTAMPS
+        asm volatile("" ::"v"(X[0]), "v"(X[3]));
+#endif
+        SUB_STAMP(8 + 8 * (m - T.m0) + 3);
+        Xp = X;
+        pc0 = Mc.c0;
+        pw = w;
+        SUB_STAMP(8 + 8 * (m - T.m0) + 4);
         // rows below: slots += L21 y (rows past the panel's go to the padding slot; columns past w meet y = 0)
         const int nch = SUB_ABL(4 | 32) ? 0 : (r - w + 15) >> 4;
 #pragma unroll
@@ -236,21 +291,21 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
         }
         if (nch > kSubPre) {   // (taller members: the chunks beyond those loaded ahead, each loaded while the one before is multiplied)
             const double* __restrict__ G = L + Mc.px;
-            const int ld = Mc.ld;
+            const unsigned ld8 = 8u * (unsigned)Mc.ld;
             double a[4], an[4];
             uint2 sw, swn;
             {
-                const int k = min(w + 16 * kSubPre + l15, r - 1);
+                const unsigned k8 = 8u * (unsigned)min(w + 16 * kSubPre + l15, r - 1);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) a[st] = G[min(4 * st + kq, w - 1) * ld + k];
+                for (int st = 0; st < 4; ++st) a[st] = sub_ldg(G, (unsigned)min(4 * st + kq, w - 1) * ld8 + k8);
                 sw = slots[(int64_t)(Mc.so + kSubPre) * 4 + kq];
             }
 #pragma unroll 1
             for (int ch = kSubPre; ch < nch; ++ch) {
                 const int chn = min(ch + 1, nch - 1);
-                const int k = min(w + 16 * chn + l15, r - 1);
+                const unsigned k8 = 8u * (unsigned)min(w + 16 * chn + l15, r - 1);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) an[st] = G[min(4 * st + kq, w - 1) * ld + k];
+                for (int st = 0; st < 4; ++st) an[st] = sub_ldg(G, (unsigned)min(4 * st + kq, w - 1) * ld8 + k8);
                 swn = slots[(int64_t)(Mc.so + chn) * 4 + kq];
                 double4_s D = {0, 0, 0, 0};
 #pragma unroll
@@ -263,17 +318,26 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
             }
         }
         __builtin_amdgcn_wave_barrier();
+        SUB_STAMP(8 + 8 * (m - T.m0) + 5);
         Mc = Mn;
         Mn = Mnn;
         cur = nxt;
     }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = 4 * v + kq;
+        if (c < pw && qok && !SUB_ABL(1)) sub_stg(xq + (uint64_t)(unsigned)pc0 * sr, lq8 + 8u * sr * (unsigned)c, Xp[v]);
+    }
+    SUB_STAMP(2);
     // the outside rows leave the wave: x[row] -= slot (reference Triangular_BCSC.h:154: omp atomic)
     const int32_t* __restrict__ orow = out_rows + T.out0;
     if (SUB_ABL(2)) return;
     if (tr) {   // X row-major: lanes along the right-hand sides (128-byte runs), four rows per instruction
         for (int j0 = 0; j0 < T.nout; j0 += 4) {
             const int j = j0 + kq;
-            if (j < T.nout && qok) atomicAdd(&xl[(uint64_t)(unsigned)orow[j] * sr], -acc[(T.ncols + j) * kSubLd + l15]);
+            if (j < T.nout && qok)
+                atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(xq + (uint64_t)(unsigned)orow[j] * sr) + lq8),
+                          -acc[(T.ncols + j) * kSubLd + l15]);
         }
     } else {    // X right-hand-side-major (sr = 1): lanes along the rows
         const int nq = min(16, nrhs - q0);
@@ -285,6 +349,7 @@ __global__ __launch_bounds__(256) void k_solve_sub_mrhs(const SubMember* __restr
             }
         }
     }
+    SUB_STAMP(3);
 }
 
 __global__ __launch_bounds__(256) void k_bsolve_sub_mrhs(const SubMember* __restrict__ members, const SubTree* __restrict__ trees,
@@ -302,17 +367,20 @@ __global__ __launch_bounds__(256) void k_bsolve_sub_mrhs(const SubMember* __rest
     const SubTree T = trees[tree];
     const int q0 = 16 * g;
     const bool qok = q0 + l15 < nrhs;
-    double* __restrict__ xl = x + (int64_t)(q0 + (qok ? l15 : 0)) * sq;
+    double* __restrict__ xq = x + (int64_t)q0 * sq;
+    const unsigned lq8 = 8u * (unsigned)((qok ? l15 : 0) * sq);
     SubPre cur, nxt;
+    double4_s Xp = {0, 0, 0, 0};   // (stored a member late: as in the forward kernel)
+    int pc0 = 0, pw = 0;
     SubMember Mc = members[T.m1 - 1];
     SubMember Mn = members[max(T.m1 - 2, T.m0)];
-    sub_load<true>(Mc, L, xl, slots, sr, l15, kq, cur, abl);
+    sub_load<true>(Mc, L, xq, lq8, slots, sr, l15, kq, cur, abl);
     // x of the outside rows (final: their supernodes were solved by the launches before); the slot of the padding rows = 0
     const int32_t* __restrict__ orow = out_rows + T.out0;
     for (int j0 = 0; j0 < T.nout; j0 += 4) {
         const int j = j0 + kq;
         if (j < T.nout && !SUB_ABL(2)) {
-            const double v = xl[(uint64_t)(unsigned)orow[j] * sr];
+            const double v = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xq + (uint64_t)(unsigned)orow[j] * sr) + lq8);
             Xs[(T.ncols + j) * kSubLd + l15] = qok ? v : 0.0;
         }
     }
@@ -321,7 +389,12 @@ __global__ __launch_bounds__(256) void k_bsolve_sub_mrhs(const SubMember* __rest
     for (int m = T.m1 - 1; m >= T.m0; --m) {
         const SubMember Mnn = members[max(m - 2, T.m0)];
         sub_arrived(cur);
-        if (m > T.m0) sub_load<true>(Mn, L, xl, slots, sr, l15, kq, nxt, abl);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = 4 * v + kq;
+            if (c < pw && qok && !SUB_ABL(1)) sub_stg(xq + (uint64_t)(unsigned)pc0 * sr, lq8 + 8u * sr * (unsigned)c, Xp[v]);
+        }
+        if (m > T.m0) sub_load<true>(Mn, L, xq, lq8, slots, sr, l15, kq, nxt, abl);
         const int w = Mc.w, r = Mc.r;
         // t = y_s - L21' x(below)  (rows past the panel's read the padding slot: 0; columns past w are dropped below)
         double4_s A = {0, 0, 0, 0};
@@ -338,17 +411,17 @@ __global__ __launch_bounds__(256) void k_bsolve_sub_mrhs(const SubMember* __rest
         }
         if (nch > kSubPre) {
             const double* __restrict__ G = L + Mc.px;
-            const int il = min(l15, w - 1), ld = Mc.ld;
+            const unsigned cb = (unsigned)min(l15, w - 1) * 8u * (unsigned)Mc.ld;
             double a[4], an[4];
             uint2 sw, swn;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) a[st] = G[il * ld + min(w + 16 * kSubPre + 4 * st + kq, r - 1)];
+            for (int st = 0; st < 4; ++st) a[st] = sub_ldg(G, cb + 8u * (unsigned)min(w + 16 * kSubPre + 4 * st + kq, r - 1));
             sw = slots[(int64_t)(Mc.so + kSubPre) * 4 + kq];
 #pragma unroll 1
             for (int ch = kSubPre; ch < nch; ++ch) {
                 const int chn = min(ch + 1, nch - 1);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) an[st] = G[il * ld + min(w + 16 * chn + 4 * st + kq, r - 1)];
+                for (int st = 0; st < 4; ++st) an[st] = sub_ldg(G, cb + 8u * (unsigned)min(w + 16 * chn + 4 * st + kq, r - 1));
                 swn = slots[(int64_t)(Mc.so + chn) * 4 + kq];
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
@@ -385,15 +458,20 @@ __global__ __launch_bounds__(256) void k_bsolve_sub_mrhs(const SubMember* __rest
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int c = 4 * v + kq;
-            if (c < w) {
-                Xs[(Mc.slot0 + c) * kSubLd + l15] = X[v];
-                if (qok && !SUB_ABL(1)) xl[(uint64_t)(unsigned)(Mc.c0 + c) * sr] = X[v];
-            }
+            if (c < w) Xs[(Mc.slot0 + c) * kSubLd + l15] = X[v];
         }
+        Xp = X;
+        pc0 = Mc.c0;
+        pw = w;
         __builtin_amdgcn_wave_barrier();
         Mc = Mn;
         Mn = Mnn;
         cur = nxt;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = 4 * v + kq;
+        if (c < pw && qok && !SUB_ABL(1)) sub_stg(xq + (uint64_t)(unsigned)pc0 * sr, lq8 + 8u * sr * (unsigned)c, Xp[v]);
     }
 }
 

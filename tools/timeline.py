@@ -21,7 +21,7 @@ e = len(ks)
 if SOLVE:  # the last forward + backward solve instead: from the last k_diag_inverse on
     # (both solves start with k_diag_inverse: take the last one that a forward-solve kernel follows)
     dinv = [i for i, k in enumerate(ks) if "k_diag_inverse" in k[2]]
-    fwd = [i for i in dinv if i + 1 < len(ks) and "k_solve" in ks[i + 1][2]]
+    fwd = [i for i in dinv if i + 1 < len(ks) and ("k_solve" in ks[i + 1][2] or "k_transpose_x" in ks[i + 1][2])]
     b = (fwd or dinv)[-1]
 t0 = ks[b][0]
 prev_end = t0
