@@ -77,6 +77,10 @@ def lib():
 
 
 def have_ref() -> bool:
+    """True where the reference-backed checker exists -- or can be built now: it is made on demand (first use by a
+    CPU test or by tests/golden/make_golden.py) where /root/reference is present, never by __graft_entry__.build()."""
+    if not REF_SO.exists() and REFERENCE_ROOT.is_dir():
+        subprocess.run(["make", "-s", "-C", str(HERE), "ref"], check=False)
     return REF_SO.exists()
 
 
@@ -84,6 +88,8 @@ def ref():
     """The reference-backed checker (only where /root/reference was available to build it)."""
     global _ref
     if _ref is None:
+        if not have_ref():
+            raise RuntimeError("oracle/_ref is not built and /root/reference is not here to build it from")
         R = C.CDLL(str(REF_SO))
         R.ref_ereach_sn.restype = C.c_int
         R.ref_ereach_sn.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -648,12 +649,44 @@ int parsy_factor_host(parsy_plan* pl, const double* values, double* lValues, dou
         CAPI_HIP(hipMemcpy(lValues, pl->h_L_dev, (size_t)S.xsize * 8, hipMemcpyDeviceToHost), -1);
         return 0;
     }
-    if (!pl->h_stream) {
-        CAPI_HIP(hipStreamCreateWithFlags(&pl->h_stream, hipStreamNonBlocking), -1);
-        CAPI_HIP(hipStreamCreateWithFlags(&pl->h_copy, hipStreamNonBlocking), -1);
-        build_download_bands(pl);
-        pl->h_band_ev.resize(pl->h_band_level.size());
-        for (hipEvent_t& e : pl->h_band_ev) CAPI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), -1);
+    if (!pl->h_ready) {
+        // streams, bands and events are made into locals and handed to the plan only when all of them exist: a setup
+        // that failed half-way must not leave a plan that "pipelines" over no band at all (and downloads nothing)
+        hipStream_t hs = nullptr, hc = nullptr;
+        std::vector<hipEvent_t> evs;
+        auto undo = [&] {
+            for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+            if (hs) (void)hipStreamDestroy(hs);
+            if (hc) (void)hipStreamDestroy(hc);
+            pl->h_band_level.clear();
+            pl->h_band_runs.clear();
+            (void)hipGetLastError();
+        };
+        bool ok = hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&hc, hipStreamNonBlocking) == hipSuccess;
+        if (ok) {
+            build_download_bands(pl);
+            evs.resize(pl->h_band_level.size(), nullptr);
+            for (hipEvent_t& e : evs)
+                if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                    e = nullptr;
+                    ok = false;
+                }
+            ok = ok && !evs.empty();
+        }
+        if (!ok) {   // the plain form: kernels, then one download
+            evs.erase(std::remove(evs.begin(), evs.end(), (hipEvent_t) nullptr), evs.end());
+            undo();
+            if (parsy::plan_factor(pl, pl->h_values_dev, pl->h_L_dev, nullptr) != 0) return -1;
+            CAPI_HIP(hipDeviceSynchronize(), -1);
+            if (seconds) *seconds = parsy_last_factor_ms(pl) * 1e-3;
+            CAPI_HIP(hipMemcpy(lValues, pl->h_L_dev, (size_t)S.xsize * 8, hipMemcpyDeviceToHost), -1);
+            return 0;
+        }
+        pl->h_stream = hs;
+        pl->h_copy = hc;
+        pl->h_band_ev = evs;
+        pl->h_ready = true;
     }
     const size_t nb = pl->h_band_level.size();
     std::atomic<int> recorded{0};

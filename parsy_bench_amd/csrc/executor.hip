@@ -78,11 +78,19 @@ int plan_upload_launches(parsy_plan* pl) {
         if (up(S.one_f, pl->dp.one_f)) return -1;
         if (S.one_b.sn.empty()) pl->dp.one_b = pl->dp.one_f;
         else if (up(S.one_b, pl->dp.one_b)) return -1;
-        // (the hand-off buffers are sized by the lists: made again by the next ONE-launch solve)
-        for (double*& q : pl->one_y) {
-            if (q) (void)hipFree(q);
-            q = nullptr;
+        // (the hand-off buffers are sized by the lists: made again by the next ONE-launch solve; the status word of the
+        // last such solve lived in them)
+        for (int d = 0; d < 2; ++d) {
+            if (pl->one_y[d]) {
+                (void)hipFree(pl->one_y[d]);
+                pl->device_bytes -= pl->one_bytes[d];
+            }
+            pl->one_y[d] = nullptr;
+            pl->one_bytes[d] = 0;
+            pl->one_cap[d] = 0;
+            pl->one_calls[d] = 0;
         }
+        pl->solve_status_word = nullptr;
     }
     {
         void* d = nullptr;
@@ -380,6 +388,7 @@ static void run_launches(parsy_plan* pl, const std::vector<Launch>& seq, double*
 // the backward solve beside a subtree launch -- parabolic_fem-class, 4: 0.79 vs 0.86 ms -- and for the much larger plans)
 static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward) {
     if (!(backward ? pl->S.solve_one_back : pl->S.solve_one)) return false;
+    if (backward ? pl->one_off_back : pl->one_off) return false;   // (its buffers could not be allocated)
     const size_t nblocks = backward ? pl->S.one_back().sn.size() : pl->S.one_f.sn.size();
     const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks) ? kOneMaxRhs
                         : (pl->S.one_big || (backward && pl->S.one_subtrees))    ? 1
@@ -402,13 +411,25 @@ static int one_begin(parsy_plan* pl, bool backward, int nrhs, hipStream_t stream
         PARSY_HIP(hipStreamSynchronize(stream));
         (void)hipFree(pl->one_y[d]);
         pl->one_y[d] = nullptr;
+        pl->device_bytes -= pl->one_bytes[d];
+        pl->one_bytes[d] = 0;
+        if (pl->solve_status_word) pl->solve_status_word = nullptr;
     }
     if (!pl->one_y[d]) {
         pl->one_cap[d] = std::max(pl->one_cap[d], want);
         const size_t len = (size_t)(backward ? pl->S.n : pl->dp.one_f.nslots) * pl->one_cap[d];
         // (the two {status, ticket} pairs live behind the two buffers: one allocation)
-        PARSY_HIP(hipMalloc((void**)&pl->one_y[d], 2 * len * sizeof(double) + 4 * sizeof(int)));
-        pl->device_bytes += (int64_t)(2 * len * sizeof(double) + 4 * sizeof(int));
+        const size_t bytes = 2 * len * sizeof(double) + 4 * sizeof(int);
+        if (hipMalloc((void**)&pl->one_y[d], bytes) != hipSuccess) {
+            // no room for the hand-off buffers: this plan's solves of that direction go by the level launches from now on
+            (void)hipGetLastError();
+            pl->one_y[d] = nullptr;
+            pl->one_cap[d] = 0;
+            (backward ? pl->one_off_back : pl->one_off) = true;
+            return 1;
+        }
+        pl->one_bytes[d] = (int64_t)bytes;
+        pl->device_bytes += (int64_t)bytes;
         PARSY_HIP(solve_arm_handoff(pl->one_y[d], (int64_t)(2 * len), stream));
         PARSY_HIP(hipMemsetAsync(pl->one_y[d] + 2 * len, 0, 4 * sizeof(int), stream));
         pl->one_calls[d] = 0;
@@ -454,11 +475,12 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         return -1;
     }
     const int64_t need = (int64_t)ldx * nrhs;
-    if (solve_takes_one_launch(pl, nrhs, true)) {
+    double *y = nullptr, *y_next = nullptr;
+    int *st = nullptr, *st_next = nullptr;
+    int one_rc = solve_takes_one_launch(pl, nrhs, true) ? one_begin(pl, true, nrhs, stream, y, y_next, st, st_next) : 1;
+    if (one_rc < 0) return -1;
+    if (one_rc == 0) {
         // the whole solve -- or everything above the subtree launch, which follows -- is ONE launch (k_bsolve_one)
-        double *y = nullptr, *y_next = nullptr;
-        int *st = nullptr, *st_next = nullptr;
-        if (one_begin(pl, true, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
         profile_mark(pl, kLaunchBackBlock, stream, pl->run_cursor, 0, 0, pl->dp.one_b.nblocks);
@@ -650,11 +672,12 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
-    if (solve_takes_one_launch(pl, nrhs, false)) {
+    double *y = nullptr, *y_next = nullptr;
+    int *st = nullptr, *st_next = nullptr;
+    int one_rc = solve_takes_one_launch(pl, nrhs, false) ? one_begin(pl, false, nrhs, stream, y, y_next, st, st_next) : 1;
+    if (one_rc < 0) return -1;
+    if (one_rc == 0) {
         // the whole solve -- or everything above the subtree launch, which comes first -- is ONE launch (k_solve_one)
-        double *y = nullptr, *y_next = nullptr;
-        int *st = nullptr, *st_next = nullptr;
-        if (one_begin(pl, false, nrhs, stream, y, y_next, st, st_next) != 0) return -1;
         PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
         run_begin(pl);
         pl->solve_ldq = 0;

@@ -35,6 +35,8 @@ struct parsy_plan {
     double* one_y[2] = {nullptr, nullptr};   // forward, backward: two buffers + the two state pairs behind them
     unsigned one_calls[2] = {0, 0};
     int one_cap[2] = {0, 0};                 // right-hand sides the buffers are made for (1, 4 or 8: grown on demand)
+    int64_t one_bytes[2] = {0, 0};           // ... and their share of device_bytes
+    bool one_off = false, one_off_back = false;   // a direction whose buffers could not be allocated: level launches from then on
     const int* solve_status_word = nullptr;   // where the last solve left its status (null: dp.sinfo)
 
     // buffers of the host-convenience calls
@@ -45,6 +47,7 @@ struct parsy_plan {
     // streams, one event per band of levels, the (offset, length) runs of lValues that are final after each band
     hipStream_t h_stream = nullptr, h_copy = nullptr;
     std::vector<hipEvent_t> h_band_ev;
+    bool h_ready = false;                    // the pipelined download's streams, bands and events all exist
     std::vector<int> h_band_level;                                    // last level of every band
     std::vector<std::vector<std::pair<int64_t, int64_t>>> h_band_runs;
     int64_t h_x_len = 0;

@@ -1539,8 +1539,17 @@ static void build_solve_one(Schedule& S, bool sharded) {
     const bool ok_b = mode == 2 || fits(nbk) || (sub && nbk <= kOneMaxSupernodesBig);
     S.one_big = mode != 2 && !fits(nbk);
     if (!ok_f && !ok_b) return;
-    if (ok_f) build_one_lists(S, mf, S.one_f);
-    if (ok_b && (!ok_f || mb != mf)) build_one_lists(S, mb, S.one_b);
+    // (a pattern whose rows are not owned by later members -- not an etree's -- or too many slots: the plan keeps its
+    // level launches instead of failing as a whole)
+    try {
+        if (ok_f) build_one_lists(S, mf, S.one_f);
+        if (ok_b && (!ok_f || mb != mf)) build_one_lists(S, mb, S.one_b);
+    } catch (const std::runtime_error&) {
+        S.one_f.clear();
+        S.one_b.clear();
+        S.one_big = false;
+        return;
+    }
     S.one_subtrees = sub;
     S.one_forced = mode == 2;
     S.solve_one = ok_f;

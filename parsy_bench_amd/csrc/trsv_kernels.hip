@@ -1986,9 +1986,10 @@ template <int NQ>
 __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restrict__ blocks, const int32_t* __restrict__ rows,
                                                          const int32_t* __restrict__ blk_w0, const double* __restrict__ L,
                                                          double* __restrict__ x, int nrhs, int ldx, int n, int nblocks,
-                                                         double* __restrict__ y, double* __restrict__ y_next,
+                                                         double* y, double* __restrict__ y_next,
                                                          int* __restrict__ state, int* __restrict__ state_next,
                                                          int wait_bias, int cap) {
+    // (y: other workgroups publish into it while this one reads: no __restrict__, every read of it is an atomic load)
     __shared__ double Dg[kTile * kLdDiag];  // the diagonal block (column-major), then its inverse in place; at the end: parts
     __shared__ double invd[kTile];
     __shared__ double s_t[16 * 17];
@@ -2081,7 +2082,8 @@ __global__ __launch_bounds__(kThreads) void k_bsolve_one(const SnDesc* __restric
         const int k0 = near + ch * kChunk, k = min(k0 + (tid & (kChunk - 1)), nb - 1);
         const int row = w + k < w_left ? D.c0 + w + k : ri[w + k];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) dst[q] = q < nrhs ? y[(int64_t)q * n + row] : 0.0;
+        for (int q = 0; q < NQ; ++q)   // (a relaxed load of wavefront scope: the same cached load, defined beside the publishers' stores)
+            dst[q] = q < nrhs ? __hip_atomic_load(&y[(int64_t)q * n + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0.0;
     };
     if (nchunks > 0) x_ahead(xv[0], nchunks - 1);
     auto far_step = [&](double (&cur)[kPc][kPr], double (&nxt)[kPc][kPr], double (&xc)[NQ], double (&xn)[NQ], int step) {

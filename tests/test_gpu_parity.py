@@ -97,6 +97,31 @@ def test_solve_on_row_major_x_matches_oracle(api, oracle, monkeypatch, name, nrh
     assert np.abs(X - X0).max() <= 1e-12 * max(1.0, np.abs(X0).max())
 
 
+@pytest.mark.parametrize("name", ["ex15", "lap30", "nd24k", "parabolic_fem"])
+@pytest.mark.parametrize("nrhs", [6, 7, 8, 16])
+def test_product_gate_with_row_major_x_forced(api, oracle, monkeypatch, name, nrhs):
+    """The product's own choice between the ONE-launch kernels and the level launches (no PARSY_SOLVE_ONE) together
+    with the row-major layout of X forced from 6 right-hand sides on.  (Round 4: an experiment that ran the level
+    launches of a partly ONE-launch solve on the caller's buffer while the plan still said "row-major, stride ldq"
+    wrote past the end of that buffer -- n x nrhs doubles addressed as n x 16 -- and the process aborted in this very
+    call; DESIGN section 7.  The ONE-launch path keeps the caller's layout and says so to every launch it makes.)"""
+    from parsy_bench_amd import inspector as I
+    monkeypatch.delenv("PARSY_SOLVE_ONE", raising=False)
+    monkeypatch.setenv("PARSY_XT_MIN", "6")
+    A, perm, sym = problem(name)
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((sym.n, nrhs))
+    for forward in (True, False):
+        X, _ = plan.solve(lv, B) if forward else plan.solve2(lv, B, forward=False)
+        assert plan.solve_status() == 0
+        for q in range(nrhs):
+            xo = oracle.blocked_lsolve(sym, lv, B[:, q], "serial") if forward else oracle.blocked_ltsolve(sym, lv, B[:, q])
+            assert np.abs(X[:, q] - xo).max() <= SOLVE_TOL * max(1.0, np.abs(xo).max()), (forward, q)
+
+
 @pytest.mark.parametrize("nrhs", [3, 19])
 def test_solve_flag_protocol_chain_matches_oracle(api, oracle, monkeypatch, nrhs):
     """PARSY_OLD_MRHS_CHAIN=1: the chain launches of rounds 1-2 (flags + staged copies per block column; 8 right-hand
