@@ -134,6 +134,63 @@ def cpu_baseline(sym, threads: int, budget_s: float = 8.0):
     return out
 
 
+def cpu_baseline_top(sym, lv, threads: int, rest: dict):
+    """Second sample: the TOP SEPARATOR's supernode alone -- the oracle's cholesky_left_par_05 root
+    phase (one supernode, dense kernels on `threads` BLAS threads: what the reference does with its last l-level,
+    parallel_PB_Cholesky_05.h:269-411) on the factor the GPU has just computed for everything below it -- and the
+    flop-weighted combination with the subtree sample: seconds = flops(rest) / rate(subtree sample) + flops(top) /
+    rate(top sample).  lv: the GPU's factor on the host (the top separator's panel is overwritten)."""
+    import time
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as O
+    blas = O.bind_system_blas()
+    try:
+        ns = sym.nsuper
+        root = ns - 1
+        c0, c1 = int(sym.super[root]), int(sym.super[root + 1])
+        w = c1 - c0
+        p0, p1 = int(sym.p[c0]), int(sym.xsize)
+        # left-looking work of this target: DSYRK on the rows of every descendant inside its columns + its own POTRF
+        u0, u1 = int(sym.updPtr[root]), int(sym.updPtr[root + 1])
+        d = np.asarray(sym.updSn[u0:u1], dtype=np.int64)
+        K = np.diff(sym.super)[d].astype(np.float64)
+        n1 = (np.asarray(sym.updUb[u0:u1], dtype=np.float64) - np.asarray(sym.updLb[u0:u1], dtype=np.float64) + 1.0)
+        f_top = float((K * n1 * (n1 + 1.0)).sum() + w ** 3 / 3.0)
+        ok_t = []
+        for _ in range(2):   # (a warm-up of the BLAS threads, then the measured run)
+            lv[p0:p1] = 0.0
+            timing = np.zeros(8 + max(threads, 1))
+            arrs = [np.ascontiguousarray(a, dtype=t) for a, t in (
+                (sym.A2p, np.int32), (sym.A2i, np.int32), (sym.A2x, np.float64), (sym.p, np.uint64), (sym.s, np.int32),
+                (sym.i_ptr, np.uint64), (sym.super, np.int32), (sym.sParent, np.int32), (sym.A1p, np.int32),
+                (sym.A1i, np.int32), (sym.col2Sup, np.int32))]
+            lp, pp, pt = np.array([0, 1], np.int32), np.array([0, 1], np.int32), np.array([root], np.int32)
+            O.lib().oracle_set_threads(threads)
+            t0 = time.perf_counter()
+            ok = O.lib().oracle_cholesky_left_par_05(
+                sym.n, O.P(arrs[0]), O.P(arrs[1]), O.P(arrs[2]), O.P(arrs[3]), O.P(arrs[4]), O.P(arrs[5]), O.P(lv),
+                O.P(arrs[6]), ns, O.P(timing), O.P(arrs[7]), O.P(arrs[8]), O.P(arrs[9]), O.P(arrs[10]), 1, O.P(lp), None,
+                0, O.P(pp), O.P(pt), 1, threads, sym.maxSupWid + 1, sym.maxCol + 1, None)
+            ok_t.append((bool(ok), time.perf_counter() - t0))
+        ok, secs = ok_t[-1]
+        if not ok:
+            raise RuntimeError("CPU port reported a non-positive pivot in the top separator")
+        total = rest["sample_gflops"] * 1e9 / rest["value"] if rest.get("value") else None   # executed flops of the whole job
+        out = {"supernode": root, "width": w, "descendants": int(u1 - u0), "flops": f_top, "seconds": secs,
+               "gflops": f_top / secs / 1e9,
+               "sample": f"the top separator's supernode alone ({w} columns, {u1 - u0} descendants, {f_top:.3e} flops: DSYRK per "
+                         f"descendant + POTRF) on the GPU's factor of everything below it; oracle cholesky_left_par_05 root phase, "
+                         f"{threads} BLAS threads ({blas or 'built-in loops'}), second of two runs"}
+        if total:
+            est = max(total - f_top, 0.0) / (rest["sample_gflops"] * 1e9) + secs
+            out["combined_value"] = 1.0 / est
+            out["combined"] = ("factorizations/s = 1 / (flops outside the top separator / subtree-sample rate + measured seconds of "
+                               "the top separator)")
+        return out
+    finally:
+        O.unbind_blas()
+
+
 def granted_cpus():
     """CPUs this process may really use: the cgroup CPU quota where one is set (v2 cpu.max, v1 cfs quota),
     else the affinity mask -- capped at the GPU box's documented per-GPU share of 16 CPUs when neither says
@@ -710,6 +767,13 @@ def main():
                 "kind_ms_per_solve": {k: v / bruns for k, v in pb["ms"].items() if v > 0},
             }
 
+    # (the CPU baseline's second sample works on this factor: the extras below reuse the buffer)
+    L_host = None
+    if world == 1 and not args.no_cpu_baseline and sym.nsuper > 1:
+        try:
+            L_host = L.cpu().numpy()
+        except Exception as e:
+            log(f"no host copy of the factor for the top-separator sample: {e!r}")
     # ---- extra objects: the other single-GPU configurations of BASELINE.json (never `value`) ----
     del plan, solve_plan, BX
     if world == 1 and not args.no_extras and args.workload == "flan":
@@ -783,6 +847,12 @@ def main():
             share, share_src = granted_cpus()
             out["cpu_baseline"] = cpu_baseline(sym, share)
             out["cpu_baseline"]["cores_source"] = share_src
+            if L_host is not None:
+                try:
+                    out["cpu_baseline"]["top_separator"] = cpu_baseline_top(sym, L_host, share, out["cpu_baseline"])
+                except Exception as e:
+                    out["cpu_baseline"]["top_separator"] = {"failed": repr(e)}
+                L_host = None
             out["cpu_baseline"]["ex15_1_thread"] = cpu_baseline_ex15(1)
             out["cpu_baseline"]["nd24k_whole_matrix"] = cpu_baseline_whole("nd24k", share)
         except Exception as e:  # the baseline is reporting only; never lose the GPU numbers to it

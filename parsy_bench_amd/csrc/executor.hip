@@ -390,9 +390,18 @@ static bool solve_takes_one_launch(const parsy_plan* pl, int nrhs, bool backward
     if (!(backward ? pl->S.solve_one_back : pl->S.solve_one)) return false;
     if (backward ? pl->one_off_back : pl->one_off) return false;   // (its buffers could not be allocated)
     const size_t nblocks = backward ? pl->S.one_back().sn.size() : pl->S.one_f.sn.size();
-    const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks) ? kOneMaxRhs
-                        : (pl->S.one_big || (backward && pl->S.one_subtrees))    ? 1
-                                                                                 : 4;
+    // (round 5, tools/gate_sweep.py: forward blocks of 5-8 right-hand sides through the ONE launch on factors of fewer than
+    // 400 entries per row -- 2-D grids of 3 400 .. 14 000 supernodes 0.26 -> 0.18, 0.33 -> 0.24, 0.35 -> 0.31 ms; 3-D grids of
+    // 580-670 entries per row lose 5 %, the backward solve loses wherever the plan is not small)
+    // -- and up to 4 096 blocks: the parabolic_fem-class plan, 6 546 blocks, takes 8 right-hand sides through its subtree and
+    // band launches in 0.51 ms against 0.60; likewise the backward solve beside a subtree launch: 4 right-hand sides per
+    // ONE launch up to that size (grids of 2 000 .. 4 000 blocks: 0.44 -> 0.34, 1.11 -> 0.93, 0.81 -> 0.68, 0.40 -> 0.26 ms), one
+    // beyond it (parabolic_fem-class, 4: 0.79 vs 0.86 ms)
+    const bool mid = nblocks <= (size_t)kOneMidBlocks && !pl->S.one_big;
+    const bool f8 = !backward && mid && pl->S.xsize < (int64_t)kOneRhs8Density * pl->S.n;
+    const int max_rhs = (pl->S.one_forced || nblocks <= (size_t)kOneSmallBlocks || f8)         ? kOneMaxRhs
+                        : (pl->S.one_big || (backward && pl->S.one_subtrees && !mid))          ? 1
+                                                                                               : 4;
     return nrhs <= max_rhs;
 }
 
@@ -708,7 +717,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     // is taken from 200 entries of L per row on)
     const bool use_xt = xt_min > 0 && nrhs >= xt_min && nrhs >= solve_small_mrhs_min() && nrhs >= solve_mrhs_min() &&
                         !pl->old_mrhs_chain && pl->S.solve_fix_list.empty() &&
-                        (pl->S.xsize >= (int64_t)200 * pl->S.n || (xt_env && *xt_env));
+                        (pl->S.xsize >= (int64_t)150 * pl->S.n || (xt_env && *xt_env));
     const int ldq = use_xt ? (nrhs + 15) & ~15 : 0;
     const int64_t need = use_xt ? (int64_t)pl->S.n * ldq : (int64_t)ldx * nrhs;
     if (pl->S.n_solve_wide > 0 && pl->xscratch_len < need) {

@@ -266,7 +266,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         const int cus = compute_units > 0 ? compute_units : 256;
         std::vector<uint8_t> elig(ns, 0);
         auto cut = [&](std::vector<double>& cost, double min_cost, std::vector<int32_t>& subtree,
-                       const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr) {
+                       const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr, int64_t min_members = -1) {
             double total = 0;
             int64_t members = 0;
             {   // everything that could be in a subtree at all
@@ -278,7 +278,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                         ++members;
                     }
             }
-            if (!forced && members < (int64_t)kSubtreeMinPerSlot * per_cu * cus) return 0;
+            if (!forced && members < (min_members >= 0 ? min_members : (int64_t)kSubtreeMinPerSlot * per_cu * cus)) return 0;
             return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)per_cu * cus)), subtree, slots,
                                  kSubMaxSlots);
         };
@@ -302,7 +302,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             S.solve_cost[t] = 2e3 + (double)S.sn[t].w * S.sn[t].r;
             slots[(size_t)t] = {S.sn[t].w, S.sn[t].r - S.sn[t].w};
         }
-        S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree, &slots);
+        // (the solves cut subtrees from far fewer supernodes on than the factorization: tools/gate_sweep.py, round 5 -- grids of
+        // 3 400 .. 9 000 supernodes: forward solve -12 .. -23 %, 8 right-hand sides up to -44 %; 750 .. 1 450: +-8 %)
+        S.n_solve_subtrees = cut(S.solve_cost, kSubtreeMinCost / 16, S.solve_subtree, &slots, kSolveSubtreeMinMembers);
         // (the backward solve walks the same subtrees from their roots down)
         S.bsolve_subtree = S.solve_subtree;
         S.n_bsolve_subtrees = S.n_solve_subtrees;
@@ -852,13 +854,20 @@ static void build_sub_tiers(Schedule& S) {
             if (!covered[(size_t)t]) next = std::min(next, level[(size_t)t]);
         if (next > lmax) break;
         // the highest top with enough trees
+        // (where not even one level leaves min_trees trees -- the narrow levels right below the wide supernodes -- a last
+        // band of at least a quarter as many: parabolic_fem-class, levels 7-8 as 128 trees)
         std::vector<std::vector<int32_t>> trees, best;
         int best_top = -1;
-        for (int top = next; top <= lmax; ++top) {
-            trees_of_band(top, trees);
-            if ((int)trees.size() < min_trees) break;
-            best.swap(trees);
-            best_top = top;
+        // (the HIGHEST top that leaves enough trees: a handful of stragglers on the lowest uncovered level -- wider supernodes
+        // among the leaves -- are few trees by themselves and many once the level above joins them)
+        for (int need : {min_trees, std::max(min_trees / 4, 1)}) {
+            for (int top = next; top <= lmax; ++top) {
+                trees_of_band(top, trees);
+                if ((int)trees.size() < need) continue;
+                best.swap(trees);
+                best_top = top;
+            }
+            if (best_top >= 0) break;
         }
         if (best_top < 0) break;
         // heaviest trees first
@@ -1912,6 +1921,92 @@ static void check_solve_one(const Schedule& S, Fail&& fail) {
     }
 }
 
+// The subtree / band launches of the many-right-hand-side solves (SubTier): every member a 16-column block of an active
+// supernode with the panel window that goes with it; members of a tree in index order; every supernode in at most one tree,
+// whole (all its blocks, left to right); the subtrees of tier 0 are those of the forward solve's subtree launch; every
+// active supernode of a level <= sub_cover_level is in a tier and no launch list is needed for it; slots inside the tree's
+// range, a member's own columns on the stack below its rows' targets; outside rows sorted and not columns of the tree.
+template <class Fail>
+static void check_sub_tiers(const Schedule& S, Fail&& fail) {
+    if (S.sub_tiers.empty()) return;
+    const int ns = S.nsuper;
+    std::vector<int32_t> sn_of_col((size_t)S.n, -1);
+    for (int t = 0; t < ns; ++t)
+        for (int c = 0; c < S.sn[t].w; ++c) sn_of_col[(size_t)S.sn[t].c0 + c] = t;
+    std::vector<int> level((size_t)ns, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int q = S.levelPtr[l]; q < S.levelPtr[l + 1]; ++q) level[(size_t)S.levelSet[q]] = l;
+    std::vector<int32_t> tree_of((size_t)ns, -1);
+    int32_t next_tree = 0;
+    for (size_t k = 0; k < S.sub_tiers.size(); ++k) {
+        const SubTier& R = S.sub_tiers[k];
+        if (R.tree0 != next_tree || R.ntrees <= 0 || (size_t)(R.tree0 + R.ntrees) > S.sub_trees.size())
+            return fail("sub tiers: tiers do not tile the trees");
+        next_tree = R.tree0 + R.ntrees;
+        if (k == 0 && (size_t)R.ntrees != S.solve_small_ranges.size() / 2) return fail("sub tiers: tier 0 is not the subtree launch");
+        for (int32_t b = R.tree0; b < R.tree0 + R.ntrees; ++b) {
+            const SubTree& T = S.sub_trees[(size_t)b];
+            if (T.m0 >= T.m1 || (size_t)T.m1 > S.sub_members.size() || T.ncols + T.nout + 1 > R.max_slots ||
+                (size_t)(T.out0 + T.nout) > S.sub_out_rows.size())
+                return fail("sub tiers: a tree's ranges");
+            int32_t prev_sn = -1, expect_c = -1;
+            for (int32_t q = T.m0; q < T.m1; ++q) {
+                const SubMember& M = S.sub_members[(size_t)q];
+                if (M.c0 < 0 || M.c0 >= S.n || M.w < 1 || M.w > kTinyWidth) return fail("sub tiers: a member's columns");
+                const int t = sn_of_col[(size_t)M.c0];
+                const SnDesc& D = S.sn[t];
+                const int j0 = M.c0 - D.c0;
+                if (!S.active[t] || j0 % kTinyWidth != 0 || M.w != std::min(kTinyWidth, D.w - j0) || M.r != D.r - j0 || M.ld != D.r ||
+                    M.px != D.px + (int64_t)j0 * D.r + j0)
+                    return fail("sub tiers: a member is not a 16-column block of an active supernode");
+                if (j0 == 0) {
+                    if (tree_of[(size_t)t] >= 0) return fail("sub tiers: a supernode in two trees");
+                    if (t <= prev_sn) return fail("sub tiers: members out of index order");
+                    if (k == 0 ? S.solve_subtree[t] < 0 : (level[(size_t)t] > R.top_level || S.sn[t].w > kSubTierMaxWidth))
+                        return fail("sub tiers: a supernode that does not belong to its tier");
+                    tree_of[(size_t)t] = b;
+                    prev_sn = t;
+                } else if (t != prev_sn || M.c0 != expect_c) {
+                    return fail("sub tiers: the blocks of a supernode are not in a row");
+                }
+                expect_c = M.c0 + M.w;
+                if (M.slot0 < 0 || M.slot0 + M.w > T.ncols) return fail("sub tiers: a member's column slots");
+                const int nch = (M.r - M.w + 15) / 16;
+                if ((size_t)(M.so + nch) * 16 > S.sub_slots.size()) return fail("sub tiers: a member's slot words");
+                for (int ch = 0; ch < nch; ++ch)
+                    for (int e = 0; e < 16; ++e) {
+                        const int k2 = M.w + 16 * ch + 4 * (e & 3) + (e >> 2), slot = S.sub_slots[(size_t)(M.so + ch) * 16 + e];
+                        if (k2 >= M.r) {
+                            if (slot != T.ncols + T.nout) return fail("sub tiers: a padding row not in the padding slot");
+                            continue;
+                        }
+                        const int32_t row = j0 + k2 < D.w ? D.c0 + j0 + k2 : S.rows[(size_t)D.pi + j0 + k2];
+                        if (slot < T.ncols) {   // a column of a member of this tree that comes later
+                            const int tt = sn_of_col[(size_t)row];
+                            bool found = false;
+                            for (int32_t q2 = q + 1; q2 < T.m1 && !found; ++q2) {
+                                const SubMember& M2 = S.sub_members[(size_t)q2];
+                                found = row >= M2.c0 && row < M2.c0 + M2.w && slot == M2.slot0 + row - M2.c0;
+                            }
+                            if (!found || tt < 0) return fail("sub tiers: a row's column slot does not belong to a later member");
+                        } else if (slot >= T.ncols + T.nout || S.sub_out_rows[(size_t)T.out0 + slot - T.ncols] != row) {
+                            return fail("sub tiers: a row's outside slot");
+                        }
+                    }
+            }
+            for (int32_t j = 0; j < T.nout; ++j) {
+                const int32_t row = S.sub_out_rows[(size_t)T.out0 + j];
+                if (j > 0 && row <= S.sub_out_rows[(size_t)T.out0 + j - 1]) return fail("sub tiers: outside rows not sorted");
+                if (tree_of[(size_t)sn_of_col[(size_t)row]] == b) return fail("sub tiers: an outside row is a column of the tree");
+            }
+        }
+    }
+    for (int t = 0; t < ns; ++t) {
+        if (S.solve_subtree[t] >= 0 && S.active[t] && tree_of[(size_t)t] < 0) return fail("sub tiers: a supernode of the subtree launch is missing");
+        if (S.active[t] && level[(size_t)t] <= S.sub_cover_level && tree_of[(size_t)t] < 0) return fail("sub tiers: a covered level has a supernode outside the tiers");
+    }
+}
+
 int64_t check_schedule(const Schedule& S, std::string& what) {
     int64_t bad = 0;
     auto fail = [&](const std::string& msg) {
@@ -1919,6 +2014,7 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
     };
     check_solve_launches(S, fail);
     check_solve_one(S, fail);
+    check_sub_tiers(S, fail);
     if (S.solve_only) return bad;
     const int nc = (int)S.csn.size();
     // ---- pieces tile their supernode; levels respect the chain-extended etree

@@ -146,7 +146,7 @@ constexpr int kSubMaxSlots = 320;   // subtrees of the solves are cut so that co
 constexpr int kSubTierMaxWidth = 64;     // bands end below the first supernode wider than this ...
 constexpr int kSubTierMinTrees = 512;    // ... and where fewer trees than this would be left (PARSY_SUB_TIER_MIN_TREES)
 constexpr int kSubTierMaxSlots = 448;    // ... or a tree would need more slots
-constexpr int kSubTierMaxDensity = 200;  // bands only for factors of fewer stored entries per row than this
+constexpr int kSubTierMaxDensity = 700;  // bands only for factors of fewer stored entries per row than this (gate sweep, round 5)
 
 enum LaunchKind : int32_t {
     kLaunchSmall = 0, kLaunchTiles = 1, kLaunchChain = 2, kLaunchBig = 3,
@@ -209,10 +209,13 @@ constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries 
                                                 // 4.6 -> 7.1 ms forward, 5.8 -> 6.2 backward) when
 constexpr int kOneMaxSupernodesBig = 32768;     // above a subtree launch, one right-hand side at a time: up to this many supernodes outside it
 constexpr int kOneSmallBlocks = 1024;     // launches of at most this many blocks take up to kOneMaxRhs right-hand sides, larger ones 4
+constexpr int kOneMidBlocks = 4096;       // ... (both: plans of at most this many blocks)
+constexpr int kOneRhs8Density = 400;      // forward: up to kOneMaxRhs right-hand sides too where the factor stores fewer entries per row than this
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
 constexpr int kSubtreeMinPerSlot = 2;     // ... and only where there are this many eligible supernodes per subtree
+constexpr int kSolveSubtreeMinMembers = 2048;   // ... the solves: from this many eligible supernodes on
 
 struct Schedule {
     int n = 0, nsuper = 0, nlevels = 0;

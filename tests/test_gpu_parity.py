@@ -924,7 +924,8 @@ def test_one_launch_solves(api, oracle, monkeypatch, name, nrhs):
     assert plan0.status() == 0
     monkeypatch.setenv("PARSY_SOLVE_ONE", "2")
     plan = api.Plan(sym, 0)
-    assert plan.info["solve_one"] == 3 and plan.check() == 0
+    # (nd24k-class: since round 5 the solves cut subtrees from 2 048 narrow supernodes on -- bit 2: that launch stays beside)
+    assert plan.info["solve_one"] == (7 if name == "nd24k" else 3) and plan.check() == 0
     rng = np.random.default_rng(5)
     b1 = oracle.rhs_init_blocked(sym, lv)
     for rep in range(3):

@@ -266,7 +266,7 @@ def test_solve_launches_are_consistent(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,auto,forced", [("tiny2d", 3, 3), ("ex15", 3, 3), ("small3d", 3, 3), ("13x13x13:27", 3, 3),
-                                              ("24x24x2:27", 3, 3), ("mid3d", 3, 3), ("lap30", 3, 3), ("nd24k", 3, 3), ("parabolic_fem", 7, 7)])
+                                              ("24x24x2:27", 3, 3), ("mid3d", 3, 3), ("lap30", 3, 3), ("nd24k", 7, 7), ("parabolic_fem", 7, 7)])
 def test_one_launch_solve_lists(name, auto, forced, monkeypatch):
     """Plans of <= 8192 supernodes (16 384 when they hold >= 4096 entries on average) and <= 2^28 stored entries solve in
     ONE launch per direction (info: bit 0 forward, bit 1 backward; bit 2: only the supernodes outside the subtree launches,
