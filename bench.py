@@ -45,7 +45,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix, datasheet (the microarch gu
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 SOLVE_TOL = 1e-9               # max|x - 1| of the solve of L x = L 1 (reference testTriangular: 1e-3)
 BACK_TOL = 1e-9                # max|x - 1| of forward + backward solve of L L' x = (P A P') 1
-PMC_ROUND = "r04"              # profiles/<round>_<workload>_pmc_traffic.json: the committed counter summary that is quoted
+PMC_ROUND = "r05"              # profiles/<round>_<workload>_pmc_traffic.json: the committed counter summary that is quoted
 
 
 def log(*a):

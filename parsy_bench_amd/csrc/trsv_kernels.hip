@@ -401,6 +401,29 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
                     const int c = 4 * st + kq;
                     lv[st] = (c < w) ? G[(int64_t)c * r + row_l] : 0.0;
                 }
+                if (tr) {
+                    // X row-major: the product the other way round -- L21 x_s, lanes along the RIGHT-HAND SIDES, the
+                    // register index along the rows -- so that an instruction's atomics are four rows x 128 contiguous
+                    // bytes (8 requests of 64 bytes with 8 adds each) instead of 16 rows x 32 bytes (16 requests with
+                    // 4 adds each): they execute at the memory side at the rate of those requests
+                    int xr[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xr[v] = ri[min(k0 + kq + 4 * v, r - 1)];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (n < nfrag_n) {
+                            double4_s acc = {0, 0, 0, 0};
+#pragma unroll
+                            for (int st = 0; st < kSt; ++st)
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[st], xa[n][st], acc, 0, 0, 0);
+                            const int q = 16 * n + l15;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (k0 + kq + 4 * v < r && q < nq) atomicAdd(&x[xr[v] * sr + (q0 + q) * sq], -acc[v]);
+                        }
+                    }
+                    continue;
+                }
                 const int xrow = ri[row_l];
                 const bool rok = k0 + l15 < r;
 #pragma unroll
