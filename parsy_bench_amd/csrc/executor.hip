@@ -456,7 +456,8 @@ static int one_begin(parsy_plan* pl, bool backward, int nrhs, hipStream_t stream
     return 0;
 }
 
-static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream) {
+// (zero_words = false: the caller's k_solve_arm_wide launch zeroes the status word and the ticket counters)
+static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream, bool zero_words = true) {
     pl->solve_status_word = nullptr;
     if (pl->epoch > INT_MAX - 2 * passes - 2) {
         PARSY_HIP(hipMemsetAsync(pl->dp.flags, 0, (size_t)pl->n_flags * sizeof(int), stream));
@@ -464,9 +465,11 @@ static int solve_begin(parsy_plan* pl, int passes, hipStream_t stream) {
         pl->epoch = 0;
     }
     pl->epoch += 1;  // first pass uses this value; the kernels add the pass index
-    PARSY_HIP(hipMemsetAsync(pl->dp.sinfo, 0, sizeof(int), stream));
-    PARSY_HIP(hipMemsetAsync(pl->dp.stickets, 0, (size_t)std::max(pl->S.n_solve_chain_launches, 1) * sizeof(int),
-                             stream));
+    if (zero_words) {
+        PARSY_HIP(hipMemsetAsync(pl->dp.sinfo, 0, sizeof(int), stream));
+        PARSY_HIP(hipMemsetAsync(pl->dp.stickets, 0, (size_t)std::max(pl->S.n_solve_chain_launches, 1) * sizeof(int),
+                                 stream));
+    }
     // diagnostic: PARSY_DEBUG_SOLVE_STALL=1 makes every waiter of the chain launches wait for an epoch that
     // is never published -- the timeout path of the hand-offs, exercised by the tests
     const char* st = std::getenv("PARSY_DEBUG_SOLVE_STALL");
@@ -504,7 +507,9 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     }
     // one epoch per pass of right-hand sides (what the chain launches publish / wait for)
     const int passes = (nrhs + 3) / 4;
-    if (solve_begin(pl, passes, stream) != 0) return -1;
+    // (several right-hand sides and wide supernodes: one prologue launch instead of memsets + a fill of n x nrhs entries)
+    const bool arm_wide = nrhs > 1 && !pl->S.solve_wide_list.empty() && !pl->old_mrhs_chain;
+    if (solve_begin(pl, passes, stream, !arm_wide) != 0) return -1;
     if (pl->S.max_width > kTile && pl->xscratch_len < need) {
         if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
         pl->xscratch = nullptr;
@@ -525,7 +530,11 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     // the chain launches hand x over through xscratch itself (armed: see solve_arm_handoff) and finish a block
     // column with a product with its inverse diagonal block
     if (!pl->S.solve_wide_list.empty()) {
-        PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
+        if (arm_wide)
+            launch_solve_arm_wide(pl->dp, (int)pl->S.solve_wide_list.size() / 2, pl->xscratch, nrhs, ldx, 0,
+                                  std::max(pl->S.n_solve_chain_launches, 1), stream);
+        else
+            PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
         launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
     }
     if (sub_tiers_usable(pl, nrhs, ldx) && pl->S.sub_cover_level >= 0) {
@@ -701,7 +710,14 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     }
     // one epoch per pass of right-hand sides (what the chain kernel publishes / waits for)
     const int passes = (nrhs + 7) / 8;
-    if (solve_begin(pl, passes, stream) != 0) return -1;
+    {
+        const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
+        pl->old_mrhs_chain = e && e[0] == '1';
+    }
+    // (several right-hand sides on the armed-buffer chain launches: one prologue launch, below)
+    const bool arm_wide = nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain && pl->S.n_solve_wide > 0 &&
+                          !pl->S.solve_wide_list.empty() && pl->S.solve_fix_list.empty();
+    if (solve_begin(pl, passes, stream, !arm_wide) != 0) return -1;
     // (many right-hand sides: k_solve_blocks_mrhs on the armed buffer; PARSY_OLD_MRHS_CHAIN=1: the flag protocol of rounds 1-2)
     {
         const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
@@ -742,6 +758,9 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
     // the chain launches hand x over through xscratch itself (one right-hand side: k_solve_chain_w; many:
     // k_solve_blocks_mrhs): every entry holds the armed pattern when the solve starts
     if (nrhs == 1 && pl->S.n_solve_wide > 0) PARSY_HIP(solve_arm_handoff(pl->xscratch, ldx, stream));
+    else if (arm_wide)
+        launch_solve_arm_wide(pl->dp, (int)pl->S.solve_wide_list.size() / 2, pl->xscratch, nrhs, ldx, ldq,
+                              std::max(pl->S.n_solve_chain_launches, 1), stream);
     else if (nrhs >= solve_mrhs_min() && !pl->old_mrhs_chain && pl->S.n_solve_wide > 0)
         PARSY_HIP(solve_arm_handoff(pl->xscratch, need, stream));
     launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);

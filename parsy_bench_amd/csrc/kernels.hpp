@@ -107,6 +107,9 @@ int solve_sub_mrhs_min();   // right-hand sides from which those kernels take th
 int solve_mrhs_min();
 int solve_small_mrhs_min();
 hipError_t solve_arm_handoff(double* xscratch, int64_t n, hipStream_t stream);
+// several right-hand sides: status word + ticket counters zeroed and the hand-off buffer armed at the wide supernodes' columns
+void launch_solve_arm_wide(const DevicePattern& P, int npairs, double* xscratch, int nrhs, int ldx, int ldq, int ntickets,
+                           hipStream_t stream);
 void launch_diag_inverse(const DevicePattern& P, int count, const double* L, double* dinv,
                          hipStream_t stream);
 void launch_bsolve_chain_w(const DevicePattern& P, int first, int count, const double* L, const double* dinv,
