@@ -393,6 +393,19 @@ def main():
         dt_b = timed(bsolve_step, warmup, steps, collective=False)
         if plan.solve_status() != 0:
             raise SystemExit(f"backward solve: a hand-off wait timed out (solve status {plan.solve_status()}, nrhs = {nrhs})")
+        # (the timed steps above include the copy that restores the right-hand side -- the solve works in place --: n x nrhs
+        # doubles read and written, 0.1 ms of a 64-right-hand-side step on the parabolic_fem-class input.  Beside them: the
+        # device time of the solve's own launches, hipEvents around one solve, best of three)
+        dev_ms = []
+        for fn in (plan.solve_device, plan.backsolve_device):
+            t = []
+            for _ in range(3):
+                X.copy_(B)
+                fn(L.data_ptr(), X.data_ptr(), nrhs, sym.n, stream)
+                torch.cuda.synchronize()
+                t.append(plan.last_solve_ms())
+            dev_ms.append(min(t))
+        measure_solves.device_ms = tuple(dev_ms)
         # the backward solve is validated once, untimed: c = (P A P') 1 from A itself (host, scipy), then
         # forward + backward solve of L L' x = c must return ones in every column
         import scipy.sparse as sp
@@ -835,7 +848,12 @@ def main():
                                        "algorithmic_GBps": bytes_q / (dsq / 10) / 1e9,
                                        "frac_of_hbm_peak": bytes_q / (dsq / 10) / 1e9 / HBM_PEAK_GBS,
                                        "backward_ms_per_block_solve": dbq / 10 * 1e3, "max_abs_err_vs_ones": eq,
-                                       "forward_backward_max_abs_err_vs_ones": ebq}
+                                       "forward_backward_max_abs_err_vs_ones": ebq,
+                                       "device_ms_forward": measure_solves.device_ms[0],
+                                       "device_ms_backward": measure_solves.device_ms[1],
+                                       "timing": "ms_per_block_solve: 10 steps back to back, each step = a copy that restores the "
+                                                 "right-hand side (the solve is in place) + the solve; device_ms_*: hipEvents around "
+                                                 "one solve's launches, best of three"}
             extras["parabolic_fem"] = pf3
             del pl3
             out["other_configs"] = extras
