@@ -664,7 +664,91 @@ __device__ __forceinline__ void lower_bound3(const int32_t* __restrict__ a, int 
 // transposed into the (unused) strict upper triangle of the same sub-block:
 // Dg[(16b+r)*ld + 16b+c] = inv(L_bb)[r][c] for r > c.  A TRSM against Ljj is then all products
 // (what a blocked dtrsm does): X_b = (B_b - sum_{p<b} X_p L_bp') inv(L_bb)'.  Ends with a workgroup barrier.
+// (round 5) One WAVE per 16 x 16 sub-block, one ENTRY per lane, by halves -- inv [A 0; B C] = [inv A, 0; -inv(C) B inv(A),
+// inv C]: the four 4 x 4 diagonal blocks by substitution (lane = (block, row, column)), then the two 4 x 4 and the one
+// 8 x 8 off-diagonal blocks as two small products each (T = B inv(A), then -inv(C) T; T goes through 64 doubles of scratch).
+// Five LDS round trips of a few reads each: about 0.5 us.  The form before (kept below, PARSY_INVERT16_COLUMNS) gave a
+// column to a thread and walked its 16 rows one after the other, every second multiply-add waiting for its own LDS
+// read: 3.7 us of the walker's 28.6-us step and ~2 us of every other tile's TRSM.  Scratch: a 16 x 16 block of Dg ABOVE the
+// block diagonal (rows of an earlier sub-block, columns of a later one: zeros that nothing reads -- the TRSM takes
+// L(b, p), p < b, from below the diagonal and the inverses from the upper triangles of the diagonal sub-blocks).
+// Divisions: none (invd holds the reciprocals of the diagonal).
 __device__ __forceinline__ void invert_diag_blocks(lds_f64* __restrict__ Dg, lds_f64* __restrict__ invd) {
+#ifndef PARSY_INVERT16_COLUMNS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);   // sub-block = wave
+    lds_f64* __restrict__ B0 = Dg + (16 * b) * kLdDiag + 16 * b;      // L[i][c] = B0[c * ld + i]; W[r][c] (r > c) -> B0[r * ld + c]
+    const lds_f64* __restrict__ dv = invd + 16 * b;
+    // scratch block (row block, column block): (0,1) (0,2) (0,3) (1,3)
+    lds_f64* __restrict__ Sb = Dg + (16 * (b < 3 ? b + 1 : 3)) * kLdDiag + (b < 3 ? 0 : 16);
+    auto SC = [&](int e) -> lds_f64& { return Sb[(e >> 4) * kLdDiag + (e & 15)]; };
+    // (every LDS read below is unconditional -- positions that are not part of the inverse yet are read and replaced by a
+    // select -- so that a phase's reads are in flight together: with the reads inside the selects each one was waited for)
+    {   // 4 x 4 diagonal blocks: lane = (d, i', k'): column k' of inv(L_dd) by substitution, entry i'
+        const int d4 = 4 * (lane >> 4), ip = (lane >> 2) & 3, kp = lane & 3;
+        const lds_f64* __restrict__ T = B0 + d4 * kLdDiag + d4;
+        const double d0 = dv[d4], d1 = dv[d4 + 1], d2 = dv[d4 + 2], d3 = dv[d4 + 3];
+        const double t10 = T[1], t20 = T[2], t30 = T[3], t21 = T[kLdDiag + 2], t31 = T[kLdDiag + 3], t32 = T[2 * kLdDiag + 3];
+        const double y0 = kp == 0 ? d0 : 0.0;
+        const double y1 = kp == 1 ? d1 : -d1 * (t10 * y0);
+        const double y2 = kp == 2 ? d2 : -d2 * fma(t21, y1, t20 * y0);
+        const double y3 = kp == 3 ? d3 : -d3 * fma(t32, y2, fma(t31, y1, t30 * y0));
+        const double y = ip == 1 ? y1 : ip == 2 ? y2 : y3;
+        if (ip > kp) B0[(d4 + ip) * kLdDiag + d4 + kp] = y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // the 4 x 4 blocks below the diagonal of the two 8 x 8 blocks: lanes 0..31 = (e, i, j)
+        const int e8 = 8 * ((lane >> 4) & 1), i = (lane >> 2) & 3, j = lane & 3;
+        double lr[4], wa[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            lr[m] = B0[(e8 + m) * kLdDiag + e8 + 4 + i];   // L[e8 + 4 + i][e8 + m]
+            wa[m] = B0[(e8 + m) * kLdDiag + e8 + j];       // inv(A)[m][j] where m > j
+        }
+        const double dj = dv[e8 + j], di = dv[e8 + 4 + i];
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) t = fma(lr[m], m > j ? wa[m] : (m == j ? dj : 0.0), t);
+        if (lane < 32) SC(lane) = t;
+        __builtin_amdgcn_wave_barrier();
+        double wc[4], tt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            wc[m] = B0[(e8 + 4 + i) * kLdDiag + e8 + 4 + m];   // inv(C)[i][m] where i > m
+            tt[m] = SC((lane & 16) + 4 * m + j);
+        }
+        double w = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w = fma(i > m ? wc[m] : (i == m ? di : 0.0), tt[m], w);
+        if (lane < 32) B0[(e8 + 4 + i) * kLdDiag + e8 + j] = -w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // the 8 x 8 block below the diagonal: lane = (i, j)
+        const int i = lane >> 3, j = lane & 7;
+        double lr[8], wa[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            lr[m] = B0[m * kLdDiag + 8 + i];   // L[8 + i][m]
+            wa[m] = B0[m * kLdDiag + j];       // inv(A)[m][j] where m > j
+        }
+        const double dj = dv[j], di = dv[8 + i];
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) t = fma(lr[m], m > j ? wa[m] : (m == j ? dj : 0.0), t);
+        SC(lane) = t;   // (the scratch reads of the step before were issued earlier: LDS operations of a wave execute in order)
+        __builtin_amdgcn_wave_barrier();
+        double wc[8], tt[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            wc[m] = B0[(8 + i) * kLdDiag + 8 + m];   // inv(C)[i][m] where i > m
+            tt[m] = SC(8 * m + j);
+        }
+        double w = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) w = fma(i > m ? wc[m] : (i == m ? di : 0.0), tt[m], w);
+        B0[(8 + i) * kLdDiag + j] = -w;
+    }
+#else
     const int tid = threadIdx.x;
     if (tid < kTile) {
         const int b16 = (tid >> 4) * 16, c = tid & 15;
@@ -683,6 +767,7 @@ __device__ __forceinline__ void invert_diag_blocks(lds_f64* __restrict__ Dg, lds
         for (int rr = 1; rr < 16; ++rr)
             if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
     }
+#endif
     // a barrier for LDS alone: vector-memory loads the caller has in flight (the walker's next diagonal tile) stay
     // in flight (__syncthreads() would wait for them: 1.5 us of the walker's step)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
