@@ -1604,7 +1604,21 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+#ifndef PARSY_WALKER_LDS_TRSM
+            // (round 5) tile (J+1,J) straight into the accumulator layout of the TRSM below -- wave q: rows 16 q + l15 of the
+            // tile, xa[g][v] = column 16 g + kq + 4 v (lanes along the rows: 128-byte segments)
+            double4_t xa[4];
+            {
+                const int row = row1 + 16 * wave + l15;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        xa[g][v] = row < r ? ld_sc1(&G[(int64_t)(col0 + 16 * g + kq + 4 * v) * ld + row]) : 0.0;
+            }
+#else
             load_b();
+#endif
             TRACE(J, 4);
             // Diagonal tile J is published as soon as its stores have landed, without a workgroup
             // barrier: every wave drains its own stores (behind the loads it has to wait for anyway)
@@ -1616,18 +1630,64 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                 if (arrived == kThreads / 64 - 1)
                     __hip_atomic_store(&tflags[f_diag], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#ifdef PARSY_WALKER_LDS_TRSM
 #pragma unroll
             for (int q = 0; q < kSub * kSub / 64; ++q) {
                 const int e = q * 64 + lane;
                 Tw[(e >> 5) * kLdSub + (e & 31)] = bv[q];
             }
-            __syncthreads();  // Ljj and the tile are in LDS
+#endif
+            __syncthreads();  // Ljj (and, LDS form, the tile) are in LDS
             TRACE(J, 3);
             load_c();  // lands behind the TRSM
             invert_diag_blocks((lds_f64*)dgbuf, (lds_f64*)invd);
             TRACE(J, 10);
+#ifndef PARSY_WALKER_LDS_TRSM
+            {
+                // The blocked TRSM on the accumulators, as the other tiles do it ("finishes in REGISTERS"): in the transposed
+                // form X_b' = inv(L_bb) (B_b' - sum_{p<b} L_bp X_p') register u of a 16-column block IS the operand of k step u
+                // of the next product -- no LDS round trip between the four blocks (the LDS form: 3.2 us of the step) --, then X
+                // goes to the panel from the registers and, for the SYRK, into the tile buffer.
+                const lds_f64* __restrict__ Dgl = (const lds_f64*)dgbuf;
+                const lds_f64* __restrict__ iv = (const lds_f64*)invd;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int p = 0; p < b; ++p)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = 16 * p + kq + 4 * u;
+                            const double lv = Dgl[k * kLdDiag + 16 * b + l15];         // L[16 b + j][k]
+                            xa[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, xa[p][u], xa[b], 0, 0, 1);
+                        }
+                    double4_t x = {0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kq + 4 * u, j = l15;
+                        double wv = 0.0;                                            // inv(L_bb)'[k][j] = inv(L_bb)[j][k]
+                        if (j > k) wv = Dgl[(16 * b + j) * kLdDiag + 16 * b + k];
+                        else if (j == k) wv = iv[16 * b + k];
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, xa[b][u], x, 0, 0, 0);
+                    }
+                    xa[b] = x;
+                }
+                TRACE(J, 5);
+                const int row = row1 + 16 * wave + l15;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = 16 * g + kq + 4 * v;
+                        if (row < r) st_sc1(&G[(int64_t)(col0 + c) * ld + row], xa[g][v]);
+                        cell(Tflat, 16 * wave + l15, c) = xa[g][v];
+                    }
+                __syncthreads();   // X is in the tile buffer: the SYRK reads other waves' rows
+            }
+#else
             invert_and_trsm_inline<false>((lds_f64*)Tflat, (lds_f64*)dgbuf, (lds_f64*)invd, kTile);
             TRACE(J, 5);
+#endif
+#ifdef PARSY_WALKER_LDS_TRSM
             {   // X = final tile (J+1,J): this wave's quadrant, all LDS reads first, then the stores
                 const int sr = row1 + kSub * wa, nr = min(kSub, r - sr), scx = col0 + kSub * wb;
                 double xq[kSub * kSub / 64];
@@ -1643,6 +1703,7 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                     if (rr < nr) st_sc1(&G[(int64_t)(scx + cc) * ld + sr + rr], xq[q]);
                 }
             }
+#endif
             TRACE(J, 11);
             // X is published the same way (drain half way through the SYRK below).
             auto publish_x_wave = [&]() {

@@ -6,7 +6,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from parsy_bench_amd import _native as N
-N._LIB_PATH = ROOT / "tools" / "libparsy_stamps.bin"
+import os
+N._LIB_PATH = Path(os.environ.get("PARSY_STAMPS_LIB", str(ROOT / "tools" / "libparsy_stamps.bin")))
 from parsy_bench_amd import api, inspector as I, matrices as M
 A, perm = M.workload(sys.argv[1] if len(sys.argv) > 1 else "nd24k")
 sym = I.analyze(A, perm)
