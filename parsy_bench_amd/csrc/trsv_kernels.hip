@@ -40,25 +40,84 @@ __device__ __forceinline__ void block_solve_inv16(double* Dg, double* invd, doub
     block_solve_apply16(Dg, invd, xs, w, nq, tid);
 }
 // (the inversions alone: they do not depend on x -- k_solve_one does them before it waits for its x; ends synchronised)
+// (round 5: one wave per 16 x 16 sub-block, one entry per lane, by halves -- inv [A 0; B C] = [inv A, 0; -inv(C) B inv(A),
+// inv C] --, as chol_kernels.hip's invert_diag_blocks: the form before gave a column to a thread and walked its 16 rows one
+// after the other (3.7 us).  Scratch: a 16 x 16 block of Dg above the block diagonal -- zeros that nothing reads.  Needs the
+// whole workgroup of kThreads = 256: wave b = sub-block b.)
 __device__ __forceinline__ void block_invert16(double* Dg, double* invd, int w, int tid) {
     if (tid < kTile) invd[tid] = 1.0 / Dg[tid * kLdDiag + tid];
     __syncthreads();
-    if (tid < kTile && (tid & ~15) < w) {
-        const int b16 = tid & ~15, c = tid & 15;
-        double y[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) y[k] = (k == c) ? invd[b16 + k] : 0.0;
-#pragma unroll
-        for (int rr = 1; rr < 16; ++rr) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < rr; ++k) sacc = fma(Dg[(b16 + k) * kLdDiag + b16 + rr], y[k], sacc);
-            y[rr] = (rr > c) ? -sacc * invd[b16 + rr] : y[rr];
+    const int lane = tid & 63;
+    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (16 * b < w) {
+        double* __restrict__ B0 = Dg + (16 * b) * kLdDiag + 16 * b;      // L[i][c] = B0[c * ld + i]; W[r][c] (r > c) -> B0[r * ld + c]
+        const double* __restrict__ dv = invd + 16 * b;
+        double* __restrict__ Sb = Dg + (16 * (b < 3 ? b + 1 : 3)) * kLdDiag + (b < 3 ? 0 : 16);
+        auto SC = [&](int e) -> double& { return Sb[(e >> 4) * kLdDiag + (e & 15)]; };
+        {   // 4 x 4 diagonal blocks: lane = (d, i', k'): column k' of inv(L_dd) by substitution, entry i'
+            const int d4 = 4 * (lane >> 4), ip = (lane >> 2) & 3, kp = lane & 3;
+            const double* __restrict__ T = B0 + d4 * kLdDiag + d4;
+            const double d0 = dv[d4], d1 = dv[d4 + 1], d2 = dv[d4 + 2], d3 = dv[d4 + 3];
+            const double t10 = T[1], t20 = T[2], t30 = T[3], t21 = T[kLdDiag + 2], t31 = T[kLdDiag + 3], t32 = T[2 * kLdDiag + 3];
+            const double y0 = kp == 0 ? d0 : 0.0;
+            const double y1 = kp == 1 ? d1 : -d1 * (t10 * y0);
+            const double y2 = kp == 2 ? d2 : -d2 * fma(t21, y1, t20 * y0);
+            const double y3 = kp == 3 ? d3 : -d3 * fma(t32, y2, fma(t31, y1, t30 * y0));
+            const double y = ip == 1 ? y1 : ip == 2 ? y2 : y3;
+            if (ip > kp) B0[(d4 + ip) * kLdDiag + d4 + kp] = y;
         }
-        __builtin_amdgcn_s_waitcnt(0);  // every read of the sub-block precedes the in-place writes
+        __builtin_amdgcn_wave_barrier();
+        {   // the 4 x 4 blocks below the diagonal of the two 8 x 8 blocks: lanes 0..31 = (e, i, j)
+            const int e8 = 8 * ((lane >> 4) & 1), i = (lane >> 2) & 3, j = lane & 3;
+            double lr[4], wa[4];
 #pragma unroll
-        for (int rr = 1; rr < 16; ++rr)
-            if (rr > c) Dg[(b16 + rr) * kLdDiag + b16 + c] = y[rr];
+            for (int m = 0; m < 4; ++m) {
+                lr[m] = B0[(e8 + m) * kLdDiag + e8 + 4 + i];
+                wa[m] = B0[(e8 + m) * kLdDiag + e8 + j];
+            }
+            const double dj = dv[e8 + j], di = dv[e8 + 4 + i];
+            double t = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) t = fma(lr[m], m > j ? wa[m] : (m == j ? dj : 0.0), t);
+            if (lane < 32) SC(lane) = t;
+            __builtin_amdgcn_wave_barrier();
+            double wc[4], tt[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                wc[m] = B0[(e8 + 4 + i) * kLdDiag + e8 + 4 + m];
+                tt[m] = SC((lane & 16) + 4 * m + j);
+            }
+            double wv = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wv = fma(i > m ? wc[m] : (i == m ? di : 0.0), tt[m], wv);
+            if (lane < 32) B0[(e8 + 4 + i) * kLdDiag + e8 + j] = -wv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // the 8 x 8 block below the diagonal: lane = (i, j)
+            const int i = lane >> 3, j = lane & 7;
+            double lr[8], wa[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                lr[m] = B0[m * kLdDiag + 8 + i];
+                wa[m] = B0[m * kLdDiag + j];
+            }
+            const double dj = dv[j], di = dv[8 + i];
+            double t = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) t = fma(lr[m], m > j ? wa[m] : (m == j ? dj : 0.0), t);
+            SC(lane) = t;
+            __builtin_amdgcn_wave_barrier();
+            double wc[8], tt[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                wc[m] = B0[(8 + i) * kLdDiag + 8 + m];
+                tt[m] = SC(8 * m + j);
+            }
+            double wv = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) wv = fma(i > m ? wc[m] : (i == m ? di : 0.0), tt[m], wv);
+            B0[(8 + i) * kLdDiag + j] = -wv;
+        }
     }
     __syncthreads();
 }
