@@ -542,18 +542,26 @@ def main():
             dt_s, dt_b, solve_err, BX, back_err = measure_solves(solve_plan, sym, L, nrhs, args.warmup, args.steps)
     elif not args.no_solve:
         # the factor is distributed (every piece final on its owner): the solves run sharded -- every rank its own
-        # subtrees, ONE reduce (forward) / broadcast (backward) of x at the cut, the supernodes above the cut on rank 0
-        # after their panels were collected there once (untimed: once per factorization, not per solve)
-        root_plan = api.Plan(sym, local_rank) if rank == 0 else None
-        SS = MG.ShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(plan), MG.PlanSolver(root_plan) if rank == 0 else None,
-                             stage_on_host=(backend != "nccl"))
-        moved = SS.gather_root_part(L)
+        # subtrees; the supernodes above the cut are solved WHERE THEY WERE FACTORED, the ranks going through the etree
+        # levels above the cut together with one all-reduce of the level's x rows per level (LeveledShardedSolve; only
+        # the pieces of a SPLIT supernode move, once per factorization, untimed).  Beside it, for comparison, the form of
+        # rounds 3-4: the panels above the cut collected on rank 0, which solves them alone (ShardedSolve).
         import scipy.sparse as sp
         A2 = sp.csc_matrix((sym.A2x, sym.A2i, sym.A2p), shape=(sym.n, sym.n))
         ones = np.ones(sym.n)
         c = A2 @ ones + A2.T @ ones - A2.diagonal()
         C = torch.from_numpy(c).to(dev).repeat(nrhs).contiguous()
         holder = {}
+        top_plan = api.Plan(sym, local_rank)
+        LS = MG.LeveledShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(plan), MG.PlanSolver(top_plan),
+                                    top_plan.solve_levels(), stage_on_host=(backend != "nccl"))
+        moved_lev = LS.gather_solve_parts(L)
+        held = torch.tensor([float(sum(int(pieces["value_end"][p] - pieces["value_begin"][p]) for p in range(len(D.owner))
+                                       if D.owner[p] == rank or (D.in_subtree[p] == 0 and LS.sn_owner[pieces["supernode"][p]] == rank)))],
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        held_all = [torch.zeros_like(held) for _ in range(world)]
+        dist.all_gather(held_all, held)
+        SS = LS
 
         def fwd():
             holder["y"] = SS.forward(L, C, nrhs, stream)
@@ -561,18 +569,40 @@ def main():
         def bwd():
             holder["x"] = SS.backward(L, holder["y"], nrhs, stream)
 
+        def check(what):
+            if plan.solve_status() != 0 or top_plan.solve_status() != 0:
+                raise SystemExit(f"sharded solve ({what}): a hand-off wait timed out")
+            if rank == 0:
+                err = float((holder["x"] - 1.0).abs().max().item())
+                if not (err <= BACK_TOL):
+                    raise SystemExit(f"sharded solves ({what}) are off: max|x - 1| = {err:.3e} for L L' x = (P A P') 1")
+                return err
+            return None
+
         dt_s = timed(fwd, args.warmup, args.steps)
         dt_b = timed(bwd, args.warmup, args.steps)
-        if plan.solve_status() != 0 or (root_plan is not None and root_plan.solve_status() != 0):
-            raise SystemExit("sharded solve: a hand-off wait timed out")
+        back_err = check("leveled")
+        exchanged = LS.exchanged
+        # the comparison form (its plan for the part above the cut: rank 0's top_plan with another mask)
+        SS = MG.ShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(plan), MG.PlanSolver(top_plan) if rank == 0 else None,
+                             stage_on_host=(backend != "nccl"))
+        moved = SS.gather_root_part(L)
+        dt_s_root = timed(fwd, args.warmup, args.steps)
+        dt_b_root = timed(bwd, args.warmup, args.steps)
+        check("root rank")
         if rank == 0:
-            back_err = float((holder["x"] - 1.0).abs().max().item())
-            if not (back_err <= BACK_TOL):
-                raise SystemExit(f"sharded solves are off: max|x - 1| = {back_err:.3e} for L L' x = (P A P') 1")
-            sharded = {"root_part_elements_collected_once": int(moved),
-                       "supernodes_above_the_cut": int(SS.root_mask.sum()),
-                       "note": "forward: subtree solves on their owners, one reduce of x, root part on rank 0; backward: "
-                               "root part on rank 0, one broadcast of x, subtree solves, one reduce to collect x"}
+            sharded = {"form": "leveled: supernodes above the cut solved by the ranks that factored them",
+                       "supernodes_above_the_cut": int(LS.root_mask.sum()), "levels_above_the_cut": len(LS.top_levels),
+                       "x_entries_all_reduced_per_solve": int(exchanged),
+                       "elements_moved_once_per_factorization": int(moved_lev),
+                       "factor_entries_held_per_rank": [int(t.item()) for t in held_all],
+                       "root_rank_form": {"forward_ms": dt_s_root / args.steps * 1e3, "backward_ms": dt_b_root / args.steps * 1e3,
+                                          "elements_moved_once_per_factorization": int(moved),
+                                          "note": "rounds 3-4: panels above the cut collected on rank 0, one reduce / "
+                                                  "broadcast of x at the cut"},
+                       "note": "forward: subtree solves on their owners, then per etree level above the cut one all-reduce of "
+                               "the level's x rows and the owners' level launches (parsy_solve_levels_device); backward: the "
+                               "same from the top level down, then the subtree solves and one reduce that collects x"}
         dist.barrier()
 
     # ---- per-kernel timing (hipEvents on the launch stream, launches serialised) for the roofline ----

@@ -273,6 +273,19 @@ int parsy_solve_status(parsy_plan* plan);
  * for the permuted system, x = P' L'^-1 L^-1 P b. Asynchronous on `stream`. */
 int parsy_backsolve_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs, int ldx,
                            void* stream);
+/* A forward / backward solve in STEPS of etree levels (triangularSolve/Triangular_BCSC.h:115-164: one level set at a time):
+ * the level launches of the plan's active supernodes (parsy_plan_set_active) whose etree level lies in
+ * [level_begin, level_end).  A solve that is distributed above the cut puts its exchange steps between two calls, as
+ * parsy_factor_level does for the factorization.  flags: */
+/* The etree level of every supernode (nsuper entries; NULL: only the count) as the solves' launches go by it; returns the
+ * number of levels.  A supernode's rows below its own columns belong to supernodes of higher levels. */
+int parsy_plan_solve_levels(const parsy_plan* plan, int32_t* level);
+#define PARSY_SOLVE_FIRST 1     /* the first step of a solve: status word, hand-off buffer, inverse diagonal blocks */
+#define PARSY_SOLVE_LAST 2      /* the last step */
+#define PARSY_SOLVE_BACKWARD 4  /* L' x = y (the steps then go from the root level down) */
+/* X keeps the caller's layout (n x nrhs, leading dimension ldx); asynchronous on `stream`; parsy_solve_status as usual. */
+int parsy_solve_levels_device(parsy_plan* plan, const double* d_lValues, double* d_x, int nrhs, int ldx, void* stream,
+                              int level_begin, int level_end, int flags);
 /* d_b = L * 1 on the stored structure (device pointers, n doubles, overwritten): the right-hand side the
  * reference's triangularTest solves (rhsInitBlocked, common/Util.h:277-288), so that L x = b has x = 1. */
 int parsy_rhs_ones_device(parsy_plan* plan, const double* d_lValues, double* d_b, void* stream);

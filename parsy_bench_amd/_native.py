@@ -76,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "parsy_last_error", "parsy_device_count", "parsy_analyze", "parsy_symbolic_free",
     "parsy_symbolic_get", "parsy_plan_from_symbolic", "parsy_grid_spd_lower",
     "parsy_grid_nested_dissection", "parsy_order_nd", "parsy_plan_profile", "parsy_plan_profile_collect",
-    "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve2_host",
+    "parsy_plan_profile_get", "parsy_factor_device_ex", "parsy_backsolve_device", "parsy_solve_levels_device", "parsy_plan_solve_levels", "parsy_solve2_host",
     "parsy_rhs_ones_device", "parsy_solve_status", "parsy_copy_segments_device", "parsy_plan_check",
     "parsy_factor_begin", "parsy_factor_level", "parsy_factor_end", "parsy_plan_pieces",
     "parsy_plan_set_active_pieces", "parsy_dist_create", "parsy_dist_destroy", "parsy_dist_get_info",
@@ -125,6 +125,8 @@ def _declare(lib):
     lib.parsy_factor_device_ex.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.parsy_factor_status.argtypes = [vp]
     lib.parsy_solve_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.parsy_plan_solve_levels.argtypes = [vp, vp]
+    lib.parsy_solve_levels_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.parsy_backsolve_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.parsy_solve2_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.parsy_rhs_ones_device.argtypes = [vp, vp, vp, vp]

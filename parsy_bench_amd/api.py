@@ -240,6 +240,20 @@ class Plan:
         if N.lib().parsy_solve_device(self._h, d_lValues, d_x, nrhs, ldx, stream) != 0:
             raise RuntimeError("parsy_solve_device failed: " + N.last_error())
 
+    def solve_levels(self) -> np.ndarray:
+        """The etree level of every supernode, as the launches of the solves go by it (parsy_plan_solve_levels)."""
+        out = np.zeros(self.sym.nsuper, dtype=np.int32)
+        N.lib().parsy_plan_solve_levels(self._h, N.ptr(out))
+        return out
+
+    def solve_levels_device(self, d_lValues: int, d_x: int, nrhs: int, ldx: int, stream: int, level_begin: int, level_end: int,
+                            first: bool, last: bool, backward: bool = False) -> None:
+        """One step of a solve that goes level by level (parsy_solve_levels_device): the active supernodes of the etree
+        levels [level_begin, level_end)."""
+        flags = (1 if first else 0) | (2 if last else 0) | (4 if backward else 0)
+        if N.lib().parsy_solve_levels_device(self._h, d_lValues, d_x, nrhs, ldx, stream, level_begin, level_end, flags) != 0:
+            raise RuntimeError("parsy_solve_levels_device failed: " + N.last_error())
+
     # level by level (the steps of a multi-device run; parsy_factor_device is exactly this sequence) ----
     def factor_begin(self, d_values: int, d_lValues: int, stream: int = 0, init: bool = True) -> None:
         if N.lib().parsy_factor_begin(self._h, d_values, d_lValues, stream, 0 if init else 1) != 0:

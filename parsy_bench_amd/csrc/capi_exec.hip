@@ -404,6 +404,15 @@ int parsy_plan_pieces(const parsy_plan* pl, int32_t* supernode, int32_t* level, 
     return nc;
 }
 
+int parsy_plan_solve_levels(const parsy_plan* pl, int32_t* level) {
+    if (!pl) return -1;
+    const parsy::Schedule& S = pl->S;
+    if (level)
+        for (int l = 0; l < S.nlevels; ++l)
+            for (int q = S.levelPtr[(size_t)l]; q < S.levelPtr[(size_t)l + 1]; ++q) level[S.levelSet[(size_t)q]] = l;
+    return S.nlevels;
+}
+
 // Diagnostics (tools/big_stats.py; not part of the public header): the BIG tasks of the plan as rows of
 // (task, launch = 2 * source level + push, K, rows in the row window, rows in the column window, identity map,
 // first row of the row window - first row of the column window); returns the number of entries (out may be null).
@@ -781,6 +790,15 @@ int parsy_backsolve_device(parsy_plan* pl, const double* d_lValues, double* d_x,
         return -1;
     }
     return parsy::plan_backsolve(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream);
+}
+
+int parsy_solve_levels_device(parsy_plan* pl, const double* d_lValues, double* d_x, int nrhs, int ldx, void* stream,
+                              int level_begin, int level_end, int flags) {
+    if (!pl || !d_lValues || !d_x) {
+        set_last_error("parsy_solve_levels_device: null argument");
+        return -1;
+    }
+    return parsy::plan_solve_levels(pl, d_lValues, d_x, nrhs, ldx, (hipStream_t)stream, level_begin, level_end, flags);
 }
 
 int parsy_copy_segments_device(double* d_dst, const double* d_src, const int64_t* d_dst_off,

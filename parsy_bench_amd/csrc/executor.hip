@@ -559,6 +559,68 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
     return 0;
 }
 
+// A solve in steps of etree levels (the exchange steps of a solve that is distributed above the cut go in between,
+// as parsy_factor_level's do for the factorization): the level launches of the plan's active supernodes whose level lies
+// in [lev0, lev1).  flags: bit 0 = the first step of a solve (status word, tickets, hand-off buffer, inverse diagonal
+// blocks), bit 1 = the last one, bit 2 = backward (levels then go DOWN from step to step).  Level launches only: the
+// caller's layout of X, no ONE launch, no bands (a rank's share of the supernodes has neither).
+int plan_solve_levels(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream, int lev0,
+                      int lev1, int flags) {
+    if (pl->device < 0) {
+        set_last_error("parsy_solve_levels: plan was built without a device (device < 0)");
+        return -1;
+    }
+    if (nrhs < 1 || ldx < pl->S.n || lev0 > lev1) {
+        set_last_error("parsy_solve_levels: need nrhs >= 1, ldx >= n and level_begin <= level_end");
+        return -1;
+    }
+    const bool first = flags & 1, last = flags & 2, backward = flags & 4;
+    const int passes = backward ? (nrhs + 3) / 4 : (nrhs + 7) / 8;
+    const int64_t need = (int64_t)ldx * nrhs;
+    if (first) {
+        if (solve_begin(pl, passes, stream) != 0) return -1;
+        {
+            const char* e = std::getenv("PARSY_OLD_MRHS_CHAIN");
+            pl->old_mrhs_chain = e && e[0] == '1';
+        }
+        if ((pl->S.n_solve_wide > 0 || pl->S.max_width > kTile) && pl->xscratch_len < need) {
+            if (pl->xscratch) PARSY_HIP(hipFree(pl->xscratch));
+            pl->xscratch = nullptr;
+            PARSY_HIP(hipMalloc((void**)&pl->xscratch, (size_t)need * sizeof(double)));
+            pl->xscratch_len = need;
+        }
+        if (!pl->S.solve_wide_list.empty() && !pl->dinv) {
+            const size_t bytes = (size_t)std::max<int64_t>(pl->S.n_dslots, 1) * kTile * kTile * sizeof(double);
+            PARSY_HIP(hipMalloc((void**)&pl->dinv, bytes));
+            pl->device_bytes += (int64_t)bytes;
+        }
+        if (backward && nrhs == 1 && pl->S.n_bpart_slots > 0 && !pl->dp.bpart) {
+            const size_t bytes = (size_t)pl->S.n_bpart_slots * kTile * sizeof(double);
+            PARSY_HIP(hipMalloc((void**)&pl->dp.bpart, bytes));
+            pl->device_bytes += (int64_t)bytes;
+        }
+        PARSY_HIP(hipEventRecord(pl->ev_s0, stream));
+        if (pl->xscratch && (pl->S.n_solve_wide > 0 || !pl->S.solve_wide_list.empty()))
+            PARSY_HIP(solve_arm_handoff(pl->xscratch, (!backward && nrhs == 1) ? (int64_t)ldx : need, stream));
+        if (!pl->S.solve_wide_list.empty())
+            launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
+        pl->solve_ldq = 0;
+        run_begin(pl);
+    }
+    const std::vector<Launch>& seq = backward ? pl->S.bsolve : pl->S.solve;
+    for (size_t li = 0; li < seq.size(); ++li)
+        if ((seq[li].level >= lev0 && seq[li].level < lev1) || (last && seq[li].kind == kLaunchSolveFixup))
+            run_range(pl, seq, li, li + 1, nullptr, d_L, d_x, nrhs, ldx, stream);
+    if (last) {
+        run_end(pl, stream);
+        PARSY_HIP(hipGetLastError());
+        PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
+        pl->epoch += passes;
+        pl->have_s = true;
+    }
+    return 0;
+}
+
 int plan_collect_profile(parsy_plan* pl) {
     // after a synchronised profiled run: add the elapsed time of each launch to its kind
     if (!pl->profile || pl->pev_kind.size() < 2) return -1;

@@ -102,6 +102,8 @@ void plan_factor_abort(parsy_plan* plan, hipStream_t stream);   // error path: d
 int plan_solve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx,
                hipStream_t stream);
 int plan_backsolve(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream);
+int plan_solve_levels(parsy_plan* plan, const double* d_L, double* d_x, int nrhs, int ldx, hipStream_t stream, int lev0,
+                      int lev1, int flags);
 int plan_collect_profile(parsy_plan* plan);
 
 }  // namespace parsy

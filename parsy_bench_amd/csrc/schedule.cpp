@@ -909,6 +909,24 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
     S.active_piece.assign((size_t)npieces, 1);
     for (int t = 0; t < npieces; ++t)
         S.active_piece[t] = active_pieces ? (active_pieces[t] != 0) : S.active[S.csn_real[t]];
+    // A subtree launch of the solves walks its subtree without waiting for anything outside it.  Under a supernode mask
+    // (a rank's share) that holds only for the subtrees the mask contains whole: the active members of the others go to
+    // the level launches, which a solve in steps of levels (plan_solve_levels) separates by its exchange steps.
+    if (S.solve_subtree_all.empty()) {
+        S.solve_subtree_all = S.solve_subtree;
+        S.bsolve_subtree_all = S.bsolve_subtree;
+    }
+    S.solve_subtree = S.solve_subtree_all;
+    S.bsolve_subtree = S.bsolve_subtree_all;
+    if (active)
+        for (auto* sub : {&S.solve_subtree, &S.bsolve_subtree}) {
+            const int count = sub == &S.solve_subtree ? S.n_solve_subtrees : S.n_bsolve_subtrees;
+            std::vector<uint8_t> whole((size_t)std::max(count, 0), 1);
+            for (int t = 0; t < ns; ++t)
+                if ((*sub)[t] >= 0 && !S.active[t]) whole[(size_t)(*sub)[t]] = 0;
+            for (int t = 0; t < ns; ++t)
+                if ((*sub)[t] >= 0 && !whole[(size_t)(*sub)[t]]) (*sub)[t] = -1;
+        }
     S.small_list.clear();
     S.tiles.clear();
     S.n_chain_launches = 0;

@@ -259,6 +259,8 @@ struct Schedule {
     // (forward solve: subtrees of tiny supernodes, one wave each; backward solve: of all supernodes of one block
     // column, one workgroup each)
     std::vector<int32_t> chol_subtree, solve_subtree, bsolve_subtree;
+    std::vector<int32_t> solve_subtree_all, bsolve_subtree_all;   // the subtrees of the whole pattern (build_launches keeps,
+                                                                   // under a mask, those the mask contains whole)
     std::vector<double> chol_cost, solve_cost;
     int n_chol_subtrees = 0, n_solve_subtrees = 0, n_bsolve_subtrees = 0;
     // (begin, end) pairs into small_list / solve_small_list / bsolve_blocks, one per workgroup of a subtree launch

@@ -179,6 +179,10 @@ class PlanSolver:
     def backward(self, L, X, nrhs, n, stream):
         self.plan.backsolve_device(L.data_ptr(), X.data_ptr(), nrhs, n, stream)
 
+    def levels(self, L, X, nrhs, n, stream, level_begin, level_end, first, last, backward):
+        """One step of a solve that goes level by level (LeveledShardedSolve): parsy_solve_levels_device."""
+        self.plan.solve_levels_device(L.data_ptr(), X.data_ptr(), nrhs, n, stream, level_begin, level_end, first, last, backward)
+
 
 class ShardedSolve:
     """Forward / backward solves on the distributed factor: every rank solves the subtrees it owns --
@@ -193,7 +197,7 @@ class ShardedSolve:
     entry (every rank passes the same right-hand side); the result is complete on the root rank."""
 
     def __init__(self, sym, pieces, dist_info, rank: int, dist_mod, sub_solver, root_solver=None, root: int = 0,
-                 stage_on_host: bool = False):
+                 stage_on_host: bool = False, _root_mask: bool = True):
         import torch
         self.n, self.rank, self.root, self.dist = sym.n, rank, root, dist_mod
         self.stage_on_host = stage_on_host
@@ -208,7 +212,7 @@ class ShardedSolve:
         self.keep = torch.from_numpy(mine | (above if rank == root else np.zeros_like(above)))   # columns whose b / x this rank carries
         self.sub, self.rootsolver = sub_solver, root_solver
         self.sub.set_mask(self.sub_mask)
-        if rank == root:
+        if rank == root and _root_mask:
             if root_solver is None:
                 raise ValueError("the root rank needs a solver for the supernodes above the cut")
             root_solver.set_mask(self.root_mask)
@@ -272,5 +276,128 @@ class ShardedSolve:
         self._collect(X, op_reduce=False)                           # everybody gets the rows above the cut
         self.sub.backward(L, X, nrhs, self.n, stream)
         X = self._masked(X, nrhs).contiguous()                      # own subtree columns (+ above the cut on the root)
+        self._collect(X, op_reduce=True)
+        return X
+
+
+class LeveledShardedSolve(ShardedSolve):
+    """ShardedSolve with the supernodes above the cut solved WHERE THEY WERE FACTORED instead of on the root rank: no
+    rank ever holds the whole top of the factor.  A supernode above the cut is solved by the owner of its first piece
+    (`gather_solve_parts` brings the other pieces of a split supernode there, once per factorization -- the panels of
+    whole supernodes do not move at all), and the ranks go through the etree levels above the cut together (the level
+    sets of the reference's leveled solve, Triangular_BCSC.h:115-164), one exchange per level:
+
+    forward   x rows of the level's supernodes: every rank holds the updates ITS supernodes made (subtrees and lower
+              levels) -> all-reduce(SUM) of those rows, then the owners solve (parsy_solve_levels_device) and the other
+              ranks drop the rows;
+    backward  the owners solve the level (top level first), then the level's x rows -- zero on the other ranks -- are
+              all-reduced: every rank has the x its own supernodes below read.
+
+    top_solver: set_mask(mask) / levels(L, X, nrhs, n, stream, level_begin, level_end, first, last, backward) --
+    PlanSolver on a GPU (a second plan of the rank, restricted to the supernodes it solves above the cut).
+    level_of: the etree level of every supernode as the plan's launches go by it (Plan.solve_levels())."""
+
+    def __init__(self, sym, pieces, dist_info, rank: int, dist_mod, sub_solver, top_solver, level_of, root: int = 0,
+                 stage_on_host: bool = False):
+        import torch
+        super().__init__(sym, pieces, dist_info, rank, dist_mod, sub_solver, top_solver, root, stage_on_host, _root_mask=False)
+        first = np.concatenate([[True], np.diff(pieces["supernode"]) != 0])
+        self.sn_owner = dist_info.owner[first].astype(np.int64)          # above the cut: who solves the supernode
+        above = self.root_mask.astype(bool)
+        self.top_mask = (above & (self.sn_owner == rank)).astype(np.uint8)
+        self.top = top_solver
+        self.top.set_mask(self.top_mask)
+        w = np.diff(sym.super)
+        mine = np.repeat(self.sub_mask.astype(bool), w)
+        top_cols = np.repeat(self.top_mask.astype(bool), w)
+        self.keep_in = torch.from_numpy(mine | top_cols)     # forward: the right-hand side of a row enters on ONE rank
+        level_of = np.asarray(level_of)
+        self.top_levels = sorted(set(level_of[above].tolist()))
+        self.level_cols, self.level_own = {}, {}
+        for lev in self.top_levels:
+            sns = np.where(above & (level_of == lev))[0]
+            cols = np.concatenate([np.arange(sym.super[t], sym.super[t + 1]) for t in sns])
+            own = np.concatenate([np.full(int(w[t]), self.sn_owner[t] == rank) for t in sns])
+            self.level_cols[lev] = torch.from_numpy(cols.astype(np.int64))
+            self.level_own[lev] = torch.from_numpy(own.astype(np.float64))
+        self.exchanged = 0        # entries of x all-reduced by the last solve
+
+    def gather_solve_parts(self, L):
+        """The pieces of a split supernode above the cut -> the rank that solves the supernode (the owner of its first
+        piece); runs of consecutive pieces with one sender and one receiver are one message.  Returns the entries moved."""
+        vb, ve = self.pieces["value_begin"], self.pieces["value_end"]
+        owner, below, sn = self.D.owner, self.D.in_subtree, self.pieces["supernode"]
+        dest = self.sn_owner[sn]
+        ops, landing, moved, p, n = [], [], 0, 0, len(owner)
+        while p < n:
+            q = p
+            while q + 1 < n and owner[q + 1] == owner[p] and below[q + 1] == below[p] and dest[q + 1] == dest[p]:
+                q += 1
+            a, b, own, to = int(vb[p]), int(ve[q]), int(owner[p]), int(dest[p])
+            if below[p] == 0 and own != to and b > a:
+                moved += b - a
+                view = L[a:b]
+                if self.rank == to:
+                    buf = view.cpu() if self.stage_on_host else view
+                    if self.stage_on_host:
+                        landing.append((view, buf))
+                    ops.append(self.dist.P2POp(self.dist.irecv, buf, own))
+                elif self.rank == own:
+                    ops.append(self.dist.P2POp(self.dist.isend, view.cpu() if self.stage_on_host else view, to))
+            p = q + 1
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, buf in landing:
+            view.copy_(buf)
+        return moved
+
+    def gather_root_part(self, L):
+        raise RuntimeError("LeveledShardedSolve keeps the panels above the cut on the ranks that solve them: gather_solve_parts")
+
+    def _level_sum(self, Xv, lev, own_only: bool):
+        """All-reduce(SUM) of the x rows of the supernodes of level `lev` above the cut (own_only: a rank contributes the
+        rows it owns, zeros elsewhere)."""
+        idx = self.level_cols[lev].to(Xv.device)
+        own = self.level_own[lev].to(Xv.device)
+        buf = Xv[:, idx]
+        if own_only:
+            buf = buf * own
+        buf = buf.contiguous()
+        if self.stage_on_host and buf.is_cuda:
+            h = buf.cpu()
+            self.dist.all_reduce(h)
+            buf.copy_(h)
+        else:
+            self.dist.all_reduce(buf)
+        self.exchanged += buf.numel()
+        return idx, own, buf
+
+    def forward(self, L, B, nrhs: int = 1, stream: int = 0):
+        """L x = b.  Returns X: complete on the root rank."""
+        X = (B.view(nrhs, self.n) * self.keep_in.to(B.device)).view(-1).contiguous()
+        Xv = X.view(nrhs, self.n)
+        self.exchanged = 0
+        self.sub.forward(L, X, nrhs, self.n, stream)
+        nl = len(self.top_levels)
+        for i, lev in enumerate(self.top_levels):
+            idx, own, buf = self._level_sum(Xv, lev, own_only=False)
+            Xv[:, idx] = buf * own                         # the sum where the supernode is solved, nothing elsewhere
+            self.top.levels(L, X, nrhs, self.n, stream, lev, lev + 1, i == 0, i == nl - 1, False)
+        self._collect(X, op_reduce=True)
+        return X
+
+    def backward(self, L, Y, nrhs: int = 1, stream: int = 0):
+        """L' x = y.  Returns X: complete on the root rank."""
+        X = Y.clone()
+        Xv = X.view(nrhs, self.n)
+        self.exchanged = 0
+        nl = len(self.top_levels)
+        for i, lev in enumerate(reversed(self.top_levels)):
+            self.top.levels(L, X, nrhs, self.n, stream, lev, lev + 1, i == 0, i == nl - 1, True)
+            idx, own, buf = self._level_sum(Xv, lev, own_only=True)
+            Xv[:, idx] = buf
+        self.sub.backward(L, X, nrhs, self.n, stream)
+        X = self._masked(X, nrhs).contiguous()             # own subtree columns (+ above the cut on the root)
         self._collect(X, op_reduce=True)
         return X

@@ -122,7 +122,7 @@ def test_distributed_factorization_matches_single_process(tmp_path, oracle, monk
 # sharded solves on the distributed factor (multigpu.ShardedSolve): subtree solves on their owners, one reduce /
 # broadcast of x at the cut, the supernodes above the cut on the root rank
 # ---------------------------------------------------------------------------
-def _solve_rank_main(rank, world, port, name, out_dir):
+def _solve_rank_main(rank, world, port, name, out_dir, leveled=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -186,8 +186,29 @@ def _solve_rank_main(rank, world, port, name, out_dir):
                     t = xq[c0: c0 + ws] - panel[ws:, :].T @ xq[rows[ws:]]
                     xq[c0: c0 + ws] = np.linalg.solve(np.tril(panel[:ws, :]).T, t)
 
-    SS = MG.ShardedSolve(sym, pieces, D, rank, dist, OracleSolver(), OracleSolver() if rank == 0 else None)
-    moved = SS.gather_root_part(L)
+        def levels(self, Lt, X, nrhs, n, stream, level_begin, level_end, first, last, back):
+            """One step of the leveled form: the masked supernodes of the etree levels [level_begin, level_end)."""
+            keep = self.mask.copy()
+            self.mask = keep & (level_of >= level_begin) & (level_of < level_end)
+            try:
+                (self.backward if back else self.forward)(Lt, X, nrhs, n, stream)
+            finally:
+                self.mask = keep
+
+    if leveled:
+        # above the cut every supernode is solved where it was factored: rank 0 never sees the other ranks' panels
+        level_of = plan.solve_levels()
+        SS = MG.LeveledShardedSolve(sym, pieces, D, rank, dist, OracleSolver(), OracleSolver(), level_of)
+        moved = SS.gather_solve_parts(L)
+        held = ~torch.isnan(L)
+        first = np.concatenate([[True], np.diff(pieces["supernode"]) != 0])
+        for p in np.where(D.in_subtree == 0)[0]:       # a panel above the cut is on exactly one rank: its solver
+            a, b = int(pieces["value_begin"][p]), int(pieces["value_end"][p])
+            want = D.owner[first][pieces["supernode"][p]] == rank or D.owner[p] == rank
+            assert bool(held[a:b].all()) == bool(want) or b == a
+    else:
+        SS = MG.ShardedSolve(sym, pieces, D, rank, dist, OracleSolver(), OracleSolver() if rank == 0 else None)
+        moved = SS.gather_root_part(L)
     rng = np.random.default_rng(17)            # (same seed on every rank: the right-hand side is replicated)
     nrhs = 3
     B = torch.from_numpy(rng.standard_normal(sym.n * nrhs))
@@ -198,17 +219,19 @@ def _solve_rank_main(rank, world, port, name, out_dir):
         np.save(Path(out_dir) / "Xf.npy", Xf.numpy())
         np.save(Path(out_dir) / "Xb.npy", Xb.numpy())
         np.save(Path(out_dir) / "moved.npy", np.array([moved, int(SS.root_mask.sum()), int(SS.sub_mask.sum())]))
+    if leveled:
+        np.save(Path(out_dir) / f"top_{rank}.npy", np.array([int(SS.top_mask.sum()), len(SS.top_levels), SS.exchanged]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("mid3d", 2), ("lap30", 4)])
-def test_sharded_solves_match_the_serial_solves(tmp_path, oracle, name, world):
+@pytest.mark.parametrize("name,world,leveled", [("mid3d", 2, False), ("lap30", 4, False), ("mid3d", 2, True), ("lap30", 4, True)])
+def test_sharded_solves_match_the_serial_solves(tmp_path, oracle, name, world, leveled):
     import torch.multiprocessing as mp
     from conftest import problem
     from parsy_bench_amd import inspector as I
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_solve_rank_main, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    port = 31500 + (os.getpid() % 2000) + (2000 if leveled else 0)
+    mp.spawn(_solve_rank_main, args=(world, port, name, str(tmp_path), leveled), nprocs=world, join=True)
     A, perm, sym = problem(name)
     ok, lv, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
     B = np.load(tmp_path / "B.npy").reshape(3, sym.n)
@@ -216,6 +239,12 @@ def test_sharded_solves_match_the_serial_solves(tmp_path, oracle, name, world):
     Xb = np.load(tmp_path / "Xb.npy").reshape(3, sym.n)
     moved, nroot, nsub0 = np.load(tmp_path / "moved.npy")
     assert nroot >= 1 and nsub0 >= 1
+    if leveled:
+        tops = np.array([np.load(tmp_path / f"top_{r}.npy") for r in range(world)])
+        assert tops[:, 0].sum() == nroot, "every supernode above the cut is solved by exactly one rank"
+        assert tops[0, 1] >= 1 and tops[0, 2] > 0
+        if world >= 4:
+            assert (tops[:, 0] > 0).sum() >= 2, "the supernodes above the cut were all solved by one rank"
     for q in range(3):
         xo = oracle.blocked_lsolve(sym, lv, B[q], "serial")
         assert np.abs(Xf[q] - xo).max() <= 1e-11 * max(1.0, np.abs(xo).max())

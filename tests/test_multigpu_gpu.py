@@ -2,7 +2,8 @@
 gloo and host-staged messages in place of RCCL (one device cannot host several RCCL ranks) -- everything else is what
 `bench.py --gpus N` runs: the library's distribution, plans restricted to the ranks' pieces, level-by-level
 factorization with the fan-out messages in between (multigpu.DistributedFactorization), then the sharded solves
-(multigpu.ShardedSolve).  Checked on rank 0 against a single plan: factor bitwise, solves to rounding."""
+(multigpu.ShardedSolve, and multigpu.LeveledShardedSolve: the supernodes above the cut solved where they were
+factored).  Checked on rank 0 against a single plan: factor bitwise, solves to rounding."""
 import os
 import sys
 from pathlib import Path
@@ -63,6 +64,22 @@ def _rank_main(rank, world, port, name, env, out_dir, distinct=False):
     Xb = SS.backward(L, B, nrhs, stream)
     torch.cuda.synchronize()
     assert sub_plan.solve_status() == 0
+    # ... and with the supernodes above the cut solved where they were factored, level by level with one all-reduce of
+    # the level's rows in between (parsy_solve_levels_device): no rank holds the other ranks' panels (NaN there)
+    L2 = torch.full_like(L, float("nan"))
+    for p in np.where(D.owner == rank)[0]:
+        a, b = int(pieces["value_begin"][p]), int(pieces["value_end"][p])
+        L2[a:b] = torch.from_numpy(own[a:b]).to(dev)
+    top_plan = api.Plan(sym, di)
+    LS = MG.LeveledShardedSolve(sym, pieces, D, rank, dist, MG.PlanSolver(sub_plan), MG.PlanSolver(top_plan),
+                                top_plan.solve_levels(), stage_on_host=not distinct)
+    LS.gather_solve_parts(L2)
+    lev_out = {}
+    for nr in (1, 3, 8):
+        Bq = B if nr == 3 else torch.from_numpy(rng.standard_normal(sym.n * nr)).to(dev)
+        lev_out[nr] = (Bq.cpu().numpy(), LS.forward(L2, Bq, nr, stream), LS.backward(L2, Bq, nr, stream))
+        torch.cuda.synchronize()
+        assert sub_plan.solve_status() == 0 and top_plan.solve_status() == 0
     # rank 0 collects the factor and checks everything against a single plan
     np.save(Path(out_dir) / f"own_{rank}.npy", own)
     dist.barrier()
@@ -79,6 +96,13 @@ def _rank_main(rank, world, port, name, env, out_dir, distinct=False):
         gb = Xb.cpu().numpy().reshape(nrhs, sym.n).T
         assert np.abs(gf - xf).max() <= 1e-10 * max(1.0, np.abs(xf).max())
         assert np.abs(gb - xb).max() <= 1e-10 * max(1.0, np.abs(xb).max())
+        for nr, (bq, lf, lb) in lev_out.items():
+            bq = bq.reshape(nr, sym.n).T
+            xf, _ = full.solve(ref, bq)
+            xb, _ = full.solve2(ref, bq, forward=False)
+            gf, gb = lf.cpu().numpy().reshape(nr, sym.n).T, lb.cpu().numpy().reshape(nr, sym.n).T
+            assert np.abs(gf - xf.reshape(sym.n, nr)).max() <= 1e-10 * max(1.0, np.abs(xf).max()), f"leveled forward solve, {nr} right-hand sides"
+            assert np.abs(gb - xb.reshape(sym.n, nr)).max() <= 1e-10 * max(1.0, np.abs(xb).max()), f"leveled backward solve, {nr} right-hand sides"
         np.save(Path(out_dir) / "ok.npy", np.array([D.info["n_messages"], D.info["n_root_pieces"]]))
     dist.barrier()
     dist.destroy_process_group()
