@@ -158,6 +158,8 @@ typedef struct parsy_plan_info {
     int32_t sub_mrhs_slots;        /* ... and the LDS slots (16 right-hand sides each) of the largest */
     int32_t sub_mrhs_tiers;        /* launches of that form per solve: the subtrees at the bottom of the etree, then bands of levels */
     int32_t sub_mrhs_cover_level;  /* ... which replace every level launch up to this etree level (-1: only the subtree launch) */
+    int64_t dense_strip_entries;   /* dense entries that carry the remainder of their source's row / column run (<= 16 rows behind
+                                    * or beside the block), multiplied with the block's staged operands */
 } parsy_plan_info;
 
 /* Build a plan from the reference-shaped symbolic arrays (host pointers, copied).

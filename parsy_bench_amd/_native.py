@@ -60,6 +60,7 @@ class PlanInfo(C.Structure):
         ("solve_one", C.c_int32), ("solve_one_blocks", C.c_int32),
         ("sub_mrhs_trees", C.c_int32), ("sub_mrhs_slots", C.c_int32),
         ("sub_mrhs_tiers", C.c_int32), ("sub_mrhs_cover_level", C.c_int32),
+        ("dense_strip_entries", C.c_int64),
     ]
 
     def as_dict(self):

@@ -343,6 +343,7 @@ int parsy_plan_get_info(const parsy_plan* pl, parsy_plan_info* o) {
     o->sub_mrhs_slots = S.sub_max_slots;
     o->sub_mrhs_tiers = (int32_t)S.sub_tiers.size();
     o->sub_mrhs_cover_level = S.sub_cover_level;
+    o->dense_strip_entries = S.n_strip_entries;
     return 0;
 }
 
@@ -430,8 +431,35 @@ int64_t parsy_debug_big_entries(const parsy_plan* pl, int32_t* out, int64_t cap)
             o[2] = E.K;
             o[3] = E.mn & 255;
             o[4] = (E.mn >> 8) & 255;
-            o[5] = (E.mn >> 16) != 0;
+            o[5] = ((E.mn >> 16) & 1) != 0;
             o[6] = E.ia - E.ja;
+        }
+        ++t;
+    }
+    return n;
+}
+
+// Diagnostics (tools/pair_stats.py): as parsy_debug_big_entries with the windows themselves -- rows of (task, launch, K,
+// rows, columns, first row of the row window, first row of the column window, source (its rank among the panel
+// offsets is all a reader needs: low 32 bits of src / 8 ... high bits), 1 = a dense entry of its task).
+int64_t parsy_debug_big_windows(const parsy_plan* pl, int64_t* out, int64_t cap) {
+    if (!pl) return -1;
+    const parsy::Schedule& S = pl->S;
+    int64_t n = 0, t = 0;
+    for (const parsy::Schedule::BigTask& b : S.big_all) {
+        for (int64_t e = b.e0; e < b.e1; ++e, ++n) {
+            if (!out || n >= cap) continue;
+            const parsy::WaveEntry& E = S.big_entries[(size_t)e];
+            int64_t* o = out + 9 * n;
+            o[0] = t;
+            o[1] = b.src_level * 2 + (b.next ? 0 : 1);
+            o[2] = E.K;
+            o[3] = E.mn & 255;
+            o[4] = (E.mn >> 8) & 255;
+            o[5] = E.ia;
+            o[6] = E.ja;
+            o[7] = E.src;
+            o[8] = e < b.em;
         }
         ++t;
     }

@@ -1084,7 +1084,7 @@ __device__ __forceinline__ void tile_task(LdsT& S, const int task, const SnDesc*
                 // v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg).  Lanes 0..31
                 // hold the sub-tile row of source row `lane` of the row window, lanes 32..63 the
                 // sub-tile column of source row `lane - 32` of the column window (-1: outside).
-                const bool ident = (c.mn >> 16) != 0;
+                const bool ident = ((c.mn >> 16) & 1) != 0;
                 const int relv = (l31 < (lane < 32 ? mi : nj))
                                      ? (ident ? l31 : c.rel - D.rbias - (lane < 32 ? subrow0 : subcol0)) : -1;
                 const int C0 = __builtin_amdgcn_ds_bpermute((32 + l15) * 4, relv);
@@ -2091,7 +2091,7 @@ __global__ __launch_bounds__(kBigThreads, kBigThreads / 64 >= 16 ? 4 : kBigWC) v
         return;
 #endif
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-        const bool ident = (E.mn >> 16) != 0;
+        const bool ident = ((E.mn >> 16) & 1) != 0;
         // (the index loads are unconditional -- rows past the window re-read its last one -- so that all twelve are
         // in flight together: guarded per lane, the compiler waited for each of them in turn; loading them before the
         // source's last chunk is multiplied, so that they land behind it, cost more in registers than it hid)
@@ -2219,6 +2219,7 @@ static constexpr int kDSlots = 4;                    // ring depth
 static constexpr int kDOp = kDK * kBLd;              // doubles of one operand of a chunk (k stride kBLd: see kBLd)
 static constexpr int kDSlot = 2 * kDOp;              // a slot: the block's rows (R), then its columns (C)
 static constexpr int kDenseThreads = 256;
+static constexpr int kDStrip = kDSlots * kDSlot;     // first double of the strips' ring (256 per slot)
 #ifdef PARSY_DENSESTAMPS
 // (diagnostic build) shader clocks per phase of the chunk loop, summed over every wave of every dense launch
 __device__ unsigned long long g_densephase[16];
@@ -2229,17 +2230,19 @@ __device__ unsigned long long g_densephase[16];
 #define DSTAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* __restrict__ sn,
-                                                                const int32_t* __restrict__ relpos,
-                                                                const WaveEntry* __restrict__ ents,
-                                                                const TileDesc* __restrict__ tasks,
-                                                                double* __restrict__ L) {
-    // (+ one 1-KiB landing area per wave for the placeholder DMA of the last iterations: below)
-    __shared__ __attribute__((aligned(16))) double S[kDSlots * kDSlot + 4 * 128];
-    {
-        int agpr_hint = 0;
-        asm volatile("; accumulators in AGPRs %0" ::"a"(agpr_hint));
-    }
+// One task of k_chol_dense.  STRIPS: entries of the task carry strips (schedule.hpp: big_strip_rows / big_strip_cols) -- up
+// to 16 rows of the source right behind the block's row window and / or 16 right behind its column window.  A strip is
+// staged like the block's operands, by one more DMA instruction per chunk (wave 0: the row strip, wave 1: the column
+// strip; [k][16 rows], 1 KiB, in a ring of its own behind the operands' -- issued ahead of the chunk's four
+// instructions, so that the wait which lets those four stay in flight has seen the strip land), and every wave multiplies
+// two 16 x 16 fragments of each strip with operands it holds anyway: the row strip times two of its four column
+// fragments, two of its four row fragments times the column strip (waves (r0, c0) = (0, 0), (0, 64), (64, 0), (64, 64)
+// take fragments 0-1 / 0-1 / 2-3 / 2-3 of their 64 columns resp. rows: together 128) -- four accumulators more, in
+// VGPRs, two operand reads more per k step.
+template <bool STRIPS>
+__device__ __forceinline__ void chol_dense_task(double* __restrict__ S, const TileDesc& td, const SnDesc* __restrict__ sn,
+                                                const int32_t* __restrict__ relpos, const WaveEntry* __restrict__ ents,
+                                                double* __restrict__ L) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -2248,13 +2251,11 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     unsigned long long dph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dlast = __builtin_readcyclecounter();
 #endif
-    const TileDesc td = tasks[blockIdx.x];
     const int64_t e_begin = td.wp, e_end = td.sp;
-    if (e_begin >= e_end) return;
     const SnDesc D = sn[td.sn];
     double* __restrict__ G = L + D.px;
     const int ld = D.ld;
-    const int total = td.part;     // chunks of the task: sum over its entries of ceil(K / 8) (host)
+    const int total = td.part & ~kDenseStripTask;     // chunks of the task: sum over its entries of ceil(K / 8) (host)
 
     // ---- loader: wave w moves columns k = w, w + 4 of both operands of a chunk (lane l: rows 2l, 2l + 1: one
     // 1-KiB column per instruction), always four instructions per chunk, so that vmcnt counts chunks.  The four are
@@ -2274,11 +2275,11 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     const double* __restrict__ lpR = lane_ptr(LE, false);
     const double* __restrict__ lpC = lane_ptr(LE, true);
     // (live = false: the task has no chunk n + 3 -- the instruction is issued all the same, from a valid address into
-    // the wave's landing area, so that every iteration issues exactly four and the loop is ONE path: a second copy of
-    // the product block for the last iterations made the register allocator move the accumulators through scratch)
+    // the slot that chunk would have had (free: everybody has read chunk n - 1, nobody reads it again), so that every
+    // iteration issues exactly four and the loop is ONE path: a second copy of the product block for the last
+    // iterations made the register allocator move the accumulators through scratch)
     auto issue = [&](int slot, int i, bool live) {
-        double* __restrict__ dst = live ? &S[slot * kDSlot + (i & 1) * kDOp + (wave + 4 * (i >> 1)) * kBLd]
-                                        : &S[kDSlots * kDSlot + wave * 128];
+        double* __restrict__ dst = &S[slot * kDSlot + (i & 1) * kDOp + (wave + 4 * (i >> 1)) * kBLd];
         const double* __restrict__ src = (i & 1) ? lpC : lpR;
         // a source's ragged last chunk re-reads its last column for the columns it does not have (their products are
         // masked out): klast = last column it has, counted from lk
@@ -2297,6 +2298,17 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         glds16(src + off, dst);
 #endif
     };
+    // ---- strips (STRIPS only): one more DMA instruction per chunk and strip -- wave 0 the row strip's, wave 1 the column
+    // strip's: lane l = rows 2 (l & 7), + 1 of k column l >> 3, 1 KiB that lands as [k][16 rows] behind the ring (kDStrip)
+    auto issue_strip = [&](int slot) {
+        if (wave < 2 && (LE.mn >> 17) != 0) {
+            const int ext = wave ? (LE.mn >> 22) & 31 : (LE.mn >> 17) & 31;   // (a strip the entry does not have, rows past a
+            const int klast = LE.K - 1 - lk;                                  // strip's last, columns past the source's last:
+            const double* __restrict__ src = L + LE.src + (wave ? LE.ja : LE.ia) + kBigTile + min(2 * (lane & 7), max(ext, 1) - 1) +
+                                             (int64_t)(lk + min(lane >> 3, klast)) * LE.ld;   // re-read, never stored)
+            glds16(src, &S[kDStrip + slot * 256 + wave * 128]);
+        }
+    };
     auto advance = [&]() {
         lk += kDK;
         lpR += (int64_t)kDK * LE.ld;
@@ -2312,6 +2324,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         }
     };
     auto fetch = [&](int slot) {
+        if (STRIPS) issue_strip(slot);
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue(slot, i, true);
         advance();
@@ -2326,11 +2339,14 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0, 0, 0, 0};
+    // strips: (row strip) x (column fragments 2 * hi_c, + 1 of this wave), (row fragments 2 * hi_r, + 1) x (column strip)
+    double4_t rs0 = {0, 0, 0, 0}, rs1 = {0, 0, 0, 0}, cs0 = {0, 0, 0, 0}, cs1 = {0, 0, 0, 0};
+    const bool hi_c = r0 != 0, hi_r = c0 != 0;
     // The operand reads and their waits are written out (inline assembly): the compiler waits for EVERY outstanding
     // LDS read whenever it needs one of them (s_waitcnt lgkmcnt(0) at the loop header and before each product block --
     // a full LDS round trip twice per chunk); here each wait names how many younger reads may stay in flight.  The
     // registers a read fills pass through the wait statement ("+v"), so that no use can be scheduled ahead of it.
-    struct Ops { double2_t r01, r23, c01, c23; };   // 16-row fragments 0..3 of the wave's rows (R) and columns (C), one k each
+    struct Ops { double2_t r01, r23, c01, c23; double rs, cs; };   // 16-row fragments 0..3 of the wave's rows (R) and columns (C), one k each; the strips' rows
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)(&S[0]);
     const unsigned roff = lds0 + 8u * (unsigned)(kq * kBLd + r0 + l15), coff = lds0 + 8u * (unsigned)(kDOp + kq * kBLd + c0 + l15);
     auto read_ops = [&](int slot, int kstep, Ops& o) {
@@ -2340,8 +2356,18 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         asm volatile("ds_read2_b64 %0, %1 offset0:32 offset1:48" : "=v"(o.r23) : "v"(ar));
         asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(o.c01) : "v"(ac));
         asm volatile("ds_read2_b64 %0, %1 offset0:32 offset1:48" : "=v"(o.c23) : "v"(ac));
+        if (STRIPS) {   // (row l15 of k column 4 kstep + kq of the two strips)
+            const unsigned as = lds0 + 8u * (unsigned)(kDStrip + slot * 256 + (4 * kstep + kq) * 16 + l15);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(o.rs) : "v"(as));
+            asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(o.cs) : "v"(as));
+        }
     };
-#define PARSY_DENSE_WAIT(o, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(o.r01), "+v"(o.r23), "+v"(o.c01), "+v"(o.c23))
+    // (wait until at most the reads issued after o's are in flight: four, with strips six)
+#define PARSY_DENSE_WAIT(o, n)                                                                                        \
+    do {                                                                                                              \
+        if (STRIPS) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(o.r01), "+v"(o.r23), "+v"(o.c01), "+v"(o.c23), "+v"(o.rs), "+v"(o.cs)); \
+        else asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(o.r01), "+v"(o.r23), "+v"(o.c01), "+v"(o.c23));         \
+    } while (0)
     // a source's ragged last chunk: lanes of k positions it does not have multiply by zero
     auto mask_ops = [&](Ops& o, bool ok) {
         o.r01 = ok ? o.r01 : double2_t{0, 0};
@@ -2361,8 +2387,24 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
 #pragma unroll
         for (int fc = 0; fc < 4; ++fc) products4(o, fc);
     };
+    // the strips of the consumer's entry (wave-uniform branches: an entry has a strip or not)
+    auto strip_products = [&](const Ops& o, bool rows, bool cols) {
+        // (written out: these four accumulators live in VGPRs -- the 128 AGPRs a wave has at two workgroups per
+        // compute unit hold the block's sixteen, and the compiler gives every matrix instruction of a function the same
+        // accumulator file.  Same instruction, same negated first operand as the builtin's blgp = 1.)
+        if (rows) {
+            const double ca = hi_c ? o.c23[0] : o.c01[0], cb = hi_c ? o.c23[1] : o.c01[1];
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(rs0) : "v"(ca), "v"(o.rs));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(rs1) : "v"(cb), "v"(o.rs));
+        }
+        if (cols) {
+            const double ra = hi_r ? o.r23[0] : o.r01[0], rb = hi_r ? o.r23[1] : o.r01[1];
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(cs0) : "v"(o.cs), "v"(ra));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(cs1) : "v"(o.cs), "v"(rb));
+        }
+    };
     auto epilogue = [&](const WaveEntry& E) {
-        const bool ident = (E.mn >> 16) != 0;
+        const bool ident = ((E.mn >> 16) & 1) != 0;
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
         int prow[4], pcol[4][4];
         if (ident) {
@@ -2409,16 +2451,48 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
                 acc[fc][fr] = double4_t{0, 0, 0, 0};
             }
         }
+        if (STRIPS) {
+            const int ms = (E.mn >> 17) & 31, ns = (E.mn >> 22) & 31;
+            // (the strips' accumulators were written by matrix instructions the compiler has not seen: the wait states
+            // before a vector instruction may read them -- long over after the block's own updates, but not its to know)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(rs0), "+v"(rs1), "+v"(cs0), "+v"(cs1));
+            if (ms) {   // rows ia + 128 + l15 (< ms) x this wave's column fragments 2 * hi_c, + 1
+                int ps = ident ? E.ia + kBigTile + l15 : relpos[(int64_t)E.rel + E.ia + kBigTile + min(l15, ms - 1)] - D.rbias;
+                if (l15 >= ms) ps = -1;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int pa = hi_c ? pcol[2][v] : pcol[0][v], pb = hi_c ? pcol[3][v] : pcol[1][v];
+                    if (ps >= pa) unsafeAtomicAdd(&G[(int64_t)pa * ld + ps], rs0[v]);
+                    if (ps >= pb) unsafeAtomicAdd(&G[(int64_t)pb * ld + ps], rs1[v]);
+                }
+                rs0 = rs1 = double4_t{0, 0, 0, 0};
+            }
+            if (ns) {   // this wave's row fragments 2 * hi_r, + 1 x columns ja + 128 + kq + 4 v (< ns)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int cc = kq + 4 * v;
+                    int pc = ident ? E.ja + kBigTile + cc : relpos[(int64_t)E.rel + E.ja + kBigTile + min(cc, ns - 1)] - D.rbias;
+                    if (cc >= ns) pc = 0x7fffffff;
+                    const int pa = hi_r ? prow[2] : prow[0], pb = hi_r ? prow[3] : prow[1];
+                    if (pa >= pc) unsafeAtomicAdd(&G[(int64_t)pc * ld + pa], cs0[v]);
+                    if (pb >= pc) unsafeAtomicAdd(&G[(int64_t)pc * ld + pb], cs1[v]);
+                }
+                cs0 = cs1 = double4_t{0, 0, 0, 0};
+            }
+        }
     };
 
     // ---- prologue: chunks 0, 1, 2 on their way; chunk 0 landed and visible; the operands of its two k steps read
     fetch(0);
     if (total > 1) fetch(1);
     else
-        for (int i = 0; i < 4; ++i) issue(0, i, false);
+        for (int i = 0; i < 4; ++i) issue(1, i, false);
     if (total > 2) fetch(2);
     else
-        for (int i = 0; i < 4; ++i) issue(0, i, false);
+        for (int i = 0; i < 4; ++i) issue(2, i, false);
+    // (waves 0 / 1 of a task with strips have up to three more instructions in flight, each AHEAD of its chunk's four: the
+    // first seven -- chunk 0 and its strip -- have landed all the same)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     Ops A, B;
@@ -2437,11 +2511,13 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         DSTAMP(0);
         __builtin_amdgcn_s_setprio(1);   // (the multiplying waves win the issue arbitration, as in k_chol_big)
         products(A);
+        if (STRIPS) strip_products(A, ((CE.mn >> 17) & 31) != 0, ((CE.mn >> 22) & 31) != 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         DSTAMP(1);
         // chunk n + 1: this wave's part has landed (the four instructions of chunk n + 2 -- or their placeholders --
         // may stay in flight), then everybody's
+        // (a strip's instruction is issued ahead of its chunk's four: the same count holds for the waves that move strips)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         DSTAMP(2);
 #ifndef PARSY_DENSEABL_NOBARRIER   // (diagnostic build: waves race through the ring -- wrong results)
@@ -2457,6 +2533,10 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
         {
             const bool live = n + 3 < total;
             const int fslot = (n + 3) & (kDSlots - 1);
+            if (STRIPS) {   // the strips of chunk n + 3, ahead of its four
+                if (live) issue_strip(fslot);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 products4(B, g);
@@ -2466,6 +2546,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
             }
             if (live) advance();
         }
+        if (STRIPS) strip_products(B, ((CE.mn >> 17) & 31) != 0, ((CE.mn >> 22) & 31) != 0);
         __builtin_amdgcn_sched_barrier(0);
         DSTAMP(6);
         ck += kDK;
@@ -2509,6 +2590,25 @@ __global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* _
     }
 #endif
 #undef PARSY_DENSE_WAIT
+}
+
+__global__ __launch_bounds__(kDenseThreads, 2) void k_chol_dense(const SnDesc* __restrict__ sn,
+                                                                const int32_t* __restrict__ relpos,
+                                                                const WaveEntry* __restrict__ ents,
+                                                                const TileDesc* __restrict__ tasks,
+                                                                double* __restrict__ L) {
+    // (the ring of four chunks, then the strips' ring: 4 x (row strip, column strip) of 16 rows x 8 k -- 80 KiB, two
+    // workgroups fill a compute unit's LDS exactly)
+    __shared__ __attribute__((aligned(16))) double S[kDStrip + kDSlots * 256];
+    {
+        int agpr_hint = 0;
+        asm volatile("; accumulators in AGPRs %0" ::"a"(agpr_hint));
+    }
+    const TileDesc td = tasks[blockIdx.x];
+    if (td.wp >= td.sp) return;
+    // (two bodies, chosen per task: the tasks without strips -- nearly all -- run the loop they always ran)
+    if (td.part & kDenseStripTask) chol_dense_task<true>(S, td, sn, relpos, ents, L);
+    else chol_dense_task<false>(S, td, sn, relpos, ents, L);
 }
 
 void launch_chol_dense(const DevicePattern& P, int first, int count, double* L, hipStream_t stream) {

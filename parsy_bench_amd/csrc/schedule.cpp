@@ -2,6 +2,7 @@
 #include "schedule.hpp"
 
 #include <cstdio>
+#include <map>
 #include <algorithm>
 #include <queue>
 #include <climits>
@@ -357,6 +358,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         // (PARSY_BIG_SUPER_MIN / PARSY_BIG_SUPER_FILL: the two thresholds, diagnostics; fill in percent)
         const int64_t super_min_tasks = env_int("PARSY_BIG_SUPER_MIN", kBigSuperMinTasks);
         const double super_max_fill = env_int("PARSY_BIG_SUPER_FILL", (int)(kBigSuperMaxFill * 100 + 0.5)) / 100.0;
+        const int super_hi = std::max(1, std::min(8, env_int("PARSY_BIG_SUPER_HI", 2)));   // (diagnostics: the edge such launches take)
         std::vector<int64_t> ltasks(launch_super.size(), 0);
         std::vector<double> lfrag(launch_super.size(), 0.0), lchunks(launch_super.size(), 0.0);
         std::vector<int64_t> keys;
@@ -396,7 +398,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             for (int64_t k : keys) ltasks[(size_t)(k >> 40)]++;
         }
         for (size_t l = 0; l < launch_super.size(); ++l)
-            if (ltasks[l] >= super_min_tasks && lfrag[l] < super_max_fill * 64.0 * lchunks[l]) launch_super[l] = 2;
+            if (ltasks[l] >= super_min_tasks && lfrag[l] < super_max_fill * 64.0 * lchunks[l]) launch_super[l] = (int8_t)super_hi;
     }
     S.big_super_r = env_sr;
     S.big_super_c = env_sc;
@@ -621,6 +623,9 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             return mode == 1 && E.K >= kDenseChunk && mi * nj >= fill_min;
         };
         S.big_entries.resize(bigk.size());
+        const bool dense_strips = env_int("PARSY_DENSE_STRIPS", 1) != 0;
+        std::map<std::pair<int64_t, int64_t>, size_t> strip_of;   // (source, ia << 32 | ja) of a task's full dense blocks
+        std::vector<uint8_t> absorbed;
         int t = 0;
         for (size_t i = 0; i < bigk.size();) {
             size_t j = i;
@@ -645,12 +650,50 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                         }
                     }
             const size_t mid = at;
+            // Strips: the remainder of a source's row run right behind a full block (<= kStripMax rows x the block's 128
+            // columns) or of its column run beside it (the block's 128 rows x <= kStripMax columns) rides with the block
+            // -- k_chol_dense has that block's operands staged and fetches 16 rows more per chunk, where k_chol_big
+            // staged the 128-wide window again for a sliver of products (Flan-class: 62 000 such entries, a third of the
+            // bytes the ragged launches staged; tools/pair_stats.py).  PARSY_DENSE_STRIPS=0: never.
+            int32_t nstrips = 0;
+            absorbed.assign(j - i, 0);
+            if (lmode && dense_strips && mid > i) {
+                strip_of.clear();
+                for (size_t d = i; d < mid; ++d) {
+                    const WaveEntry& E = S.big_entries[d];
+                    if ((E.mn & 0xffff) == (kBigTile | (kBigTile << 8))) strip_of[{E.src, ((int64_t)E.ia << 32) | (uint32_t)E.ja}] = d;
+                }
+                for (size_t q = i; q < j && !strip_of.empty(); ++q) {
+                    const WaveEntry& R = bigk[q].e;
+                    if (is_dense(R, lmode)) continue;
+                    const int mi = R.mn & 255, nj = (R.mn >> 8) & 255;
+                    const bool row_strip = mi <= kStripMax && nj == kBigTile, col_strip = nj <= kStripMax && mi == kBigTile;
+                    if (!row_strip && !col_strip) continue;
+                    const auto it = strip_of.find({R.src, ((int64_t)(R.ia - (row_strip ? kBigTile : 0)) << 32) |
+                                                          (uint32_t)(R.ja - (col_strip ? kBigTile : 0))});
+                    if (it == strip_of.end()) continue;
+                    WaveEntry& E = S.big_entries[it->second];
+                    if (E.K != R.K || ((E.mn >> 16) & 1) != ((R.mn >> 16) & 1) || E.rel != R.rel || E.ld != R.ld) continue;
+                    if ((row_strip ? big_strip_rows(E) : big_strip_cols(E)) != 0) continue;
+                    if (big_strip_rows(E) == 0 && big_strip_cols(E) == 0) ++nstrips;
+                    E.mn |= row_strip ? mi << 17 : nj << 22;
+                    absorbed[q - i] = 1;
+                    {
+                        double pairs = 0;
+                        for (int jj = R.ja; jj < R.ja + nj; ++jj) pairs += std::max(0, R.ia + mi - std::max(R.ia, jj));
+                        S.dense_flops += 2.0 * R.K * pairs;
+                    }
+                    dweight += ceil_div(R.K, 64);
+                }
+            }
             for (size_t q = i; q < j; ++q)
-                if (!is_dense(bigk[q].e, lmode)) {
+                if (!is_dense(bigk[q].e, lmode) && !absorbed[q - i]) {
                     S.big_entries[at++] = bigk[q].e;
                     weight += ceil_div(bigk[q].e.K, 16) + 4;
                 }
+            const size_t jend = at;     // (entries that ride with a dense block leave unused slots up to j)
             S.n_dense_entries += (int64_t)(mid - i);
+            S.n_strip_entries += nstrips;
             while (t + 1 < nc && big_tile0[t + 1] <= tile) ++t;   // tiles ascend within a launch ...
             if (tile < big_tile0[t]) {                             // ... and start over with the next one
                 t = 0;
@@ -660,10 +703,10 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
             const int64_t local = tile - big_tile0[t];
             S.big_all.push_back(Schedule::BigTask{t, (int32_t)(local % nbr128) * kBigTile,
                                                   (int32_t)(local / nbr128) * kBigTile,
-                                                  (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)j,
+                                                  (int32_t)std::min<int64_t>(weight, INT32_MAX), (int64_t)i, (int64_t)jend,
                                                   (int32_t)(launch >> 1), (int32_t)((launch & 1) == 0), bigk[i].sr, bigk[i].sc,
                                                   (int64_t)mid, (int32_t)std::min<int64_t>(dweight, INT32_MAX),
-                                                  (int32_t)std::min<int64_t>(dchunks, INT32_MAX)});
+                                                  (int32_t)std::min<int64_t>(dchunks, INT32_MAX), nstrips});
             i = j;
         }
     }
@@ -970,7 +1013,8 @@ void build_launches(Schedule& S, const uint8_t* active, const uint8_t* active_pi
         L.first = (int32_t)S.big_tasks.size();
         auto wt = [dense](const Schedule::BigTask* b) { return dense ? b->dweight : b->weight; };
         auto desc = [dense](const Schedule::BigTask* b) {
-            return dense ? TileDesc{b->sn, b->row0, b->col0, b->dchunks, b->e0, b->em} : TileDesc{b->sn, b->row0, b->col0, 0, b->em, b->e1};
+            return dense ? TileDesc{b->sn, b->row0, b->col0, b->dchunks | (b->strips > 0 ? kDenseStripTask : 0), b->e0, b->em}
+                         : TileDesc{b->sn, b->row0, b->col0, 0, b->em, b->e1};
         };
         auto by_weight = [&](const Schedule::BigTask* a, const Schedule::BigTask* b) { return wt(a) > wt(b); };
         // group edge: as large as leaves every XCD at least kBigGroupsPerXcd groups to balance with
@@ -2056,9 +2100,14 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
     // a BIG entry is any block of the source's rows x rows: the pairs (i, j), i >= j, of it
     auto block_flops = [](const WaveEntry& E) {
         const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-        double pairs = 0;
-        for (int j = E.ja; j < E.ja + nj; ++j) pairs += std::max(0, E.ia + mi - std::max(E.ia, j));
-        return 2.0 * E.K * pairs;
+        auto pairs_of = [](int ia, int m, int ja, int n) {
+            double pairs = 0;
+            for (int j = ja; j < ja + n; ++j) pairs += std::max(0, ia + m - std::max(ia, j));
+            return pairs;
+        };
+        // (+ the strips that ride with a dense block: rows behind it x its columns, its rows x columns beside it)
+        return 2.0 * E.K * (pairs_of(E.ia, mi, E.ja, nj) + pairs_of(E.ia + mi, big_strip_rows(E), E.ja, nj) +
+                            pairs_of(E.ia, mi, E.ja + nj, big_strip_cols(E)));
     };
     for (int t = 0; t < nc; ++t) {
         const SnDesc& T = S.csn[t];
@@ -2100,16 +2149,19 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             for (int64_t q = T.upd0; q < T.upd0 + T.nupd; ++q)
                 if (S.upd[q].src == E.src && S.upd[q].K == E.K) u = q;
             const int mi = E.mn & 255, nj = (E.mn >> 8) & 255;
-            const bool ident = (E.mn >> 16) != 0;
-            if (u < 0 || mi < 1 || mi > kBigTile || nj < 1 || nj > kBigTile || E.ia + mi > S.upd[u].m || E.ja + nj > S.upd[u].n1 ||
+            const bool ident = big_ident(E);
+            const int ms = big_strip_rows(E), ns = big_strip_cols(E);
+            if ((ms || ns) && (e >= b.em || mi != kBigTile || nj != kBigTile || ms > kStripMax || ns > kStripMax))
+                fail("BIG entry " + std::to_string(e) + " carries a strip but is not a full dense block");
+            if (u < 0 || mi < 1 || mi > kBigTile || nj < 1 || nj > kBigTile || E.ia + mi + ms > S.upd[u].m || E.ja + nj + ns > S.upd[u].n1 ||
                 ident != (S.upd[u].rel < 0) || S.level_of[S.upd_src[u]] != b.src_level) {
                 fail("BIG entry " + std::to_string(e) + " of piece " + std::to_string(b.sn) + " has a bad window or source");
                 continue;
             }
             // the rows it names land in the task's tile
             auto rel_at = [&](int k) { return ident ? k : S.relpos[(size_t)S.upd[u].rel + k] - T.rbias; };
-            if (rel_at(E.ia) / win_r != b.row0 / win_r || rel_at(E.ia + mi - 1) / win_r != b.row0 / win_r ||
-                rel_at(E.ja) / win_c != b.col0 / win_c || rel_at(E.ja + nj - 1) / win_c != b.col0 / win_c)
+            if (rel_at(E.ia) / win_r != b.row0 / win_r || rel_at(E.ia + mi + ms - 1) / win_r != b.row0 / win_r ||
+                rel_at(E.ja) / win_c != b.col0 / win_c || rel_at(E.ja + nj + ns - 1) / win_c != b.col0 / win_c)
                 fail("BIG entry " + std::to_string(e) + " names rows outside its task's tile");
             covered[(size_t)u] += block_flops(E);
         }
@@ -2143,7 +2195,8 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
                     continue;
                 }
                 const Schedule::BigTask* it = find_task(td.wp);
-                const bool ok = it && (dense ? (it->e0 == td.wp && it->em == td.sp && td.part == it->dchunks)
+                const bool ok = it && (dense ? (it->e0 == td.wp && it->em == td.sp && (td.part & ~kDenseStripTask) == it->dchunks &&
+                                                ((td.part & kDenseStripTask) != 0) == (it->strips > 0))
                                              : (it->em == td.wp && it->e1 == td.sp));
                 if (!ok || it->sn != td.sn || it->row0 != td.row0 || it->col0 != td.col0) {
                     fail("BIG launch task " + std::to_string(q) + " is not a task of the plan");
@@ -2161,12 +2214,15 @@ int64_t check_schedule(const Schedule& S, std::string& what) {
             const Schedule::BigTask& b = S.big_all[k];
             if (b.em < b.e0 || b.em > b.e1) fail("BIG task " + std::to_string(k) + " has a bad dense / ragged split");
             int64_t dch = 0;
+            int32_t nst = 0;
             for (int64_t e = b.e0; e < b.em; ++e) {
                 const WaveEntry& E = S.big_entries[(size_t)e];
+                nst += big_strip_rows(E) || big_strip_cols(E);
                 if (E.K < kDenseChunk) fail("BIG entry " + std::to_string(e) + " is filed as dense but is narrower than a chunk");
                 dch += ceil_div(E.K, kDenseChunk);
             }
             if (dch != b.dchunks) fail("BIG task " + std::to_string(k) + " has a wrong dense chunk count");
+            if (nst != b.strips) fail("BIG task " + std::to_string(k) + " has a wrong count of entries with strips");
             if (!S.active_piece[b.sn]) continue;
             want += (b.em > b.e0) + (b.e1 > b.em);
             if (b.em > b.e0 && b.e1 > b.em && !(dense_pos[k] > 0 && ragged_pos[k] > dense_pos[k]))

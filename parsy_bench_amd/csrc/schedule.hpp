@@ -90,7 +90,17 @@ struct WaveEntry {    // one (descendant, 32x32 sub-tile) pair of the tile kerne
     int32_t ld, K;    // rows and width of the descendant
     int32_t ia, ja;   // first descendant row (counted from lb) inside the sub-tile's row / column window
     int32_t mn;       // rows in the row window | rows in the column window << 8  (1..32 each)
+                      // BIG entries (windows of up to 128): | identity row map << 16 | rows of the ROW STRIP behind the
+                      // block << 17 | columns of the COLUMN STRIP beside it << 22 (0..16 each: big_strip_rows / _cols)
 };
+// A dense BIG entry (a full 128 x 128 block of a source's rows) may carry the remainder of its source's row run -- up to
+// kStripMax rows right behind the block, times the block's column window -- and / or of its column run: k_chol_dense
+// multiplies them with the operands it has staged for the block, plus a strip of 16 rows per chunk.
+constexpr int kStripMax = 16;
+inline bool big_ident(const WaveEntry& E) { return (E.mn >> 16) & 1; }
+inline int big_strip_rows(const WaveEntry& E) { return (E.mn >> 17) & 31; }
+inline int big_strip_cols(const WaveEntry& E) { return (E.mn >> 22) & 31; }
+constexpr int kDenseStripTask = 1 << 30;   // TileDesc::part of a k_chol_dense task: an entry of it carries a strip
 
 struct TileDesc {     // one workgroup of the TILES / CHAIN kernels
     int32_t sn;
@@ -289,13 +299,15 @@ struct Schedule {
     // ragged rest [em, e1) for k_chol_big; each part in update order.  dchunks: 8-wide k chunks of the dense part.
     struct BigTask { int32_t sn, row0, col0, weight; int64_t e0, e1; int32_t src_level, next;
                      int32_t sr, sc;      // sr x sc: the super-tile's edge in 128 x 128 tiles
-                     int64_t em; int32_t dweight, dchunks; };
+                     int64_t em; int32_t dweight, dchunks;
+                     int32_t strips; };   // dense entries of it that carry a strip (WaveEntry::mn)
     std::vector<BigTask> big_all;         // every task, grouped by (src_level, next)
     std::vector<TileDesc> big_tasks;      // tasks of the launches (active targets): k_chol_big: wp, sp = the ragged part [em, e1) of a
                                           // task; k_chol_dense: its dense part [e0, em), part = its 8-wide k chunks
     double big_flops = 0;                 // flops of the BIG launches (dense + ragged entries)
     double dense_flops = 0;               // ... of which through k_chol_dense
     int64_t n_dense_entries = 0;
+    int64_t n_strip_entries = 0;          // dense entries that carry a row / column strip
     std::vector<Launch> chol;
 
     // solve launch data

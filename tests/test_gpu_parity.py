@@ -843,6 +843,45 @@ def test_factor_with_dense_launches(api, oracle, monkeypatch, name, piece, mink,
 
 
 # ---------------------------------------------------------------------------
+# Strips (round 5): the remainder of a source's row run right behind a full 128 x 128 block (<= 16 rows), or of its
+# column run beside it, rides with the block through k_chol_dense instead of being an entry of the ragged launch.
+# PARSY_DENSE_STRIPS=0 is the form without: the same products in another order of sums -- rounding apart, each bitwise
+# reproducible, both against the oracle.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,piece,mink,sup", [("lap30", 128, 32, "2"), ("lap30", 256, 64, "2x1"), ("nd24k", 256, 64, "2"),
+                                                 ("nd24k", 128, 24, "2"), ("mid3d", 128, 16, "2")])
+def test_factor_with_dense_strips(api, oracle, monkeypatch, name, piece, mink, sup):
+    from parsy_bench_amd import inspector as I
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_BIG_SUPER", sup)
+    monkeypatch.setenv("PARSY_BIG_DENSE", "2")
+    monkeypatch.setenv("PARSY_DENSE_STRIPS", "0")
+    plan0 = api.Plan(sym, 0)
+    assert plan0.info["dense_strip_entries"] == 0 and plan0.check() == 0
+    lv0, _ = plan0.factor(sym.A2x)
+    assert plan0.status() == 0
+    monkeypatch.delenv("PARSY_DENSE_STRIPS")
+    plan = api.Plan(sym, 0)
+    info = plan.info
+    assert plan.check() == 0 and info["big_flops"] == plan0.info["big_flops"]
+    if name != "mid3d":
+        assert info["dense_strip_entries"] > 0, "this case is meant to have strips"
+        assert info["dense_flops"] > plan0.info["dense_flops"] and info["big_entries"] == plan0.info["big_entries"]
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    ok, lo, _ = oracle.cholesky_05(sym, sym.A2x, I.trivial_hlevel(sym))
+    assert ok
+    scale = np.abs(lo).max()
+    assert np.abs(lv - lo).max() <= FACTOR_TOL * scale, f"{name}: strips vs oracle {np.abs(lv - lo).max() / scale:.3e}"
+    assert np.abs(lv - lv0).max() <= FACTOR_TOL * scale
+    for _ in range(2):
+        lv2, _ = plan.factor(sym.A2x)
+        assert np.array_equal(lv, lv2)   # fixed summation order: bitwise reproducible
+
+
+# ---------------------------------------------------------------------------
 # two chain launches per level (the tiles of the diagonal squares with the walkers, then the tiles of the rows below
 # them): what the largest jobs take by themselves, forced here (PARSY_CHAIN_SPLIT).  The same tiles, updates and sums:
 # the factor must be bitwise the one-launch factor.
