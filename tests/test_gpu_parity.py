@@ -97,6 +97,46 @@ def test_solve_on_row_major_x_matches_oracle(api, oracle, monkeypatch, name, nrh
     assert np.abs(X - X0).max() <= 1e-12 * max(1.0, np.abs(X0).max())
 
 
+@pytest.mark.parametrize("name,env", [("ex15", {}), ("lap30", {}), ("nd24k", {}), ("mid3d", {"PARSY_FORCE_UNFUSED": "1"}),
+                                      ("parabolic_fem", {})])
+@pytest.mark.parametrize("nrhs", [1, 3, 8, 19])
+def test_solve_in_steps_of_levels_matches_oracle(api, oracle, monkeypatch, name, env, nrhs):
+    """parsy_solve_levels_device (round 5: the steps of a solve that is distributed above the cut, Triangular_BCSC.h:115-164's
+    level sets one call at a time): the whole solve as one call per etree level, and as three calls of level ranges, forward
+    and backward, every column against the oracle.  PARSY_FORCE_UNFUSED: the per-block-column form of the wide supernodes,
+    whose x goes from scratch into x in the LAST step."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A, perm, sym = problem(name)
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    nl = int(plan.solve_levels().max()) + 1
+    assert nl == sym.nlevels
+    dev = torch.device("cuda", 0)
+    Ld = torch.from_numpy(lv).to(dev)
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((nrhs, sym.n))
+    cuts = sorted({0, nl // 3, (2 * nl) // 3, nl})
+    for backward in (False, True):
+        want = [oracle.blocked_ltsolve(sym, lv, B[q]) if backward else oracle.blocked_lsolve(sym, lv, B[q], "serial") for q in range(nrhs)]
+        for ranges in ([(l, l + 1) for l in range(nl)], list(zip(cuts[:-1], cuts[1:]))):
+            X = torch.from_numpy(B.reshape(-1).copy()).to(dev)
+            order = ranges[::-1] if backward else ranges
+            for i, (a, b) in enumerate(order):
+                plan.solve_levels_device(Ld.data_ptr(), X.data_ptr(), nrhs, sym.n, 0, a, b, i == 0, i == len(order) - 1, backward)
+            torch.cuda.synchronize()
+            assert plan.solve_status() == 0
+            Xh = X.cpu().numpy().reshape(nrhs, sym.n)
+            for q in range(nrhs):
+                assert np.abs(Xh[q] - want[q]).max() <= SOLVE_TOL * max(1.0, np.abs(want[q]).max()), \
+                    f"{name}: {'backward' if backward else 'forward'} solve in {len(ranges)} steps, column {q}"
+    # a refused call says why
+    with pytest.raises(RuntimeError, match="level_begin <= level_end"):
+        plan.solve_levels_device(Ld.data_ptr(), Ld.data_ptr(), 1, sym.n, 0, 3, 2, True, True)
+
+
 @pytest.mark.parametrize("name", ["ex15", "lap30", "nd24k", "parabolic_fem"])
 @pytest.mark.parametrize("nrhs", [6, 7, 8, 16])
 def test_product_gate_with_row_major_x_forced(api, oracle, monkeypatch, name, nrhs):
