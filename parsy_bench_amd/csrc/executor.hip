@@ -40,6 +40,7 @@ int plan_upload_launches(parsy_plan* pl) {
     PARSY_HIP(hipSetDevice(pl->device));
     for (void* d : pl->launch_owned) (void)hipFree(d);
     pl->launch_owned.clear();
+    pl->levels_open = false;
     const Schedule& S = pl->S;
     if (upload(pl, S.small_list, pl->dp.small_list, true)) return -1;
     if (upload(pl, S.small_ranges, pl->dp.small_ranges, true)) return -1;
@@ -486,6 +487,7 @@ int plan_backsolve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int
         set_last_error("parsy_backsolve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
+    pl->levels_open = false;
     const int64_t need = (int64_t)ldx * nrhs;
     double *y = nullptr, *y_next = nullptr;
     int *st = nullptr, *st_next = nullptr;
@@ -575,6 +577,10 @@ int plan_solve_levels(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, 
         return -1;
     }
     const bool first = flags & 1, last = flags & 2, backward = flags & 4;
+    if (!first && (!pl->levels_open || pl->levels_backward != backward || pl->levels_nrhs != nrhs)) {
+        set_last_error("parsy_solve_levels: a step without PARSY_SOLVE_FIRST needs an open solve of the same direction and width");
+        return -1;
+    }
     const int passes = backward ? (nrhs + 3) / 4 : (nrhs + 7) / 8;
     const int64_t need = (int64_t)ldx * nrhs;
     if (first) {
@@ -606,6 +612,9 @@ int plan_solve_levels(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, 
             launch_diag_inverse(pl->dp, (int)pl->S.solve_wide_list.size() / 2, d_L, pl->dinv, stream);
         pl->solve_ldq = 0;
         run_begin(pl);
+        pl->levels_open = true;
+        pl->levels_backward = backward;
+        pl->levels_nrhs = nrhs;
     }
     const std::vector<Launch>& seq = backward ? pl->S.bsolve : pl->S.solve;
     for (size_t li = 0; li < seq.size(); ++li)
@@ -617,6 +626,7 @@ int plan_solve_levels(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, 
         PARSY_HIP(hipEventRecord(pl->ev_s1, stream));
         pl->epoch += passes;
         pl->have_s = true;
+        pl->levels_open = false;
     }
     return 0;
 }
@@ -752,6 +762,7 @@ int plan_solve(parsy_plan* pl, const double* d_L, double* d_x, int nrhs, int ldx
         set_last_error("parsy_solve: need nrhs >= 1 and ldx >= n");
         return -1;
     }
+    pl->levels_open = false;   // (a solve in steps of levels that was never finished is abandoned)
     double *y = nullptr, *y_next = nullptr;
     int *st = nullptr, *st_next = nullptr;
     int one_rc = solve_takes_one_launch(pl, nrhs, false) ? one_begin(pl, false, nrhs, stream, y, y_next, st, st_next) : 1;

@@ -48,6 +48,8 @@ struct parsy_plan {
     hipStream_t h_stream = nullptr, h_copy = nullptr;
     std::vector<hipEvent_t> h_band_ev;
     bool h_ready = false;                    // the pipelined download's streams, bands and events all exist
+    bool levels_open = false, levels_backward = false;   // a solve in steps of levels (plan_solve_levels) is under way
+    int levels_nrhs = 0;
     std::vector<int> h_band_level;                                    // last level of every band
     std::vector<std::vector<std::pair<int64_t, int64_t>>> h_band_runs;
     int64_t h_x_len = 0;

@@ -246,8 +246,9 @@ class ShardedSolve:
         return moved
 
     def _masked(self, X, nrhs):
-        keep = self.keep.to(X.device)
-        return (X.view(nrhs, self.n) * keep).view(-1)
+        if self.keep.device != X.device:
+            self.keep = self.keep.to(X.device)
+        return (X.view(nrhs, self.n) * self.keep).view(-1)
 
     def _collect(self, X, op_reduce=True):
         if self.stage_on_host and X.is_cuda:
@@ -358,8 +359,10 @@ class LeveledShardedSolve(ShardedSolve):
     def _level_sum(self, Xv, lev, own_only: bool):
         """All-reduce(SUM) of the x rows of the supernodes of level `lev` above the cut (own_only: a rank contributes the
         rows it owns, zeros elsewhere)."""
-        idx = self.level_cols[lev].to(Xv.device)
-        own = self.level_own[lev].to(Xv.device)
+        if self.level_cols[lev].device != Xv.device:       # (once: the index lists live where X lives)
+            self.level_cols[lev] = self.level_cols[lev].to(Xv.device)
+            self.level_own[lev] = self.level_own[lev].to(Xv.device)
+        idx, own = self.level_cols[lev], self.level_own[lev]
         buf = Xv[:, idx]
         if own_only:
             buf = buf * own
@@ -375,7 +378,9 @@ class LeveledShardedSolve(ShardedSolve):
 
     def forward(self, L, B, nrhs: int = 1, stream: int = 0):
         """L x = b.  Returns X: complete on the root rank."""
-        X = (B.view(nrhs, self.n) * self.keep_in.to(B.device)).view(-1).contiguous()
+        if self.keep_in.device != B.device:
+            self.keep_in = self.keep_in.to(B.device)
+        X = (B.view(nrhs, self.n) * self.keep_in).view(-1).contiguous()
         Xv = X.view(nrhs, self.n)
         self.exchanged = 0
         self.sub.forward(L, X, nrhs, self.n, stream)

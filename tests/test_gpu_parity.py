@@ -135,6 +135,8 @@ def test_solve_in_steps_of_levels_matches_oracle(api, oracle, monkeypatch, name,
     # a refused call says why
     with pytest.raises(RuntimeError, match="level_begin <= level_end"):
         plan.solve_levels_device(Ld.data_ptr(), Ld.data_ptr(), 1, sym.n, 0, 3, 2, True, True)
+    with pytest.raises(RuntimeError, match="needs an open solve"):
+        plan.solve_levels_device(Ld.data_ptr(), X.data_ptr(), nrhs, sym.n, 0, 0, 1, False, False)
 
 
 @pytest.mark.parametrize("name", ["ex15", "lap30", "nd24k", "parabolic_fem"])
