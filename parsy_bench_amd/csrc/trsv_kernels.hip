@@ -1313,6 +1313,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_chain_mrhs(const SnDesc* 
 //     atomicAdd per (row, right-hand side) at the end (reference Triangular_BCSC.h:139-157: the `omp atomic` scatter).
 // 64 right-hand sides per pass over L.  Every wait is bounded and watches the solve's status word.
 // ---------------------------------------------------------------------------
+#ifdef PARSY_BLKSTAMPS
+// (diagnostic build, tools/blk_stamps.py) the block-column tasks of the LAST launch leave, per block column jb: 100-MHz
+// clock when X_(jb-1) was seen whole, after the products with it, after the product with the inverse block, after the stores
+__device__ unsigned long long g_blkstamp[512 * 8];
+#define BLK_STAMP(i) do { if (tid == 0 && plane == 0 && jb < 512) g_blkstamp[jb * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" void parsy_debug_blkstamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blkstamp), sizeof(unsigned long long) * 512 * 8);
+}
+#else
+#define BLK_STAMP(i) do { } while (0)
+#endif
 #define TSF(c, q) ts[(c) * kLdXm + (q)]
 __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc* __restrict__ sn,
                                                                    const PanelDesc* __restrict__ pds,
@@ -1368,6 +1379,40 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
             }
         }
         __syncthreads();
+        // The chain's step, block column jb - 1 -> jb, was 64 products with X_(jb-1), 40 with the inverse block and the
+        // stores, one after the other (tools/blk_stamps.py: 2.4 + 1.4 + 0.8 of a 5.7-us hop, the hand-off itself 1.0).  With
+        //     M = inv(L_jj) L(jb, jb-1)   (64 x 64, needs no X: formed here, wave v its columns 16 v .. 16 v + 15, -> LDS)
+        //     P = inv(L_jj) (B_jb - sum_{k < jb-1} L(jb, k) X_k)   (formed while X_(jb-1) is still on its way)
+        // what is left behind the wait is X_jb = P - M X_(jb-1): the 64 products alone, in two independent sets of
+        // accumulators.
+        double* __restrict__ Ms = ts;   // Ms[k][row] = M[row][k], ld kLdDiag (the layout of Dg: the same operand reads)
+        if (jb > 0) {
+            const int cbp = cb - kTile;
+            double4_s am[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) am[rg] = double4_s{0, 0, 0, 0};
+            // B operand: lane (j = l15, kk = kq) holds L(jb, jb-1)[4 st + kk][16 v + j]
+            const double* __restrict__ bcol = G + (int64_t)(cbp + 16 * wave + l15) * r + cb;
+            double lb[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int i = 4 * st + kq;
+                const double v = bcol[min(i, wbk - 1)];
+                lb[st] = i < wbk ? v : 0.0;
+            }
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (st < 4 * rg + 4)
+                        am[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(4 * st + kq) * kLdDiag + 16 * rg + l15], lb[st], am[rg], 0, 0, 0);
+            // accumulator (lane (j, kk): rows 16 rg + kk + 4 v of column 16 wave + j) -> Ms[column][row]
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Ms[(16 * wave + l15) * kLdDiag + 16 * rg + kq + 4 * v] = am[rg][v];
+            __syncthreads();
+        }
         // this lane's rows of the block as A operand: row 16 rg + l15 (clamped into the block)
         const double* __restrict__ arow[4];
         bool aok[4];
@@ -1395,23 +1440,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) acc[rg] = double4_s{0, 0, 0, 0};
             bool ok = true;
-            for (int k = 0; k < jb && ok; ++k) {
-                // L(jb, k): columns 64 k + 4 st + kq, issued before the wait for X_k
-                double av[16][4];
-#pragma unroll
-                for (int st = 0; st < 16; ++st) {
-                    const int64_t col = (int64_t)(k * kTile + 4 * st + kq) * r;
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const double a = arow[rg][col];
-                        av[st][rg] = aok[rg] ? a : 0.0;
-                    }
-                }
+            // X_k (this wave's 16 right-hand sides, rows 4 st + kq) as soon as it is there; lazy: a block that is not the
+            // one right before this one first watches ONE value, then goes on to the full poll (normally satisfied at once)
+            auto take_x = [&](int k, bool lazy, double (&bv)[16]) __attribute__((always_inline)) {
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
-                // only the block right before this one is on the critical path: a workgroup further down the chain
-                // first watches ONE value of X_k lazily, then goes on to the full poll (normally satisfied at once)
-                if (jb - k > 1) {
+                if (lazy) {
                     const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + (k * kTile + 63) * sr);
                     while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
                         if (give_up(t0, spins)) {
@@ -1421,7 +1455,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                         __builtin_amdgcn_s_sleep(48);
                     }
                 }
-                double bv[16];
                 while (ok) {
                     bool in = true;
 #pragma unroll
@@ -1435,6 +1468,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     if (give_up(t0, spins)) ok = false;
                     else __builtin_amdgcn_s_sleep(1);
                 }
+            };
+            for (int k = 0; k < jb - 1 && ok; ++k) {
+                // L(jb, k): columns 64 k + 4 st + kq, issued before the wait for X_k
+                double av[16][4];
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const int64_t col = (int64_t)(k * kTile + 4 * st + kq) * r;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const double a = arow[rg][col];
+                        av[st][rg] = aok[rg] ? a : 0.0;
+                    }
+                }
+                double bv[16];
+                take_x(k, true, bv);
                 if (!ok) break;
 #pragma unroll
                 for (int st = 0; st < 16; ++st)
@@ -1446,12 +1494,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                 if (lane == 0) atomicMin(info, -1);
                 return;
             }
-            // T = B - sum: k step st = 4 rg + v of the product with the inverse block
+            // T' = B - sum: k step st = 4 rg + v of the product with the inverse block
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) tv[4 * rg + v] -= acc[rg][v];
-            // X_jb = inv(L_jj) T (row group rg needs k <= 16 rg + 15)
+            // P = inv(L_jj) T' (row group rg needs k <= 16 rg + 15) -- X_jb itself for the first block column
             double4_s out[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) out[rg] = double4_s{0, 0, 0, 0};
@@ -1461,16 +1509,55 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                 for (int rg = 0; rg < 4; ++rg)
                     if (st < 4 * rg + 4)
                         out[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(4 * st + kq) * kLdDiag + 16 * rg + l15], tv[st], out[rg], 0, 0, 0);
+            if (jb > 0) {
+                // M as A operand (rows 16 rg + l15, columns 4 st + kq), in registers before the wait
+                double mv[16][4];
+#pragma unroll
+                for (int st = 0; st < 16; ++st)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) mv[st][rg] = Ms[(4 * st + kq) * kLdDiag + 16 * rg + l15];
+                double bv[16];
+                take_x(jb - 1, false, bv);
+                if (!ok) {
+                    if (lane == 0) atomicMin(info, -1);
+                    return;
+                }
+                BLK_STAMP(0);
+                double4_s m0[4], m1[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) m0[rg] = m1[rg] = double4_s{0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 16; st += 2)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        m0[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st][rg], bv[st], m0[rg], 0, 0, 0);
+                        m1[rg] = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st + 1][rg], bv[st + 1], m1[rg], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) out[rg] -= m0[rg] + m1[rg];
+            }
+#ifdef PARSY_BLKSTAMPS
+            asm volatile("" ::"v"(out[3][3]));
+            BLK_STAMP(1);
+#endif
             // straight from the accumulators to x and the armed buffer (lane (q = l15, row = kq + 4 v))
+            // (the armed buffer first: it is what the next block column polls)
+            BLK_STAMP(2);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = 16 * rg + kq + 4 * v;
-                    if (c < wbk && qok) {
+                    if (c < wbk && qok)
                         __hip_atomic_store(&xscratch[qoff + (cb + c) * sr], unarmed(out[rg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        x[qoff + (cb + c) * sr] = out[rg][v];
-                    }
+                }
+            BLK_STAMP(3);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = 16 * rg + kq + 4 * v;
+                    if (c < wbk && qok) x[qoff + (cb + c) * sr] = out[rg][v];
                 }
         }
         return;
