@@ -112,6 +112,9 @@ def _rank_main(rank, world, port, name, env, out_dir, distinct=False):
 @pytest.mark.parametrize("name,world,env", [
     ("mid3d", 2, {}),
     ("lap30", 3, {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "32"}),
+    # 2 x 2 super-tiles and the dense kernel wherever a dense entry exists: strips ride with their blocks (round 5) -- the
+    # distributed factor must still be bitwise the single-plan one
+    ("nd24k", 3, {"PARSY_PIECE_WIDTH": "256", "PARSY_BIG_MINK": "64", "PARSY_BIG_SUPER": "2", "PARSY_BIG_DENSE": "2"}),
 ])
 def test_ranks_sharing_the_device_factor_and_solve(tmp_path, name, world, env):
     import torch.multiprocessing as mp

@@ -121,6 +121,35 @@ def test_super_tiles_cover_every_update_once(monkeypatch, name, piece, mink, sup
         N.lib().parsy_plan_destroy(h1)
 
 
+@pytest.mark.parametrize("name,piece,mink,sup", [("nd24k", 256, 64, "2"), ("lap30", 128, 32, "2"), ("lap30", 256, 64, "2x1")])
+def test_strips_ride_with_their_dense_blocks(monkeypatch, name, piece, mink, sup):
+    """Round 5: a remainder of <= 16 rows (columns) of a source's run right behind (beside) a full 128 x 128 block is not
+    an entry of the ragged launch but rides with that block (WaveEntry::mn bits 17-26).  The flop identity of
+    parsy_plan_check counts the strips with their blocks; the pairing is made per task from the pattern alone, so a
+    rank's piece mask changes neither the count nor the check; PARSY_DENSE_STRIPS=0 is the plan without."""
+    from parsy_bench_amd import api
+    A, perm, sym = problem(name)
+    monkeypatch.setenv("PARSY_PIECE_WIDTH", str(piece))
+    monkeypatch.setenv("PARSY_BIG_MINK", str(mink))
+    monkeypatch.setenv("PARSY_BIG_SUPER", sup)
+    monkeypatch.setenv("PARSY_BIG_DENSE", "2")
+    monkeypatch.setenv("PARSY_DENSE_STRIPS", "0")
+    plan0 = api.Plan(sym, -1)
+    monkeypatch.delenv("PARSY_DENSE_STRIPS")
+    plan = api.Plan(sym, -1)
+    i0, i1 = plan0.info, plan.info
+    assert i0["dense_strip_entries"] == 0 and i1["dense_strip_entries"] > 0
+    assert plan0.check() == 0 and plan.check() == 0
+    assert i1["big_flops"] == i0["big_flops"] and i1["dense_flops"] > i0["dense_flops"]
+    assert i1["dense_entries"] == i0["dense_entries"] and i1["big_tasks"] <= i0["big_tasks"]
+    D = api.Dist(plan, 3)
+    for rank in range(3):
+        plan.set_active_pieces(D.mask(rank))
+        assert plan.check() == 0 and plan.info["dense_strip_entries"] == i1["dense_strip_entries"]
+    plan.set_active_pieces(None)
+    assert plan.check() == 0
+
+
 @pytest.mark.parametrize("name,piece,mink,mode", [("mid3d", 128, 16, 2), ("lap30", 128, 32, 1), ("nd24k", 512, 128, 2),
                                                   ("nd24k", None, None, 2)])
 def test_split_chain_launches_are_consistent(monkeypatch, name, piece, mink, mode):
