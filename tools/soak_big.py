@@ -25,6 +25,8 @@ CASES = [("lap30", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16"}, REPS),
          ("nd24k", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "16", "PARSY_BIG_DENSE": "4"}, REPS),
          ("lap30", {"PARSY_PIECE_WIDTH": "128", "PARSY_BIG_MINK": "32", "PARSY_BIG_DENSE": "2", "PARSY_BIG_SUPER": "2"}, REPS),
          ("nd24k", {"PARSY_PIECE_WIDTH": "256", "PARSY_BIG_MINK": "64", "PARSY_BIG_DENSE": "2"}, REPS),
+         # round 5: strips riding with their dense blocks (2 x 2 super-tiles, the dense kernel wherever a full block exists)
+         ("nd24k", {"PARSY_PIECE_WIDTH": "256", "PARSY_BIG_MINK": "64", "PARSY_BIG_DENSE": "2", "PARSY_BIG_SUPER": "2"}, REPS),
          ("64x64x64", {}, max(REPS // 3, 10)),
          ("flan", {}, max(REPS // 15, 5))]
 for name, env, reps in CASES:
@@ -54,7 +56,7 @@ for name, env, reps in CASES:
             stat += plans[j].status() != 0
     bad += mism + stat
     print(f"{name} {env}: {reps} rounds (alone / two in flight alternating), big_tasks {info['big_tasks']} "
-          f"big_entries {info['big_entries']} dense_entries {info['dense_entries']} pieces {info['n_pieces']}: checksum mismatches {mism}, bad status {stat}, "
+          f"big_entries {info['big_entries']} dense_entries {info['dense_entries']} strips {info['dense_strip_entries']} pieces {info['n_pieces']}: checksum mismatches {mism}, bad status {stat}, "
           f"{time.time() - t0:.1f} s", flush=True)
     del plans, Ls
 print("SOAK", "FAILED" if bad else "ok")
