@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(kChainThreads, 1) void k_solve_chain_w(const SnDesc
 // product too (t through LDS into operand layout); the rows below the supernode's columns are scattered at the end
 // with atomics, as in the one-vector kernel.
 static constexpr int kMrhsWideBlocks = 128;   // backward launches of at least this many blocks take 64 right-hand sides per pass
+static constexpr int kBChainMinBlocks = 128;  // ... chain launches: k_bsolve_chain_mrhs from this many block columns on
 static constexpr int kLdXm = kRhsM + 16;  // row stride of the staged x_jb / t_jb (doubles): conflict-free operand reads
 static constexpr int kSolveRowsM = kSolveRowsMrhs;   // rows of a chunk task of k_solve_blocks_mrhs (schedule.hpp)
 
@@ -3047,6 +3048,361 @@ __global__ __launch_bounds__(kThreads, QG == 4 ? 1 : 2) void k_bsolve_block_mrhs
     }
   }
 }
+// ---------------------------------------------------------------------------
+// The chain launches of the backward solve with many right-hand sides, 64 per pass (round 5): a kernel of its own -- inside
+// k_bsolve_block_mrhs, beside that kernel's other forms, the compiler spilled 235 registers.  One workgroup per block column
+// of a wide supernode, taken by ticket (last block column first).  First the rows below the supernode's own columns (x final
+// there), 64-row chunks over the four waves as in k_bsolve_block_mrhs, reduced ONCE into the staged Y; then the chain, every
+// wave for itself on 16 right-hand sides and all 64 columns (the comment inside).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc* __restrict__ sn, const PanelDesc* __restrict__ pds,
+                                                                  const int32_t* __restrict__ rows, const double* __restrict__ L,
+                                                                  double* __restrict__ x, double* __restrict__ xscratch, int nrhs,
+                                                                  int ldx, int* __restrict__ info, int* __restrict__ ticket,
+                                                                  int wait_bias, int nblocks, const double* __restrict__ dinv) {
+    constexpr int QG = 4;
+    __shared__ double Dg[kTile * kLdDiag];
+    __shared__ double ts[kTile * kLdXm];
+    __shared__ double Ms[kTile * kLdDiag];   // Ms[k][c] = M[c][k]
+    __shared__ int s_task;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    if (tid == 0) s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int plane = s_task / nblocks;
+    const PanelDesc pd = pds[s_task - plane * nblocks];
+    const SnDesc D = sn[pd.sn];
+    const int r = D.r, w = D.w, cb = pd.jb * kTile, wbk = min(kTile, w - cb);
+    const double* __restrict__ G = L + D.px;
+    const int32_t* __restrict__ ri = rows + D.pi;
+    {   // the inverse diagonal block (DIAG_INVERSE; identity outside the block) -> LDS: Dg[c][k] = inv(L_jj)[k][c]
+        double dtmp[kTile * kTile / kThreads];
+        const double* __restrict__ inv_blk = dinv + (int64_t)(D.dslot + pd.jb) * (kTile * kTile);
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) dtmp[t] = inv_blk[t * kThreads + tid];
+#pragma unroll
+        for (int t = 0; t < kTile * kTile / kThreads; ++t) {
+            const int e = t * kThreads + tid;
+            Dg[(e >> 6) * kLdDiag + (e & 63)] = dtmp[t];
+        }
+    }
+    const int nbc = (w + kTile - 1) / kTile;
+    const bool has_up = pd.jb + 1 < nbc;
+    __syncthreads();
+    if (has_up) {
+        // M[c'][k] = sum_c inv(L_jj)[c][c'] L[64 (jb+1) + k][cb + c]: wave v the k's 16 v .. 16 v + 15
+        const int k0 = (pd.jb + 1) * kTile + 16 * wave + l15;      // this lane's row of block jb + 1 (B operand: j = l15)
+        const bool kin = k0 < w;
+        const double* __restrict__ brow = G + (int64_t)cb * r + min(k0, w - 1);
+        double lb[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int c = 4 * st + kq;
+            const double v = brow[(int64_t)min(c, wbk - 1) * r];
+            lb[st] = (kin && c < wbk) ? v : 0.0;
+        }
+        double4_s am[4];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) am[cg] = double4_s{0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+                if (st >= 4 * cg)     // (inv(L_jj)[c][c'] = 0 for c < c')
+                    am[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(16 * cg + l15) * kLdDiag + 4 * st + kq], lb[st], am[cg], 0, 0, 0);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Ms[(16 * wave + l15) * kLdDiag + 16 * cg + kq + 4 * v] = am[cg][v];
+    }
+    constexpr int kPassRhs = 16 * QG;
+    for (int pass = plane; pass * kPassRhs < nrhs; pass += kPassLanes) {
+        const int q0 = pass * kPassRhs;
+        const int nq = min(kPassRhs, nrhs - q0);
+        __syncthreads();
+        for (int e = tid; e < kTile * kPassRhs; e += kThreads) {
+            const int c = e & 63, q = e >> 6;
+            TSM(c, q) = (c < wbk && q < nq) ? x[(int64_t)(q0 + q) * ldx + D.c0 + cb + c] : 0.0;
+        }
+        double4_s acc[4][QG];   // [16 columns][16 right-hand sides]: lane (q = l15, c = kq + 4 v)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < QG; ++b) acc[a][b] = double4_s{0, 0, 0, 0};
+        // operand pointers of this lane: column c = 16 cg + l15 of the block (clamped), right-hand side 16 qg + l15
+        const double* __restrict__ acol[4];
+        const double* __restrict__ xcol[QG];
+        bool aok[4], bok[QG];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            aok[g] = 16 * g + l15 < wbk;
+            acol[g] = G + (int64_t)(cb + min(16 * g + l15, wbk - 1)) * r;
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            bok[g] = 16 * g + l15 < nq;
+            xcol[g] = x + (int64_t)(q0 + min(16 * g + l15, nq - 1)) * ldx;
+        }
+        // ---- the rows below (chain: below the supernode's own columns -- ancestors, final; otherwise everything
+        // below the block: the later blocks were solved by earlier launches): 64-row chunks over the waves, 16 rows
+        // (4 k steps) of loads in flight ahead of their 64 products
+        // Software-pipelined over the k steps (4 rows each) of all of this wave's chunks: the operands of step t + 3 are
+        // loaded while the 4 x QG products of step t are issued (a ring of four operand sets); the row ids of a chunk are
+        // ONE load per lane, issued a chunk and a half ahead and handed to the lanes that need them by ds_bpermute.
+        // (The plain form -- ids, then operands, then 64 products, per 16 rows -- waited two dependent round trips per 64
+        // products: Flan-class input, 64 right-hand sides: 45 -> 37 ms per backward solve.)
+        {
+            const int kstart = w + 64 * wave;
+            constexpr int kStride = 64 * (kThreads / 64);
+            const int nsteps = kstart < r ? 16 * ((r - kstart + kStride - 1) / kStride) : 0;
+            auto row_ids = [&](int j) {   // lane l: the row id of row l of this wave's chunk j (clamped into the panel)
+                const int kr = min(kstart + kStride * j + lane, r - 1);
+                return (kr < w) ? (D.c0 + kr) : ri[kr];
+            };
+            int ridA = row_ids(0), ridB = row_ids(1);
+            double ra[4][4], rb[4][QG];
+            auto load = [&](int t, double (&A)[4], double (&B)[QG]) {
+                const int j = t >> 4, u = t & 15;
+                const int k = kstart + kStride * j + 4 * u + kq;
+                const bool kin = k < r && t < nsteps;
+                const int kc = min(k, r - 1);
+                const int rid = __builtin_amdgcn_ds_bpermute((4 * u + kq) * 4, (j & 1) ? ridB : ridA);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double a = acol[g][kc];
+                    A[g] = (kin && aok[g]) ? a : 0.0;
+                }
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const double b2 = xcol[g][rid];
+                    B[g] = (kin && bok[g]) ? b2 : 0.0;
+                }
+            };
+            if (nsteps > 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) load(t, ra[t], rb[t]);
+            }
+            for (int t = 0; t < nsteps; t += 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tt = t + i;
+                    load(tt + 3, ra[(i + 3) & 3], rb[(i + 3) & 3]);
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i][cg], rb[i][qg], acc[cg][qg], 0, 0, 0);
+                    if ((tt & 15) == 13) {   // the loads of this chunk's steps are all issued: its id register takes chunk j + 2
+                        const int j = tt >> 4;
+                        const int v = row_ids(j + 2);
+                        if (j & 1) ridB = v;
+                        else ridA = v;
+                    }
+                }
+            }
+        }
+        {
+            // ---- the later blocks of this supernode but the one right above, last one first, each as soon as its X is
+            // published: rows 64 I + 16 wave .. + 15 for this wave (every 128-byte line of L read once per workgroup: with
+            // all 64 rows per wave -- 16 lines per load instruction, four times over -- the Flan-class solve took 45-49 ms)
+            bool ok = true;
+            for (int I = nbc - 1; I > pd.jb + 1 && ok; --I) {
+                double av[4][4], bv[4][QG];
+                int kk[4];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    kk[st] = I * kTile + 16 * wave + 4 * st + kq;
+                    const int kc = min(kk[st], w - 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double a = acol[g][kc];
+                        av[st][g] = (kk[st] < w && aok[g]) ? a : 0.0;
+                    }
+                }
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                // Only the block right above this one is on the critical path of the chain.  A workgroup further up
+                // would poll for a long time, with 16 loads per lane and round, next to hundreds of others on the
+                // same lines (the top separator: 313 workgroups): it first watches ONE value of the block lazily
+                // (the last column this wave reads: one load per wave and round), and goes on to the full poll --
+                // normally satisfied at once -- when that value is there.
+                if (I - pd.jb > 1) {
+                    const int kw = min(I * kTile + 16 * wave + 15, w - 1);
+                    const long long* __restrict__ watch =
+                        reinterpret_cast<const long long*>(xscratch + (int64_t)q0 * ldx + D.c0 + kw);
+                    while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed ||
+                           wait_bias != 0) {
+                        if ((++spins & 15) == 0 &&
+                            (wall_clock64() - t0 > kSolveSpinTicks ||
+                             __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(48);
+                    }
+                    if (!ok) {
+                        if (lane == 0) atomicMin(info, -1);
+                        break;
+                    }
+                }
+                for (;;) {
+                    bool in = true;
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) {
+                            long long b = 0;
+                            if (kk[st] < w && bok[g])
+                                b = __hip_atomic_load(reinterpret_cast<const long long*>(
+                                                          xscratch + (xcol[g] - x) + D.c0 + kk[st]),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            bv[st][g] = __longlong_as_double(b);
+                        }
+                    if (__all(in && wait_bias == 0)) break;
+                    if ((++spins & 15) == 0 &&
+                        (wall_clock64() - t0 > kSolveSpinTicks ||
+                         __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) {
+                    if (lane == 0) atomicMin(info, -1);
+                    break;   // (the result is wrong and reported; nobody may hang)
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            acc[cg][qg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st][cg], bv[st][qg], acc[cg][qg], 0, 0, 0);
+            }
+        }
+        {
+            // ---- The chain (round 5: the mirror of k_solve_blocks_mrhs's block-column task).  Its step used to be: 16 rows of
+            // block I per wave (64 products), the four waves' parts subtracted from the staged Y one after the other behind
+            // barriers, the product with the inverse block by 16 columns per wave behind two more, the stores through LDS -- 19 us
+            // per block column on the Flan-class top separator.  Now the parts are reduced ONCE, after the block second next
+            // (T in LDS), and what follows is every wave's own, on 16 right-hand sides and all 64 columns, no barrier:
+            //     P = inv(L_jj)' T,     M = inv(L_jj)' L(jb + 1, jb)'   (64 x 64, formed when the pass starts)
+            //     X_jb = P - M X_(jb+1)                                   (all that is left behind the last wait)
+            // lane (q = l15, kk = kq) holds T[4 st + kk][q] -- the accumulator layout is the B-operand layout of k step
+            // st = 4 cg + v --, results go straight from the accumulators to the armed buffer and x.
+            for (int wv = 0; wv < kThreads / 64; ++wv) {
+                __syncthreads();
+                if (wave == wv) {
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) TSM(16 * cg + kq + 4 * v, 16 * qg + l15) -= acc[cg][qg][v];
+                }
+            }
+            __syncthreads();
+            const bool won = 16 * wave < nq;                 // this wave's 16 right-hand sides are in the pass
+            const bool qok = 16 * wave + l15 < nq;
+            double tv[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) tv[st] = TSM(4 * st + kq, 16 * wave + l15);
+            if (won) {
+                const int64_t qoff = (int64_t)(q0 + min(16 * wave + l15, nq - 1)) * ldx + D.c0;   // this lane's right-hand side, row c0
+                const double* __restrict__ xq = xscratch + qoff;
+                bool ok = true;
+                auto take_x = [&](int I, bool lazy, double (&bv)[16]) __attribute__((always_inline)) {
+                    const unsigned long long t0 = wall_clock64();
+                    int spins = 0;
+                    auto give_up = [&]() {
+                        return (++spins & 15) == 0 && (wall_clock64() - t0 > kSolveSpinTicks ||
+                                                       __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0);
+                    };
+                    if (lazy) {   // (a block further up: watch ONE value first -- the top separator has 313 workgroups polling)
+                        const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + min(I * kTile + 63, w - 1));
+                        while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
+                            if (give_up()) {
+                                ok = false;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(48);
+                        }
+                    }
+                    while (ok) {
+                        bool in = true;
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) {
+                            const int k = I * kTile + 4 * st + kq;
+                            long long b = 0;
+                            if (k < w && qok)
+                                b = __hip_atomic_load(reinterpret_cast<const long long*>(xq + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            bv[st] = __longlong_as_double(b);
+                        }
+                        if (__all(in && wait_bias == 0)) break;
+                        if (give_up()) ok = false;
+                        else __builtin_amdgcn_s_sleep(1);
+                    }
+                };
+                // P = inv(L_jj)' T: X[c'][q] = sum_{c >= c'} inv(L_jj)[c][c'] T[c][q]
+                double4_s out[4];
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) out[cg] = double4_s{0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < 16; ++st)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+                        if (st >= 4 * cg)
+                            out[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(16 * cg + l15) * kLdDiag + 4 * st + kq], tv[st], out[cg], 0, 0, 0);
+                if (has_up) {
+                    // (M's operands take the registers of the last block's: not before that block is multiplied)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    double mv[16][4];
+#pragma unroll
+                    for (int st = 0; st < 16; ++st)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) mv[st][cg] = Ms[(4 * st + kq) * kLdDiag + 16 * cg + l15];
+                    double bv[16];
+                    take_x(pd.jb + 1, false, bv);
+                    if (!ok) {
+                        if (lane == 0) atomicMin(info, -1);
+                        return;
+                    }
+                    double4_s m0[4], m1[4];
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) m0[cg] = m1[cg] = double4_s{0, 0, 0, 0};
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) {
+                            m0[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st][cg], bv[st], m0[cg], 0, 0, 0);
+                            m1[cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st + 1][cg], bv[st + 1], m1[cg], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) out[cg] -= m0[cg] + m1[cg];
+                }
+                // straight from the accumulators (lane (q = l15, c = 16 cg + kq + 4 v)): the armed buffer first, then x
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = 16 * cg + kq + 4 * v;
+                        if (c < wbk && qok)
+                            __hip_atomic_store(&xscratch[qoff + cb + c], unarmed(out[cg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = 16 * cg + kq + 4 * v;
+                        if (c < wbk && qok) x[qoff + cb + c] = out[cg][v];
+                    }
+            }
+        }
+    }
+}
+
 #undef TSM
 
 // Backward solve of supernodes of width <= 16: one WAVE per supernode, or per subtree of them from its root down
@@ -3563,6 +3919,18 @@ void launch_bsolve_block(const DevicePattern& P, int first, int count, const dou
         const char* e = std::getenv("PARSY_BMRHS_WIDE_ONLY");
         return !(e && e[0] == '0');
     }();
+    // (round 5) chain launches of more than 16 right-hand sides: k_bsolve_chain_mrhs from kBChainMinBlocks block columns on
+    // (PARSY_BCHAIN_MIN_BLOCKS), 64 right-hand sides per pass
+    static const int bchain_min = [] {
+        const char* e = std::getenv("PARSY_BCHAIN_MIN_BLOCKS");
+        return e && *e ? std::atoi(e) : kBChainMinBlocks;
+    }();
+    if (chain && nrhs > 16 && nrhs >= bmrhs_min() && count >= bchain_min) {
+        const int mlanes = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
+        hipLaunchKernelGGL(k_bsolve_chain_mrhs, dim3(count * mlanes), dim3(kThreads), 0, stream, P.sn, pds, P.rows, L, x, xscratch, nrhs,
+                           ldx, P.sinfo, P.stickets + ticket, wait_bias, count, dinv);
+        return;
+    }
     if (nrhs >= bmrhs_min() && (!wide_only || count >= kMrhsWideBlocks)) {   // 64 right-hand sides per pass over L, products on the matrix cores
         // launches of few blocks (the top of the tree, small inputs) take 16 right-hand sides per pass in up to 8
         // workgroups per block side by side; the others 64 per pass (L read once per 64)
