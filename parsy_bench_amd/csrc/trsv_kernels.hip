@@ -3290,16 +3290,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
             //     X_jb = P - M X_(jb+1)                                   (all that is left behind the last wait)
             // lane (q = l15, kk = kq) holds T[4 st + kk][q] -- the accumulator layout is the B-operand layout of k step
             // st = 4 cg + v --, results go straight from the accumulators to the armed buffer and x.
-            for (int wv = 0; wv < kThreads / 64; ++wv) {
-                __syncthreads();
-                if (wave == wv) {
+            // (the reduction in four rounds, all waves at once: in round rd wave v subtracts its part of the columns
+            // 16 ((v + rd) & 3) .. + 15 -- disjoint quarters of T, a fixed order of sums per entry; one wave after the other
+            // with all of its sixteen tiles took 4 us of the step)
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg)
+            for (int rd = 0; rd < 4; ++rd) {
+                __syncthreads();
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+                    if (cg == ((wave + rd) & 3)) {
 #pragma unroll
                         for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
                             for (int v = 0; v < 4; ++v) TSM(16 * cg + kq + 4 * v, 16 * qg + l15) -= acc[cg][qg][v];
-                }
+                    }
             }
             __syncthreads();
             const bool won = 16 * wave < nq;                 // this wave's 16 right-hand sides are in the pass
