@@ -1326,6 +1326,7 @@ extern "C" void parsy_debug_blkstamps(unsigned long long* out) {
 #define BLK_STAMP(i) do { } while (0)
 #endif
 #define TSF(c, q) ts[(c) * kLdXm + (q)]
+template <bool NARROW>   // at most 16 right-hand sides in all: the block-column tasks' waves share the rows of one group
 __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc* __restrict__ sn,
                                                                    const PanelDesc* __restrict__ pds,
                                                                    const int32_t* __restrict__ rows,
@@ -1338,7 +1339,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
     const bool tr = ldq > 0;
     const int64_t sr = tr ? ldq : 1, sq = tr ? 1 : ldx;
     __shared__ double Dg[kTile * kLdDiag];   // block task: inverse diagonal block, Dg[k][row] = inv(L_jj)[row][k]
-    __shared__ double ts[kTile * kLdXm];     // block task: T / X_jb as [row][q]; chunk task: the staged X_jb as [col][q]
+    __shared__ double ts[kTile * kLdXm];     // block task: M; chunk task: the staged X_jb as [col][q]
+    __shared__ double Tx[kTile * 17];        // block task, at most 16 right-hand sides: T' as [row][q]
     __shared__ int32_t s_task, s_ok;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1425,6 +1427,111 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
         for (int pass = plane; pass * kRhsM < nrhs; pass += kPassLanes) {
             const int q0 = pass * kRhsM;
             const int nq = min(kRhsM, nrhs - q0);
+            if constexpr (NARROW) {
+                // ---- at most 16 right-hand sides: ONE group, and the four waves share its ROWS -- wave v the rows
+                // 16 v .. 16 v + 15 of the block -- instead of three of them standing by: 16 products per earlier block and
+                // 16 behind the last wait (64 on one wave before: parabolic_fem-class, 8 right-hand sides, the chains 305 us of
+                // a 511-us solve).  P = inv(L_jj) T' needs the rows above a wave's own: T' goes through LDS once, before the wait.
+                const bool qok = l15 < nq;
+                const int64_t qoff = (q0 + min(l15, nq - 1)) * sq + D.c0 * sr;
+                const double* __restrict__ xq = xscratch + qoff;
+                const bool aokw = 16 * wave + l15 < wbk;
+                const double* __restrict__ ar = G + cb + min(16 * wave + l15, wbk - 1);
+                double tvo[4];   // this wave's rows of B_jb: rows 16 wave + 4 v + kq (the accumulator layout)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = 16 * wave + 4 * v + kq;
+                    const double t = x[qoff + (cb + min(c, wbk - 1)) * sr];
+                    tvo[v] = (qok && c < wbk) ? t : 0.0;
+                }
+                bool ok = true;
+                auto take_x = [&](int k, bool lazy, double (&bv)[16]) __attribute__((always_inline)) {
+                    const unsigned long long t0 = wall_clock64();
+                    int spins = 0;
+                    if (lazy) {
+                        const long long* __restrict__ watch = reinterpret_cast<const long long*>(xq + (k * kTile + 63) * sr);
+                        while (__hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kXArmed || wait_bias != 0) {
+                            if (give_up(t0, spins)) {
+                                ok = false;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(48);
+                        }
+                    }
+                    while (ok) {
+                        bool in = true;
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) {
+                            const long long b = __hip_atomic_load(reinterpret_cast<const long long*>(xq + (k * kTile + 4 * st + kq) * sr),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            in = in && b != kXArmed;
+                            bv[st] = qok ? __longlong_as_double(b) : 0.0;
+                        }
+                        if (__all((in || !qok) && wait_bias == 0)) break;
+                        if (give_up(t0, spins)) ok = false;
+                        else __builtin_amdgcn_s_sleep(1);
+                    }
+                };
+                double4_s a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+                for (int k = 0; k < jb - 1 && ok; ++k) {
+                    double av[16];
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const double a = ar[(int64_t)(k * kTile + 4 * st + kq) * r];
+                        av[st] = aokw ? a : 0.0;
+                    }
+                    double bv[16];
+                    take_x(k, true, bv);
+                    if (!ok) break;
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2) {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st + 1], bv[st + 1], a1, 0, 0, 0);
+                    }
+                }
+                if (!ok) {
+                    if (lane == 0) atomicMin(info, -1);
+                    return;
+                }
+                // T' = B - sums -> LDS as [row][q] (every wave reads the rows up to its own)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Tx[(16 * wave + 4 * v + kq) * 17 + l15] = tvo[v] - (a0[v] + a1[v]);
+                __syncthreads();
+                double4_s out = {0, 0, 0, 0};
+                for (int st = 0; st < 4 * wave + 4; ++st)     // (inv(L_jj)[row][k] = 0 for k > row)
+                    out = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(4 * st + kq) * kLdDiag + 16 * wave + l15], Tx[(4 * st + kq) * 17 + l15], out, 0, 0, 0);
+                if (jb > 0) {
+                    double mv[16];
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) mv[st] = Ms[(4 * st + kq) * kLdDiag + 16 * wave + l15];
+                    double bv[16];
+                    take_x(jb - 1, false, bv);
+                    if (!ok) {
+                        if (lane == 0) atomicMin(info, -1);
+                        return;
+                    }
+                    double4_s m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2) {
+                        m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st], bv[st], m0, 0, 0, 0);
+                        m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mv[st + 1], bv[st + 1], m1, 0, 0, 0);
+                    }
+                    out -= m0 + m1;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = 16 * wave + kq + 4 * v;
+                    if (c < wbk && qok)
+                        __hip_atomic_store(&xscratch[qoff + (cb + c) * sr], unarmed(out[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = 16 * wave + kq + 4 * v;
+                    if (c < wbk && qok) x[qoff + (cb + c) * sr] = out[v];
+                }
+                __syncthreads();   // (Tx is free for the next pass)
+                continue;
+            } else {
             if (16 * wave >= nq) continue;             // (this wave's 16 right-hand sides are not in the pass)
             const bool qok = 16 * wave + l15 < nq;
             const int64_t qoff = (q0 + min(16 * wave + l15, nq - 1)) * sq + D.c0 * sr;   // this lane's right-hand side, row c0
@@ -1560,6 +1667,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     const int c = 16 * rg + kq + 4 * v;
                     if (c < wbk && qok) x[qoff + (cb + c) * sr] = out[rg][v];
                 }
+            }
         }
         return;
     }
@@ -1700,8 +1808,12 @@ void launch_solve_blocks_mrhs(const DevicePattern& P, int first, int count, cons
                               hipStream_t stream) {
     if (count <= 0) return;
     const int lanes_m = std::min(kPassLanes, (nrhs + kRhsM - 1) / kRhsM);
-    hipLaunchKernelGGL(k_solve_blocks_mrhs, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn, P.solve_mtasks + first,
-                       P.rows, L, dinv, x, xscratch, nrhs, ldx, ldq, P.sinfo, P.stickets + ticket, wait_bias, count);
+    if (nrhs <= 16)
+        hipLaunchKernelGGL(k_solve_blocks_mrhs<true>, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn, P.solve_mtasks + first,
+                           P.rows, L, dinv, x, xscratch, nrhs, ldx, ldq, P.sinfo, P.stickets + ticket, wait_bias, count);
+    else
+        hipLaunchKernelGGL(k_solve_blocks_mrhs<false>, dim3(count * lanes_m), dim3(kThreads), 0, stream, P.sn, P.solve_mtasks + first,
+                           P.rows, L, dinv, x, xscratch, nrhs, ldx, ldq, P.sinfo, P.stickets + ticket, wait_bias, count);
 }
 
 // X between its two layouts: right-hand-side-major a[q * lda + row] <-> row-major b[row * ldb + q] (64 x 64 tiles
