@@ -267,7 +267,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
         const int cus = compute_units > 0 ? compute_units : 256;
         std::vector<uint8_t> elig(ns, 0);
         auto cut = [&](std::vector<double>& cost, double min_cost, std::vector<int32_t>& subtree,
-                       const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr, int64_t min_members = -1) {
+                       const std::vector<std::pair<int32_t, int32_t>>* slots = nullptr, int64_t min_members = -1, int aim_per_cu = 0) {
             double total = 0;
             int64_t members = 0;
             {   // everything that could be in a subtree at all
@@ -280,7 +280,7 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                     }
             }
             if (!forced && members < (min_members >= 0 ? min_members : (int64_t)kSubtreeMinPerSlot * per_cu * cus)) return 0;
-            return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)per_cu * cus)), subtree, slots,
+            return find_subtrees(tree, elig, cost, std::max(min_cost, total / ((double)(aim_per_cu > 0 ? aim_per_cu : per_cu) * cus)), subtree, slots,
                                  kSubMaxSlots);
         };
         if (!S.solve_only) {
@@ -293,7 +293,11 @@ void build_schedule(const PatternRef& P, const size_t* lC, const int* A2p, const
                     c += 1e4 + 2.0 * S.upd[u].K * (double)S.upd[u].m * S.upd[u].n1;
                 S.chol_cost[t] = c;
             }
-            S.n_chol_subtrees = cut(S.chol_cost, kSubtreeMinCost, S.chol_subtree);
+            // (the factorization's subtrees aim at more, smaller ones than the threshold above counts with: a workgroup
+            // keeps a whole panel in LDS, one or two per compute unit, and the launch runs alone on the device -- Flan-class
+            // 3.8 -> 2.9 ms with 64 per unit, 3.2 with 128: profiles/r05_dense_thresholds.txt.  PARSY_CHOL_SUBTREES)
+            S.n_chol_subtrees = cut(S.chol_cost, kSubtreeMinCost, S.chol_subtree, nullptr, -1,
+                                    forced ? 0 : std::max(1, env_int("PARSY_CHOL_SUBTREES", kCholSubtreesPerCu)));
         }
         S.solve_cost.assign(ns, 0.0);
         // solves: the subtrees of TINY supernodes (one wave walks one: the wave-per-supernode solve kernel)

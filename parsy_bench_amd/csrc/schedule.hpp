@@ -222,6 +222,7 @@ constexpr int kOneSmallBlocks = 1024;     // launches of at most this many block
 constexpr int kOneMidBlocks = 4096;       // ... (both: plans of at most this many blocks)
 constexpr int kOneRhs8Density = 400;      // forward: up to kOneMaxRhs right-hand sides too where the factor stores fewer entries per row than this
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
+constexpr int kCholSubtreesPerCu = 64;    // ... the factorization's: this many
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
 constexpr double kSubtreeMinCost = 2e5;   // ... but never cut below this cost (flop equivalents; solves: 1/16 of it)
 constexpr int kSubtreeMinPerSlot = 2;     // ... and only where there are this many eligible supernodes per subtree
