@@ -220,7 +220,9 @@ constexpr int64_t kOneMaxEntries = 1 << 28;     // ... this many stored entries 
 constexpr int kOneMaxSupernodesBig = 32768;     // above a subtree launch, one right-hand side at a time: up to this many supernodes outside it
 constexpr int kOneSmallBlocks = 1024;     // launches of at most this many blocks take up to kOneMaxRhs right-hand sides, larger ones 4
 constexpr int kOneMidBlocks = 4096;       // ... (both: plans of at most this many blocks)
-constexpr int kOneRhs8Density = 400;      // forward: up to kOneMaxRhs right-hand sides too where the factor stores fewer entries per row than this
+constexpr int kOneRhs8Density = 300;      // forward: up to kOneMaxRhs right-hand sides too where the factor stores fewer entries per row than this
+                                          // (400 until the level launches of at most 16 right-hand sides shared their rows: 30^3 7-point, 316 per row,
+                                          // 8 right-hand sides 0.407 with the ONE launch, 0.350 without; 96 x 96 x 12 27-point, 351: 0.689 / 0.646)
 constexpr int kOneMaxRhs = 8;             // ... the block has at most this many right-hand sides (PARSY_SOLVE_ONE=0: never, 2: always)
 constexpr int kCholSubtreesPerCu = 64;    // ... the factorization's: this many
 constexpr int kSubtreesPerCu = 16;        // subtree launches: aim at this many subtrees per compute unit ...
