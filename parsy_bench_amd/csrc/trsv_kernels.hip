@@ -1489,14 +1489,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                         a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st + 1], bv[st + 1], a1, 0, 0, 0);
                     }
                 }
+                // (a hand-off that timed out is reported; the waves leave TOGETHER, behind the barrier)
                 if (!ok) {
                     if (lane == 0) atomicMin(info, -1);
-                    return;
+                    s_ok = 0;
                 }
                 // T' = B - sums -> LDS as [row][q] (every wave reads the rows up to its own)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Tx[(16 * wave + 4 * v + kq) * 17 + l15] = tvo[v] - (a0[v] + a1[v]);
                 __syncthreads();
+                if (!s_ok) return;
                 double4_s out = {0, 0, 0, 0};
                 for (int st = 0; st < 4 * wave + 4; ++st)     // (inv(L_jj)[row][k] = 0 for k > row)
                     out = __builtin_amdgcn_mfma_f64_16x16x4f64(Dg[(4 * st + kq) * kLdDiag + 16 * wave + l15], Tx[(4 * st + kq) * 17 + l15], out, 0, 0, 0);
@@ -1508,7 +1510,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     take_x(jb - 1, false, bv);
                     if (!ok) {
                         if (lane == 0) atomicMin(info, -1);
-                        return;
+                        s_ok = 0;
                     }
                     double4_s m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
 #pragma unroll
@@ -1518,18 +1520,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_solve_blocks_mrhs(const SnDesc*
                     }
                     out -= m0 + m1;
                 }
+                // (this block's x stays armed after a time-out: its waiters see the status word)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = 16 * wave + kq + 4 * v;
-                    if (c < wbk && qok)
+                    if (c < wbk && qok && ok)
                         __hip_atomic_store(&xscratch[qoff + (cb + c) * sr], unarmed(out[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = 16 * wave + kq + 4 * v;
-                    if (c < wbk && qok) x[qoff + (cb + c) * sr] = out[v];
+                    if (c < wbk && qok && ok) x[qoff + (cb + c) * sr] = out[v];
                 }
                 __syncthreads();   // (Tx is free for the next pass)
+                if (!s_ok) return;
                 continue;
             } else {
             if (16 * wave >= nq) continue;             // (this wave's 16 right-hand sides are not in the pass)

@@ -986,6 +986,36 @@ def test_solve_timeout_is_reported_not_returned_as_success(api, oracle, monkeypa
     api.dropin_reset()
 
 
+@pytest.mark.parametrize("nrhs", [8, 40])
+def test_many_rhs_solve_timeout_is_reported(api, oracle, monkeypatch, nrhs):
+    """The same with many right-hand sides: the block-column tasks of k_solve_blocks_mrhs (8: the waves share one group's
+    rows and leave together behind a barrier; 40: a wave per group) and the backward chain kernels run into their bounded
+    waits, the solve reports -1 instead of hanging or returning a wrong x, and the next solve is clean."""
+    monkeypatch.setenv("PARSY_SOLVE_ONE", "0")
+    A, perm, sym = problem("lap30")
+    plan = api.Plan(sym, 0)
+    lv, _ = plan.factor(sym.A2x)
+    assert plan.status() == 0
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((sym.n, nrhs))
+    X, _ = plan.solve(lv, B)
+    assert plan.solve_status() == 0
+    monkeypatch.setenv("PARSY_DEBUG_SOLVE_STALL", "1")
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve(lv, B)
+    assert plan.solve_status() == -1
+    with pytest.raises(RuntimeError, match="timed out"):
+        plan.solve2(lv, B, forward=False)
+    monkeypatch.delenv("PARSY_DEBUG_SOLVE_STALL")
+    X2, _ = plan.solve(lv, B)
+    assert plan.solve_status() == 0 and np.array_equal(X2, X) or np.abs(X2 - X).max() <= 1e-12 * max(1.0, np.abs(X).max())
+    Xb, _ = plan.solve2(lv, B, forward=False)
+    assert plan.solve_status() == 0
+    for q in (0, nrhs - 1):
+        xb = oracle.blocked_ltsolve(sym, lv, B[:, q])
+        assert np.abs(Xb[:, q] - xb).max() <= SOLVE_TOL * max(1.0, np.abs(xb).max())
+
+
 # ---------------------------------------------------------------------------
 # ONE-launch solves of small plans (k_solve_one, k_bsolve_one): one workgroup per block column taken by ticket
 # in level order, every value handed over as the data itself (an armed buffer) instead of level launches.  By itself
