@@ -3406,6 +3406,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
             //     X_jb = P - M X_(jb+1)                                   (all that is left behind the last wait)
             // lane (q = l15, kk = kq) holds T[4 st + kk][q] -- the accumulator layout is the B-operand layout of k step
             // st = 4 cg + v --, results go straight from the accumulators to the armed buffer and x.
+#ifdef PARSY_BLKSTAMPS
+            { const int jb = pd.jb; BLK_STAMP(4); }
+#endif
             // (the reduction in four rounds, all waves at once: in round rd wave v subtracts its part of the columns
             // 16 ((v + rd) & 3) .. + 15 -- disjoint quarters of T, a fixed order of sums per entry; one wave after the other
             // with all of its sixteen tiles took 4 us of the step)
@@ -3422,6 +3425,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
                     }
             }
             __syncthreads();
+#ifdef PARSY_BLKSTAMPS
+            const int jb = pd.jb;   // (BLK_STAMP's index)
+            BLK_STAMP(5);
+#endif
             const bool won = 16 * wave < nq;                 // this wave's 16 right-hand sides are in the pass
             const bool qok = 16 * wave + l15 < nq;
             double tv[16];
@@ -3484,11 +3491,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) mv[st][cg] = Ms[(4 * st + kq) * kLdDiag + 16 * cg + l15];
                     double bv[16];
+                    BLK_STAMP(6);
                     take_x(pd.jb + 1, false, bv);
                     if (!ok) {
                         if (lane == 0) atomicMin(info, -1);
                         return;
                     }
+                    BLK_STAMP(0);
                     double4_s m0[4], m1[4];
 #pragma unroll
                     for (int cg = 0; cg < 4; ++cg) m0[cg] = m1[cg] = double4_s{0, 0, 0, 0};
@@ -3502,6 +3511,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
 #pragma unroll
                     for (int cg = 0; cg < 4; ++cg) out[cg] -= m0[cg] + m1[cg];
                 }
+#ifdef PARSY_BLKSTAMPS
+                asm volatile("" ::"v"(out[3][3]));
+                BLK_STAMP(1);
+#endif
                 // straight from the accumulators (lane (q = l15, c = 16 cg + kq + 4 v)): the armed buffer first, then x
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
@@ -3511,6 +3524,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_bsolve_chain_mrhs(const SnDesc*
                         if (c < wbk && qok)
                             __hip_atomic_store(&xscratch[qoff + cb + c], unarmed(out[cg][v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                BLK_STAMP(3);
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
