@@ -336,8 +336,9 @@ static int bmrhs_min() {                // ... of the backward solve (PARSY_BMRH
     return v;
 }
 static constexpr int kLdXs = kRhsM + 4; // row stride of xs in LDS
+static constexpr int kSmallMrhsHalvesMin = 512;   // k_solve_small_mrhs<64>: launches of at least this many supernodes sweep in halves
 
-template <int WMAX>  // widest supernode of the launch, rounded up to 16 / 32 / 64: sizes LDS and loops
+template <int WMAX, bool HALVES = false>  // WMAX: widest supernode of the launch, rounded up to 16 / 32 / 64: sizes LDS and loops
 __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __restrict__ sn,
                                                                const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ ranges,
@@ -445,13 +446,20 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
         }
         // ---- (B) rows below the diagonal block
         const int nfrag_n = (nq + 15) >> 4;
-        if (r > w) {
+        // (HALVES, for launches of many supernodes up to 64 wide: the right-hand sides in two halves of 32, the rows below
+        // swept once per half -- with the x operands of all 64 in registers the kernel takes 311 of them and ONE workgroup
+        // fits a compute unit: Flan-class, levels 3-5, 64 right-hand sides: 12 500 supernodes in 2.75 ms; in halves 214
+        // registers, two workgroups: forward solve 18.3 -> 17.6 ms.  A launch of few supernodes has the units to itself
+        // either way and keeps the one sweep: nd24k- / mid3d-class +1.4 / +3 % in halves)
+        constexpr int kNh = HALVES ? 2 : 4;   // 16-right-hand-side groups per sweep
+        if (r > w)
+          for (int n0 = 0; n0 < nfrag_n; n0 += kNh) {
             constexpr int kSt = WMAX / 4;
-            double xa[4][kSt];  // A operands: xa[n][st] = x_s[c = 4 st + kq][rhs 16 n + l15]
+            double xa[kNh][kSt];  // A operands: xa[n][st] = x_s[c = 4 st + kq][rhs 16 (n0 + n) + l15]
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < kNh; ++n)
 #pragma unroll
-                for (int st = 0; st < kSt; ++st) xa[n][st] = xs[(4 * st + kq) * kLdXs + 16 * n + l15];
+                for (int st = 0; st < kSt; ++st) xa[n][st] = xs[(4 * st + kq) * kLdXs + 16 * (n0 + n) + l15];
             for (int k0 = w + 16 * wave; k0 < r; k0 += 16 * (kThreads / 64)) {
                 const int row_l = min(k0 + l15, r - 1);
                 double lv[kSt];
@@ -469,13 +477,13 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
 #pragma unroll
                     for (int v = 0; v < 4; ++v) xr[v] = ri[min(k0 + kq + 4 * v, r - 1)];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        if (n < nfrag_n) {
+                    for (int n = 0; n < kNh; ++n) {
+                        if (n0 + n < nfrag_n) {
                             double4_s acc = {0, 0, 0, 0};
 #pragma unroll
                             for (int st = 0; st < kSt; ++st)
                                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[st], xa[n][st], acc, 0, 0, 0);
-                            const int q = 16 * n + l15;
+                            const int q = 16 * (n0 + n) + l15;
 #pragma unroll
                             for (int v = 0; v < 4; ++v)
                                 if (k0 + kq + 4 * v < r && q < nq) atomicAdd(&x[xr[v] * sr + (q0 + q) * sq], -acc[v]);
@@ -486,15 +494,15 @@ __global__ __launch_bounds__(kThreads) void k_solve_small_mrhs(const SnDesc* __r
                 const int xrow = ri[row_l];
                 const bool rok = k0 + l15 < r;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    if (n < nfrag_n) {
+                for (int n = 0; n < kNh; ++n) {
+                    if (n0 + n < nfrag_n) {
                         double4_s acc = {0, 0, 0, 0};
 #pragma unroll
                         for (int st = 0; st < kSt; ++st)
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[n][st], lv[st], acc, 0, 0, 0);
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const int q = 16 * n + kq + 4 * v;
+                            const int q = 16 * (n0 + n) + kq + 4 * v;
                             if (rok && q < nq) atomicAdd(&x[xrow * sr + (q0 + q) * sq], -acc[v]);
                         }
                     }
@@ -524,6 +532,10 @@ void launch_solve_small(const DevicePattern& P, int first, int count, int wmax, 
             hipLaunchKernelGGL(k_solve_small_mrhs<32>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
                                P.rows, L, x, nrhs, ldx, ldq);
         else
+            if (count >= kSmallMrhsHalvesMin || nrhs <= 32)   // (at most 32 right-hand sides: one sweep either way, fewer registers)
+                hipLaunchKernelGGL((k_solve_small_mrhs<64, true>), dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges, P.rows, L, x,
+                                   nrhs, ldx, ldq);
+            else
             hipLaunchKernelGGL(k_solve_small_mrhs<64>, dim3(count), dim3(kThreads), 0, stream, P.sn, list, ranges,
                                P.rows, L, x, nrhs, ldx, ldq);
     } else {
